@@ -1,0 +1,93 @@
+/* amgh.h -- C ABI of the HOST setup library (libngsamg_host.so).
+ *
+ * Cold path: builds the frozen AMG hierarchy on the host, in the reference's CSR / block-CSR formats,
+ * which amgx_create (amgx.h) then uploads once.  It stands where the reference's setup layer stands:
+ *   BaseAMGPC::FinalizeLevel -> BuildAMGMat -> BaseAMGFactory::SetUpLevels
+ *   (reference src/base/precond/amg_pc.cpp:420-434, 565-736; src/base/factory/base_factory.cpp:219-525).
+ * All arrays handed out by amgh_level_get are owned by the hierarchy handle and stay valid until
+ * amgh_destroy; arrays passed in are borrowed for the duration of the call only.
+ *
+ * Every function returns 0 on success, non-zero on error (message via amgh_last_error()); the Python
+ * shim rethrows, like the reference's ngcore::Exception -> RuntimeError path.
+ */
+#ifndef NGSAMG_AMGH_H
+#define NGSAMG_AMGH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* (block-)CSR matrix view; layout of NGSolve's SparseMatrix<Mat<br,bc>> */
+typedef struct amgh_matrix {
+  int64_t n_rows, n_cols;
+  int32_t br, bc;            /* block height / width                                  */
+  const int64_t* rowptr;     /* [n_rows+1]                                            */
+  const int32_t* col;        /* [nnz] ascending per row                               */
+  const double* val;         /* [nnz*br*bc] row-major blocks                          */
+} amgh_matrix;
+
+/* options = the ngs_amg_* flags that shape the hierarchy (reference amg_pc.cpp:270-339,
+ * base_factory.cpp:23-59, h1_impl.hpp:300-370, elasticity_pc_impl.hpp:36-142) */
+typedef struct amgh_options {
+  int32_t max_levels;        /* ngs_amg_max_levels        (10)                        */
+  int64_t max_coarse_size;   /* ngs_amg_max_coarse_size   (50)                        */
+  double first_aaf;          /* ngs_amg_first_aaf         (0.05 3D / 0.1 2D)          */
+  double aaf;                /* ngs_amg_aaf               (2^-dim)                    */
+  int32_t enable_sp;         /* ngs_amg_enable_sp         (1)                         */
+  double sp_omega;           /* ngs_amg_sp_omega          (1.0)                       */
+  int32_t sp_max_per_row;    /* ngs_amg_sp_max_per_row    (3; 1+dim elasticity)       */
+  double sp_min_frac;        /* ngs_amg_sp_min_frac       (0.08 3D / 0.15 2D)         */
+  double soc_thresh;         /* pairwise strength threshold (own; 0.25)               */
+  int32_t max_rounds;        /* cap of pairwise rounds per level (own; 8)             */
+  int32_t regularize_cmats;  /* ngs_amg_regularize_cmats  => pseudo-inverse diagonals */
+  int32_t dim;               /* spatial dimension                                     */
+  int32_t energy;            /* 0 = H1 (h1_scal/h1_2d/h1_3d), 1 = elasticity          */
+  int32_t log_level;
+} amgh_options;
+
+typedef struct amgh_level {
+  amgh_matrix A, P, PT;      /* P / PT have n_rows == 0 on the coarsest level          */
+  const uint8_t* free;       /* [n] 1 = free block row                                 */
+  const double* dinv;        /* [n*bs*bs] inverted (block) diagonal, 0 for non-free    */
+  const double* coords;      /* [n*dim] or NULL                                        */
+  const int32_t* color;      /* [n] greedy colour of free rows, -1 otherwise           */
+  int32_t n_colors;
+  const int32_t* agg;        /* [n] vertex -> coarse vertex or -1 (NULL on coarsest)   */
+} amgh_level;
+
+typedef struct amgh_hierarchy amgh_hierarchy;
+
+const char* amgh_last_error(void);
+void amgh_default_options(amgh_options* o, int dim, int energy);
+
+int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
+               const amgh_options* opts, amgh_hierarchy** out);
+int amgh_n_levels(const amgh_hierarchy* h);
+int amgh_level_get(const amgh_hierarchy* h, int level, amgh_level* out);
+/* dense inverse of the coarsest matrix restricted to free dofs; n = scalar size (0 if unavailable) */
+int amgh_coarse_inverse(const amgh_hierarchy* h, int64_t* n, const double** inv);
+const char* amgh_log(const amgh_hierarchy* h);
+void amgh_destroy(amgh_hierarchy* h);
+
+/* stand-alone smoother data (CreateJacobiSmoother / CreateHybridGSS mirrors,
+ * reference src/base/smoothers/python_smoothers.cpp:144-387) */
+int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, double* dinv_out);
+int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors);
+
+/* sparse helpers exposed for tests and the Python utils mirror (SparseMM, reference python_utils.cpp:30-193) */
+int amgh_transpose_count(const amgh_matrix* A, int64_t* rowptr_out /*[n_cols+1]*/);
+int amgh_transpose_fill(const amgh_matrix* A, const int64_t* rowptr_T, int32_t* col_out, double* val_out);
+/* C = A*B in two calls: first with col_out == NULL to obtain rowptr (size n_rows+1), then fill */
+int amgh_matmul(const amgh_matrix* A, const amgh_matrix* B, int64_t* rowptr_out, int32_t* col_out, double* val_out);
+
+/* synthetic P1 problems on Kuhn grids (stand-in for the calling FEM package) */
+int amgh_kuhn_pattern(int dim, const int64_t* shape, int64_t* rowptr_out);
+int amgh_kuhn_assemble(int dim, const int64_t* shape, const double* coords, int kind, int bs, double mu, double lam,
+                       const double* cell_coef_or_null, const int64_t* rowptr, int32_t* col_out, double* val_out,
+                       double* load_out_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,167 @@
+"""ctypes bindings of the two native libraries (include/amgh.h, include/amgx.h).
+
+The libraries are built in-tree by ``__graft_entry__.build()``.  There is deliberately no Python or CPU
+fallback for the device library: if ``libngsamg_hip.so`` is missing or fails to load, every use of the
+apply path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class NgsAMGError(RuntimeError):
+    """Raised for every non-zero return of the native libraries (the reference throws
+    ngcore::Exception, surfaced to Python as RuntimeError)."""
+
+
+# ---------------------------------------------------------------------------------------------
+# host library
+# ---------------------------------------------------------------------------------------------
+
+class amgh_matrix(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("br", C.c_int32), ("bc", C.c_int32),
+                ("rowptr", c_i64p), ("col", c_i32p), ("val", c_f64p)]
+
+
+class amgh_options(C.Structure):
+    _fields_ = [("max_levels", C.c_int32), ("max_coarse_size", C.c_int64), ("first_aaf", C.c_double),
+                ("aaf", C.c_double), ("enable_sp", C.c_int32), ("sp_omega", C.c_double),
+                ("sp_max_per_row", C.c_int32), ("sp_min_frac", C.c_double), ("soc_thresh", C.c_double),
+                ("max_rounds", C.c_int32), ("regularize_cmats", C.c_int32), ("dim", C.c_int32),
+                ("energy", C.c_int32), ("log_level", C.c_int32)]
+
+
+class amgh_level(C.Structure):
+    _fields_ = [("A", amgh_matrix), ("P", amgh_matrix), ("PT", amgh_matrix), ("free", c_u8p),
+                ("dinv", c_f64p), ("coords", c_f64p), ("color", c_i32p), ("n_colors", C.c_int32),
+                ("agg", c_i32p)]
+
+
+_host = None
+_hip = None
+
+
+def _load(name):
+    path = os.path.join(LIBDIR, name)
+    if not os.path.exists(path):
+        raise NgsAMGError(f"{path} not found - run `python __graft_entry__.py` (build()) first")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def host():
+    global _host
+    if _host is not None:
+        return _host
+    lib = _load("libngsamg_host.so")
+    vp = C.c_void_p
+    lib.amgh_last_error.restype = C.c_char_p
+    lib.amgh_default_options.argtypes = [C.POINTER(amgh_options), C.c_int, C.c_int]
+    lib.amgh_default_options.restype = None
+    lib.amgh_setup.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_f64p, C.POINTER(amgh_options), C.POINTER(vp)]
+    lib.amgh_n_levels.argtypes = [vp]
+    lib.amgh_level_get.argtypes = [vp, C.c_int, C.POINTER(amgh_level)]
+    lib.amgh_coarse_inverse.argtypes = [vp, c_i64p, C.POINTER(c_f64p)]
+    lib.amgh_log.argtypes = [vp]
+    lib.amgh_log.restype = C.c_char_p
+    lib.amgh_destroy.argtypes = [vp]
+    lib.amgh_destroy.restype = None
+    lib.amgh_calc_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int, c_f64p]
+    lib.amgh_coloring.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_i32p, c_i32p]
+    lib.amgh_transpose_count.argtypes = [C.POINTER(amgh_matrix), c_i64p]
+    lib.amgh_transpose_fill.argtypes = [C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
+    lib.amgh_matmul.argtypes = [C.POINTER(amgh_matrix), C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
+    lib.amgh_kuhn_pattern.argtypes = [C.c_int, c_i64p, c_i64p]
+    lib.amgh_kuhn_assemble.argtypes = [C.c_int, c_i64p, c_f64p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       c_f64p, c_i64p, c_i32p, c_f64p, c_f64p]
+    _host = lib
+    return lib
+
+
+def hcheck(rc):
+    if rc != 0:
+        raise NgsAMGError(host().amgh_last_error().decode())
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy <-> ctypes helpers
+# ---------------------------------------------------------------------------------------------
+
+def ptr(a, ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_array(p, n, dtype):
+    """numpy view (no copy) of n items behind a ctypes pointer; None for NULL / n == 0."""
+    if not p or n == 0:
+        return np.empty(0, dtype=dtype)
+    return np.ctypeslib.as_array(p, shape=(int(n),)).view(dtype)
+
+
+class Matrix:
+    """(block-)CSR matrix on the host: int64 rowptr, int32 col, fp64 row-major blocks."""
+
+    def __init__(self, n_rows, n_cols, br, bc, rowptr, col, val, owner=None):
+        self.n_rows, self.n_cols, self.br, self.bc = int(n_rows), int(n_cols), int(br), int(bc)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.col = np.ascontiguousarray(col, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64).reshape(-1)
+        self._owner = owner     # keeps the native hierarchy alive for zero-copy views
+        if self.rowptr.shape[0] != self.n_rows + 1:
+            raise NgsAMGError("Matrix: rowptr has wrong length")
+        if self.col.shape[0] != self.nnz or self.val.shape[0] != self.nnz * self.br * self.bc:
+            raise NgsAMGError("Matrix: col/val have wrong length")
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1]) if self.rowptr.size else 0
+
+    @property
+    def shape(self):
+        return (self.n_rows * self.br, self.n_cols * self.bc)
+
+    def desc(self, cls=amgh_matrix):
+        d = cls()
+        d.n_rows, d.n_cols, d.br, d.bc = self.n_rows, self.n_cols, self.br, self.bc
+        d.rowptr = ptr(self.rowptr, C.c_int64)
+        d.col = ptr(self.col, C.c_int32)
+        d.val = ptr(self.val, C.c_double)
+        return d
+
+    @classmethod
+    def from_desc(cls, d, owner):
+        if d.n_rows == 0 and not d.rowptr:
+            return None
+        rowptr = as_array(d.rowptr, d.n_rows + 1, np.int64)
+        nnz = int(rowptr[-1])
+        return cls(d.n_rows, d.n_cols, d.br, d.bc, rowptr, as_array(d.col, nnz, np.int32),
+                   as_array(d.val, nnz * d.br * d.bc, np.float64), owner=owner)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        if self.br == 1 and self.bc == 1:
+            return sp.csr_matrix((self.val, self.col, self.rowptr), shape=self.shape)
+        return sp.bsr_matrix((self.val.reshape(-1, self.br, self.bc), self.col, self.rowptr), shape=self.shape).tocsr()
+
+    @classmethod
+    def from_scipy(cls, A, bs=1):
+        import scipy.sparse as sp
+        if bs == 1:
+            A = sp.csr_matrix(A)
+            A.sort_indices()
+            return cls(A.shape[0], A.shape[1], 1, 1, A.indptr, A.indices, A.data)
+        B = sp.bsr_matrix(A, blocksize=(bs, bs))
+        B.sort_indices()
+        return cls(B.shape[0] // bs, B.shape[1] // bs, bs, bs, B.indptr, B.indices, B.data)

@@ -1,0 +1,193 @@
+// C ABI of the host setup library, see include/amgh.h.
+#include "../../../include/amgh.h"
+#include "hierarchy.hpp"
+#include <cstring>
+#include <memory>
+
+struct amgh_hierarchy { std::unique_ptr<amgh::Hierarchy> h; };
+
+namespace amgh {
+void kuhn_pattern(int dim, const int64_t* shape, int64_t* rowptr);
+void kuhn_assemble(int dim, const int64_t* shape, const double* coords, int kind, int bs, double mu, double lam,
+                   const double* cell_coef, const int64_t* rowptr, int32_t* col, double* val, double* load);
+}
+
+namespace {
+thread_local std::string g_err;
+thread_local std::unique_ptr<amgh::BCSR> g_mm_cache;
+
+amgh::BCSR to_bcsr(const amgh_matrix* m) {
+  amgh::BCSR A;
+  A.n_rows = m->n_rows; A.n_cols = m->n_cols; A.br = m->br; A.bc = m->bc;
+  A.rowptr.assign(m->rowptr, m->rowptr + m->n_rows + 1);
+  const int64_t nnz = A.rowptr.back();
+  A.col.assign(m->col, m->col + nnz);
+  A.val.assign(m->val, m->val + nnz * m->br * m->bc);
+  return A;
+}
+
+void view(const amgh::BCSR& A, amgh_matrix* m) {
+  m->n_rows = A.n_rows; m->n_cols = A.n_cols; m->br = A.br; m->bc = A.bc;
+  m->rowptr = A.rowptr.data(); m->col = A.col.data(); m->val = A.val.data();
+}
+
+template <class F>
+int guard(F&& f) {
+  try { f(); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return 1; }
+  catch (...) { g_err = "unknown error"; return 2; }
+}
+
+void check_matrix(const amgh_matrix* m) {
+  if (!m || !m->rowptr || m->n_rows < 0 || m->n_cols < 0) throw amgh::Error("invalid matrix descriptor");
+  if (m->br < 1 || m->bc < 1 || m->br > 6 || m->bc > 6) throw amgh::Error("unsupported block size (1..6)");
+  if (m->rowptr[m->n_rows] > 0 && (!m->col || !m->val)) throw amgh::Error("matrix descriptor lacks col/val");
+}
+}  // namespace
+
+extern "C" {
+
+const char* amgh_last_error(void) { return g_err.c_str(); }
+
+void amgh_default_options(amgh_options* o, int dim, int energy) {
+  amgh::Options d;
+  o->max_levels = d.max_levels;
+  o->max_coarse_size = d.max_coarse_size;
+  if (energy == 1) { o->first_aaf = dim == 3 ? 0.025 : 0.05; o->sp_max_per_row = 1 + dim; }
+  else { o->first_aaf = dim == 3 ? 0.05 : 0.1; o->sp_max_per_row = 3; }
+  o->aaf = dim == 3 ? 0.125 : 0.25;
+  o->enable_sp = 1;
+  o->sp_omega = 1.0;
+  o->sp_min_frac = dim == 3 ? 0.08 : 0.15;
+  o->soc_thresh = d.soc_thresh;
+  o->max_rounds = d.max_rounds;
+  o->regularize_cmats = 0;
+  o->dim = dim;
+  o->energy = energy;
+  o->log_level = 0;
+}
+
+int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
+               const amgh_options* opts, amgh_hierarchy** out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->n_rows != A->n_cols || A->br != A->bc) throw amgh::Error("amgh_setup: matrix must be square with square blocks");
+    if (!opts || !out) throw amgh::Error("amgh_setup: null argument");
+    amgh::Options o;
+    o.max_levels = opts->max_levels; o.max_coarse_size = opts->max_coarse_size;
+    o.first_aaf = opts->first_aaf; o.aaf = opts->aaf; o.enable_sp = opts->enable_sp;
+    o.sp_omega = opts->sp_omega; o.sp_max_per_row = opts->sp_max_per_row; o.sp_min_frac = opts->sp_min_frac;
+    o.soc_thresh = opts->soc_thresh; o.max_rounds = opts->max_rounds; o.regularize_cmats = opts->regularize_cmats;
+    o.dim = opts->dim; o.energy = opts->energy; o.log_level = opts->log_level;
+    if (o.max_levels < 1) throw amgh::Error("amgh_setup: max_levels must be >= 1");
+    if (o.dim != 2 && o.dim != 3) throw amgh::Error("amgh_setup: dim must be 2 or 3");
+    amgh::BCSR A0 = to_bcsr(A);
+    auto h = new amgh_hierarchy();
+    h->h.reset(amgh::setup_levels(A0, free_or_null, coords_or_null, o));
+    *out = h;
+  });
+}
+
+int amgh_n_levels(const amgh_hierarchy* h) { return h ? (int)h->h->levels.size() : 0; }
+
+int amgh_level_get(const amgh_hierarchy* h, int level, amgh_level* out) {
+  return guard([&] {
+    if (!h || !out || level < 0 || level >= (int)h->h->levels.size()) throw amgh::Error("amgh_level_get: bad level");
+    const amgh::Level& L = h->h->levels[level];
+    std::memset(out, 0, sizeof(*out));
+    view(L.A, &out->A);
+    if (L.P.n_rows > 0) { view(L.P, &out->P); view(L.PT, &out->PT); }
+    out->free = L.free.data();
+    out->dinv = L.dinv.data();
+    out->coords = L.coords.empty() ? nullptr : L.coords.data();
+    out->color = L.color.data();
+    out->n_colors = L.n_colors;
+    out->agg = L.agg.empty() ? nullptr : L.agg.data();
+  });
+}
+
+int amgh_coarse_inverse(const amgh_hierarchy* h, int64_t* n, const double** inv) {
+  return guard([&] {
+    if (!h || !n || !inv) throw amgh::Error("amgh_coarse_inverse: null argument");
+    *n = h->h->coarse_n;
+    *inv = h->h->coarse_n ? h->h->coarse_inv.data() : nullptr;
+  });
+}
+
+const char* amgh_log(const amgh_hierarchy* h) { return h ? h->h->log.c_str() : ""; }
+
+void amgh_destroy(amgh_hierarchy* h) { delete h; }
+
+int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, double* dinv_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->br != A->bc) throw amgh::Error("amgh_calc_dinv: square blocks required");
+    amgh::BCSR M = to_bcsr(A);
+    amgh::calc_dinv(M, free_or_null, pinv != 0, dinv_out);
+  });
+}
+
+int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors) {
+  return guard([&] {
+    check_matrix(A);
+    amgh::BCSR M = to_bcsr(A);
+    *n_colors = amgh::greedy_coloring(M, free_or_null, color_out);
+  });
+}
+
+int amgh_transpose_count(const amgh_matrix* A, int64_t* rowptr_out) {
+  return guard([&] {
+    check_matrix(A);
+    for (int64_t i = 0; i <= A->n_cols; i++) rowptr_out[i] = 0;
+    const int64_t nnz = A->rowptr[A->n_rows];
+    for (int64_t k = 0; k < nnz; k++) rowptr_out[A->col[k] + 1]++;
+    for (int64_t i = 0; i < A->n_cols; i++) rowptr_out[i + 1] += rowptr_out[i];
+  });
+}
+
+int amgh_transpose_fill(const amgh_matrix* A, const int64_t* rowptr_T, int32_t* col_out, double* val_out) {
+  return guard([&] {
+    check_matrix(A);
+    amgh::BCSR T = amgh::transpose(to_bcsr(A));
+    if (T.rowptr.back() != rowptr_T[A->n_cols]) throw amgh::Error("amgh_transpose_fill: rowptr mismatch");
+    std::memcpy(col_out, T.col.data(), T.col.size() * sizeof(int32_t));
+    std::memcpy(val_out, T.val.data(), T.val.size() * sizeof(double));
+  });
+}
+
+int amgh_matmul(const amgh_matrix* A, const amgh_matrix* B, int64_t* rowptr_out, int32_t* col_out, double* val_out) {
+  return guard([&] {
+    check_matrix(A); check_matrix(B);
+    if (!col_out) {
+      g_mm_cache.reset(new amgh::BCSR(amgh::matmul(to_bcsr(A), to_bcsr(B))));
+      std::memcpy(rowptr_out, g_mm_cache->rowptr.data(), g_mm_cache->rowptr.size() * sizeof(int64_t));
+    } else {
+      if (!g_mm_cache) throw amgh::Error("amgh_matmul: fill call without a preceding count call");
+      std::memcpy(col_out, g_mm_cache->col.data(), g_mm_cache->col.size() * sizeof(int32_t));
+      std::memcpy(val_out, g_mm_cache->val.data(), g_mm_cache->val.size() * sizeof(double));
+      g_mm_cache.reset();
+    }
+  });
+}
+
+int amgh_kuhn_pattern(int dim, const int64_t* shape, int64_t* rowptr_out) {
+  return guard([&] {
+    if (dim != 2 && dim != 3) throw amgh::Error("kuhn: dim must be 2 or 3");
+    for (int d = 0; d < dim; d++) if (shape[d] < 2) throw amgh::Error("kuhn: need at least 2 vertices per direction");
+    amgh::kuhn_pattern(dim, shape, rowptr_out);
+  });
+}
+
+int amgh_kuhn_assemble(int dim, const int64_t* shape, const double* coords, int kind, int bs, double mu, double lam,
+                       const double* cell_coef_or_null, const int64_t* rowptr, int32_t* col_out, double* val_out,
+                       double* load_out_or_null) {
+  return guard([&] {
+    if (dim != 2 && dim != 3) throw amgh::Error("kuhn: dim must be 2 or 3");
+    const int nrot = dim * (dim - 1) / 2;
+    if ((kind == 0 && bs != 1) || (kind == 1 && bs != dim) || (kind == 2 && bs != dim + nrot) || kind < 0 || kind > 2)
+      throw amgh::Error("kuhn: kind / block size mismatch");
+    amgh::kuhn_assemble(dim, shape, coords, kind, bs, mu, lam, cell_coef_or_null, rowptr, col_out, val_out, load_out_or_null);
+  });
+}
+
+}  // extern "C"

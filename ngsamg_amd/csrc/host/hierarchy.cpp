@@ -1,0 +1,456 @@
+// Host AMG setup (cold path).  What it restates from the reference, in simplified form:
+//   * strength graph from matrix entries: edge weight |trace-like(A_ij)|
+//       (src/h1/h1_impl.hpp:383-429 BuildAlgMesh_ALG_scal)
+//   * successive pairwise agglomeration in rounds until the level's coarsening target is met
+//       (SPW: src/base/coarsening/spw_agg.hpp:21-85; targets first_aaf / aaf: h1_impl.hpp:333-334)
+//   * Dirichlet vertices are dropped from the coarse space (free_verts; amg_pc_vertex_impl.hpp)
+//   * piecewise prolongation, then one smoothing step with the auxiliary (edge-weight) matrix,
+//       truncated to sp_max_per_row entries (vertex_factory_impl.hpp:1601-1659, 2440-2751)
+//   * elasticity: rigid-body prolongation blocks Q = [I, -skew(t); 0, I]
+//       (src/elasticity/elasticity_energy.hpp:447-490), displacement-only fine level embeds with 3x6 blocks
+//       (elasticity_pc_impl.hpp:668-685)
+//   * Galerkin coarse matrices (P^T A) P (utils_sparseMM.hpp:93-109), explicit P^T (utils_sparseMM.cpp:54-93)
+//   * stop rule: max_levels / max_coarse_size (base_factory.cpp:339-340)
+//   * smoother diagonals (gssmoother.cpp:143-170) and the coarsest-level inverse (amg_pc.cpp:843-928)
+// Bit-identical aggregates w.r.t. the reference are neither attainable (no NGSolve/netgen) nor needed for
+// apply-path parity; the apply path only consumes the frozen arrays produced here.
+#include "hierarchy.hpp"
+#include <omp.h>
+#include <cmath>
+#include <algorithm>
+#include <numeric>
+#include <sstream>
+
+namespace amgh {
+
+namespace {
+
+struct Graph {
+  int64_t n = 0;
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> adj;
+  std::vector<double> w;
+};
+
+Graph strength_graph(const BCSR& A, const std::vector<uint8_t>& free, int dim, int energy) {
+  Graph G;
+  G.n = A.n_rows;
+  const int bs = A.br;
+  const int sub = (energy == 1) ? std::min(dim, bs) : bs;   // elasticity: displacement-displacement part only
+  std::vector<int64_t> cnt(G.n + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < G.n; i++) {
+    int64_t c = 0;
+    if (free[i])
+      for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) { int32_t j = A.col[k]; if (j != i && free[j]) c++; }
+    cnt[i + 1] = c;
+  }
+  G.ptr.assign(G.n + 1, 0);
+  for (int64_t i = 0; i < G.n; i++) G.ptr[i + 1] = G.ptr[i] + cnt[i + 1];
+  G.adj.resize(G.ptr[G.n]);
+  G.w.resize(G.ptr[G.n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < G.n; i++) {
+    if (!free[i]) continue;
+    int64_t p = G.ptr[i];
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+      int32_t j = A.col[k];
+      if (j == i || !free[j]) continue;
+      const double* b = &A.val[k * bs * bs];
+      double w;
+      if (bs == 1) w = std::fabs(b[0]);
+      else {
+        double s = 0;
+        for (int r = 0; r < sub; r++) for (int c = 0; c < sub; c++) s += b[r * bs + c] * b[r * bs + c];
+        w = std::sqrt(s);
+      }
+      G.adj[p] = j; G.w[p] = w; p++;
+    }
+  }
+  return G;
+}
+
+// One pairwise matching round.  map[i] = new vertex id.  Returns the number of new vertices.
+int64_t pairwise_round(const Graph& G, const std::vector<uint8_t>& active, double thresh, std::vector<int32_t>& map) {
+  const int64_t n = G.n;
+  std::vector<double> mx(n, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    double m = 0;
+    for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) m = std::max(m, G.w[k]);
+    mx[i] = m;
+  }
+  map.assign(n, -1);
+  int64_t nn = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!active[i] || map[i] >= 0) continue;
+    int32_t best = -1;
+    double bs = 0;
+    for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+      int32_t j = G.adj[k];
+      if (map[j] >= 0 || !active[j]) continue;
+      double d = mx[i] * mx[j];
+      if (d <= 0) continue;
+      double s = G.w[k] / std::sqrt(d);
+      if (s >= thresh && s > bs) { bs = s; best = j; }
+    }
+    map[i] = (int32_t)nn;
+    if (best >= 0) map[best] = (int32_t)nn;
+    nn++;
+  }
+  return nn;
+}
+
+// Contract a graph along map (values in [0, nn)); vertices with map < 0 are dropped. Edge weights are summed.
+Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
+  // member lists
+  std::vector<int64_t> mptr(nn + 1, 0);
+  for (int64_t i = 0; i < G.n; i++) if (map[i] >= 0) mptr[map[i] + 1]++;
+  for (int64_t I = 0; I < nn; I++) mptr[I + 1] += mptr[I];
+  std::vector<int32_t> mem(mptr[nn]);
+  {
+    std::vector<int64_t> pos(mptr.begin(), mptr.end() - 1);
+    for (int64_t i = 0; i < G.n; i++) if (map[i] >= 0) mem[pos[map[i]]++] = (int32_t)i;
+  }
+  Graph C;
+  C.n = nn;
+  const int nt = omp_get_max_threads();
+  std::vector<std::vector<int32_t>> tadj(nt);
+  std::vector<std::vector<double>> tw(nt);
+  std::vector<int64_t> len(nn, 0), tstart(nt + 1);
+  for (int t = 0; t <= nt; t++) tstart[t] = (nn * t) / nt;
+#pragma omp parallel num_threads(nt)
+  {
+    int t = omp_get_thread_num();
+    std::vector<int64_t> owner(nn, -1);
+    std::vector<int32_t> slot(nn, 0);
+    std::vector<int32_t> cols;
+    std::vector<double> acc;
+    std::vector<int32_t> order;
+    for (int64_t I = tstart[t]; I < tstart[t + 1]; I++) {
+      cols.clear(); acc.clear();
+      for (int64_t m = mptr[I]; m < mptr[I + 1]; m++) {
+        int32_t i = mem[m];
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          int32_t J = map[G.adj[k]];
+          if (J < 0 || J == I) continue;
+          if (owner[J] != I) { owner[J] = I; slot[J] = (int32_t)cols.size(); cols.push_back(J); acc.push_back(G.w[k]); }
+          else acc[slot[J]] += G.w[k];
+        }
+      }
+      order.resize(cols.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cols[a] < cols[b]; });
+      for (auto q : order) { tadj[t].push_back(cols[q]); tw[t].push_back(acc[q]); }
+      len[I] = (int64_t)cols.size();
+    }
+  }
+  C.ptr.assign(nn + 1, 0);
+  for (int64_t I = 0; I < nn; I++) C.ptr[I + 1] = C.ptr[I] + len[I];
+  C.adj.resize(C.ptr[nn]);
+  C.w.resize(C.ptr[nn]);
+  for (int t = 0; t < nt; t++) {
+    int64_t off = C.ptr[tstart[t]];
+    std::copy(tadj[t].begin(), tadj[t].end(), C.adj.begin() + off);
+    std::copy(tw[t].begin(), tw[t].end(), C.w.begin() + off);
+  }
+  return C;
+}
+
+// Aggregation for one level: repeated pairwise rounds until n_agg <= target * n_free.
+// Returns agg (fine vertex -> aggregate or -1) and the number of aggregates.
+int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double target, const Options& o,
+                  std::vector<int32_t>& agg, int& rounds_done) {
+  const int64_t n = G0.n;
+  int64_t nfree = 0;
+  for (int64_t i = 0; i < n; i++) nfree += free[i] ? 1 : 0;
+  agg.assign(n, -1);
+  if (nfree == 0) return 0;
+  // round 0 works on the fine graph restricted to free vertices
+  std::vector<int32_t> map;
+  Graph cur;              // current contracted graph (empty => use G0)
+  const Graph* g = &G0;
+  std::vector<uint8_t> active(free.begin(), free.end());
+  std::vector<int32_t> size;   // fine vertices per current vertex
+  int64_t ncur = nfree;
+  bool first = true;
+  rounds_done = 0;
+  for (int round = 0; round < o.max_rounds; round++) {
+    if (!first && (double)ncur <= target * (double)nfree) break;
+    int64_t nn = pairwise_round(*g, active, o.soc_thresh, map);
+    if (!first && nn > 0.97 * ncur) { break; }   // stuck: no more viable partners
+    // compose
+    if (first) {
+      for (int64_t i = 0; i < n; i++) agg[i] = free[i] ? map[i] : -1;
+    } else {
+      for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = map[agg[i]];
+    }
+    Graph next = contract(*g, map, nn);
+    cur = std::move(next);
+    g = &cur;
+    active.assign(nn, 1);
+    ncur = nn;
+    first = false;
+    rounds_done++;
+  }
+  if (first) return 0;
+  // orphan round: aggregates made of a single fine vertex join their strongest neighbour
+  size.assign(ncur, 0);
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) size[agg[i]]++;
+  std::vector<int32_t> remap(ncur);
+  std::iota(remap.begin(), remap.end(), 0);
+  for (int64_t I = 0; I < ncur; I++) {
+    if (size[I] != 1 || remap[I] != I) continue;
+    int32_t best = -1;
+    double bw = 0;
+    for (int64_t k = cur.ptr[I]; k < cur.ptr[I + 1]; k++) {
+      int32_t J = remap[cur.adj[k]];
+      if (J == I) continue;
+      if (cur.w[k] > bw) { bw = cur.w[k]; best = J; }
+    }
+    if (best >= 0) { remap[I] = best; size[best] += 1; size[I] = 0; }
+  }
+  // path-compress and renumber
+  std::vector<int32_t> newid(ncur, -1);
+  int64_t nn = 0;
+  for (int64_t I = 0; I < ncur; I++) {
+    int32_t r = remap[I];
+    while (remap[r] != r) r = remap[r];
+    remap[I] = r;
+  }
+  for (int64_t I = 0; I < ncur; I++) if (remap[I] == I) newid[I] = (int32_t)nn++;
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = newid[remap[agg[i]]];
+  return nn;
+}
+
+// scalar prolongation weights (n_f x n_c CSR): aux-matrix smoothed piecewise prolongation
+BCSR prolongation_weights(const Graph& G0, const std::vector<int32_t>& agg, int64_t nc, const Options& o) {
+  const int64_t n = G0.n;
+  BCSR W;
+  W.n_rows = n; W.n_cols = nc; W.br = W.bc = 1;
+  const int maxr = std::max(1, o.sp_max_per_row);
+  std::vector<int32_t> cols((size_t)n * maxr);
+  std::vector<double> vals((size_t)n * maxr);
+  std::vector<int32_t> len(n, 0);
+#pragma omp parallel
+  {
+    std::vector<std::pair<int32_t, double>> cand;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+      const int32_t I = agg[i];
+      if (I < 0) continue;
+      cand.clear();
+      double total = 0;
+      if (o.enable_sp)
+        for (int64_t k = G0.ptr[i]; k < G0.ptr[i + 1]; k++) {
+          int32_t J = agg[G0.adj[k]];
+          if (J < 0) continue;
+          total += G0.w[k];
+          bool found = false;
+          for (auto& c : cand) if (c.first == J) { c.second += G0.w[k]; found = true; break; }
+          if (!found) cand.push_back({J, G0.w[k]});
+        }
+      int32_t* oc = &cols[(size_t)i * maxr];
+      double* ov = &vals[(size_t)i * maxr];
+      if (total <= 0) { oc[0] = I; ov[0] = 1.0; len[i] = 1; continue; }
+      for (auto& c : cand) c.second *= o.sp_omega / total;
+      if (o.sp_omega != 1.0) {
+        bool found = false;
+        for (auto& c : cand) if (c.first == I) { c.second += 1.0 - o.sp_omega; found = true; break; }
+        if (!found) cand.push_back({I, 1.0 - o.sp_omega});
+      }
+      std::sort(cand.begin(), cand.end(), [](auto& a, auto& b) { return a.second > b.second || (a.second == b.second && a.first < b.first); });
+      int keep = 0;
+      double s = 0;
+      for (auto& c : cand) {
+        if (keep >= maxr) break;
+        if (keep > 0 && c.second < o.sp_min_frac) break;
+        keep++; s += c.second;
+      }
+      std::sort(cand.begin(), cand.begin() + keep, [](auto& a, auto& b) { return a.first < b.first; });
+      for (int q = 0; q < keep; q++) { oc[q] = cand[q].first; ov[q] = cand[q].second / s; }
+      len[i] = keep;
+    }
+  }
+  W.rowptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; i++) W.rowptr[i + 1] = W.rowptr[i] + len[i];
+  W.col.resize(W.rowptr[n]);
+  W.val.resize(W.rowptr[n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int q = 0; q < len[i]; q++) { W.col[W.rowptr[i] + q] = cols[(size_t)i * maxr + q]; W.val[W.rowptr[i] + q] = vals[(size_t)i * maxr + q]; }
+  return W;
+}
+
+// block prolongation from scalar weights
+BCSR block_prolongation(const BCSR& W, int bs_f, int bs_c, int dim, int energy,
+                        const std::vector<double>& xf, const std::vector<double>& xc) {
+  if (bs_f == 1 && bs_c == 1) return W;
+  BCSR P;
+  P.n_rows = W.n_rows; P.n_cols = W.n_cols; P.br = bs_f; P.bc = bs_c;
+  P.rowptr = W.rowptr; P.col = W.col;
+  P.val.assign((size_t)W.nnz() * bs_f * bs_c, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < W.n_rows; i++)
+    for (int64_t k = W.rowptr[i]; k < W.rowptr[i + 1]; k++) {
+      double* b = &P.val[(size_t)k * bs_f * bs_c];
+      const double w = W.val[k];
+      if (energy == 0) {
+        for (int r = 0; r < std::min(bs_f, bs_c); r++) b[r * bs_c + r] = w;
+        continue;
+      }
+      // rigid body block: displacement rows [I, R(t)], rotation rows [0, I]; u = u_c + w_c x t
+      const int32_t J = W.col[k];
+      double t[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) t[d] = xf[i * dim + d] - xc[(int64_t)J * dim + d];
+      for (int r = 0; r < dim; r++) b[r * bs_c + r] = w;
+      if (dim == 2) {
+        if (bs_c > 2) { b[0 * bs_c + 2] = -w * t[1]; b[1 * bs_c + 2] = w * t[0]; }
+        if (bs_f > 2) b[2 * bs_c + 2] = w;
+      } else {
+        if (bs_c > 3) {
+          b[0 * bs_c + 4] = w * t[2];  b[0 * bs_c + 5] = -w * t[1];
+          b[1 * bs_c + 3] = -w * t[2]; b[1 * bs_c + 5] = w * t[0];
+          b[2 * bs_c + 3] = w * t[1];  b[2 * bs_c + 4] = -w * t[0];
+        }
+        for (int r = dim; r < bs_f; r++) b[r * bs_c + r] = w;
+      }
+    }
+  return P;
+}
+
+}  // namespace
+
+void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv) {
+  const int bs = A.br, bb = bs * bs;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < A.n_rows; i++) {
+    double* d = &dinv[i * bb];
+    for (int q = 0; q < bb; q++) d[q] = 0.0;
+    if (free && !free[i]) continue;
+    const double* blk = nullptr;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { blk = &A.val[k * bb]; break; }
+    if (!blk) continue;
+    for (int q = 0; q < bb; q++) d[q] = blk[q];
+    if (pinv) pseudo_inverse_try_normal(d, bs);
+    else if (bs == 1) d[0] = 1.0 / d[0];
+    else if (!dense_inverse(d, bs)) pseudo_inverse_try_normal(d, bs);
+  }
+}
+
+int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color) {
+  const int64_t n = A.n_rows;
+  int ncol = 0;
+  std::vector<int64_t> mark(64, -1);
+  for (int64_t i = 0; i < n; i++) {
+    color[i] = -1;
+    if (free && !free[i]) continue;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+      int32_t j = A.col[k];
+      if (j >= i) continue;          // only already-coloured (lower) neighbours matter
+      int32_t c = color[j];
+      if (c >= 0) { if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1); mark[c] = i; }
+    }
+    int c = 0;
+    while (c < (int)mark.size() && mark[c] == i) c++;
+    if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1);
+    color[i] = c;
+    ncol = std::max(ncol, c + 1);
+  }
+  return ncol;
+}
+
+Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coords0, const Options& o) {
+  auto H = new Hierarchy();
+  H->opts = o;
+  std::ostringstream log;
+  const int dim = o.dim;
+  const int nrot = (dim * (dim - 1)) / 2;
+  H->levels.emplace_back();
+  {
+    Level& L = H->levels.back();
+    L.A = A0;
+    L.free.assign(A0.n_rows, 1);
+    if (free0) std::copy(free0, free0 + A0.n_rows, L.free.begin());
+    if (coords0) L.coords.assign(coords0, coords0 + A0.n_rows * dim);
+    else if (o.energy == 1) throw Error("elasticity setup needs vertex coordinates");
+  }
+  while (true) {
+    const int lev = (int)H->levels.size() - 1;
+    Level& F = H->levels[lev];
+    const int64_t nf = F.A.n_rows;
+    int64_t nfree = 0;
+    for (auto f : F.free) nfree += f;
+    log << "level " << lev << ": n=" << nf << " bs=" << F.A.br << " nnz=" << F.A.nnz() << " free=" << nfree << "\n";
+    if (lev + 1 >= o.max_levels) break;
+    if (lev > 0 && nf <= o.max_coarse_size) break;
+    if (lev == 0 && nfree <= o.max_coarse_size && nfree == nf) break;
+    Graph G = strength_graph(F.A, F.free, dim, o.energy);
+    const double target = (lev == 0) ? o.first_aaf : o.aaf;
+    std::vector<int32_t> agg;
+    int rounds = 0;
+    int64_t nc = aggregate(G, F.free, target, o, agg, rounds);
+    if (nc == 0 || nc >= nfree) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
+    BCSR W = prolongation_weights(G, agg, nc, o);
+    const int bs_f = F.A.br;
+    const int bs_c = (o.energy == 1) ? dim + nrot : bs_f;
+    // coarse coordinates = mean of the aggregate's members
+    std::vector<double> xc;
+    if (!F.coords.empty()) {
+      xc.assign(nc * dim, 0.0);
+      std::vector<int32_t> cnt(nc, 0);
+      for (int64_t i = 0; i < nf; i++) if (agg[i] >= 0) { cnt[agg[i]]++; for (int d = 0; d < dim; d++) xc[(int64_t)agg[i] * dim + d] += F.coords[i * dim + d]; }
+      for (int64_t I = 0; I < nc; I++) for (int d = 0; d < dim; d++) xc[I * dim + d] /= std::max(1, cnt[I]);
+    }
+    F.P = block_prolongation(W, bs_f, bs_c, dim, o.energy, F.coords, xc);
+    F.PT = transpose(F.P);
+    F.agg = agg;
+    Level C;
+    C.A = restrict_matrix(F.PT, F.A, F.P);
+    C.free.assign(nc, 1);
+    C.coords = std::move(xc);
+    log << "  rounds=" << rounds << " nc=" << nc << " P nnz=" << F.P.nnz() << "\n";
+    H->levels.push_back(std::move(C));
+  }
+  // smoother data per level
+  for (auto& L : H->levels) {
+    L.dinv.resize((size_t)L.A.n_rows * L.A.br * L.A.br);
+    calc_dinv(L.A, L.free.data(), o.regularize_cmats != 0, L.dinv.data());
+    L.color.resize(L.A.n_rows);
+    L.n_colors = greedy_coloring(L.A, L.free.data(), L.color.data());
+  }
+  // coarsest-level inverse on the free dofs (zero rows/cols elsewhere), dense
+  {
+    Level& L = H->levels.back();
+    const int bs = L.A.br;
+    const int64_t N = L.A.n_rows * bs;
+    if (N <= 4096) {
+      std::vector<int64_t> fidx;
+      for (int64_t i = 0; i < L.A.n_rows; i++) if (L.free[i]) for (int c = 0; c < bs; c++) fidx.push_back(i * bs + c);
+      const int64_t nfr = (int64_t)fidx.size();
+      std::vector<int64_t> pos(N, -1);
+      for (int64_t q = 0; q < nfr; q++) pos[fidx[q]] = q;
+      std::vector<double> D((size_t)nfr * nfr, 0.0);
+      for (int64_t i = 0; i < L.A.n_rows; i++)
+        for (int64_t k = L.A.rowptr[i]; k < L.A.rowptr[i + 1]; k++) {
+          int64_t j = L.A.col[k];
+          for (int r = 0; r < bs; r++) for (int c = 0; c < bs; c++) {
+            int64_t pr = pos[i * bs + r], pc = pos[j * bs + c];
+            if (pr >= 0 && pc >= 0) D[pr * nfr + pc] = L.A.val[(k * bs + r) * bs + c];
+          }
+        }
+      bool chol = nfr > 0 ? spd_inverse(D.data(), (int)nfr) : true;
+      if (!chol) log << "  coarse matrix not SPD: pseudo-inverse used\n";
+      H->coarse_n = N;
+      H->coarse_inv.assign((size_t)N * N, 0.0);
+      for (int64_t a = 0; a < nfr; a++) for (int64_t b = 0; b < nfr; b++) H->coarse_inv[fidx[a] * N + fidx[b]] = D[a * nfr + b];
+    } else {
+      H->coarse_n = 0;   // too large for a dense inverse: caller falls back to clev = none (smoothing only)
+      log << "  coarsest level too large for dense inverse (" << N << ")\n";
+    }
+  }
+  H->log = log.str();
+  return H;
+}
+
+}  // namespace amgh

@@ -1,0 +1,56 @@
+// Host AMG setup: produces the frozen hierarchy (level matrices, P, P^T, smoother diagonals, colours,
+// coarse inverse) that is uploaded once to the GPU.  Minimal restatement of the reference's setup layer
+// (SURVEY.md section 7, step 2): same formats and block shapes, own (simpler) aggregation.
+#pragma once
+#include "bcsr.hpp"
+
+namespace amgh {
+
+struct Options {
+  // level control (reference src/base/factory/base_factory.hpp:92-152, base_factory.cpp:23-59)
+  int max_levels = 10;
+  int64_t max_coarse_size = 50;
+  double first_aaf = 0.05;       // target n_1/n_0      (h1_impl.hpp:333)
+  double aaf = 0.125;            // target n_{l+1}/n_l  (h1_impl.hpp:334)
+  // smoothed prolongation (h1_impl.hpp:320-324, elasticity_pc_impl.hpp:58-62)
+  int enable_sp = 1;
+  double sp_omega = 1.0;
+  int sp_max_per_row = 3;
+  double sp_min_frac = 0.08;
+  // pairwise aggregation
+  double soc_thresh = 0.25;      // relative strength threshold for a viable partner
+  int max_rounds = 8;            // hard cap of pairwise rounds per level
+  // smoother diagonals
+  int regularize_cmats = 0;      // => pseudo-inverse dinv (gssmoother.cpp:161-164)
+  // problem class
+  int dim = 3;
+  int energy = 0;                // 0: H1 (P = w * I_bs), 1: elasticity (rigid body blocks, coarse bs = dim + nrot)
+  int log_level = 0;
+};
+
+struct Level {
+  BCSR A;
+  BCSR P, PT;                    // to the next coarser level (empty on the coarsest)
+  std::vector<uint8_t> free;     // per block row
+  std::vector<double> dinv;      // n * bs * bs, zero for non-free rows
+  std::vector<double> coords;    // n * dim
+  std::vector<int32_t> color;    // greedy multicolouring of the graph of A (free rows), -1 for non-free
+  int n_colors = 0;
+  std::vector<int32_t> agg;      // fine vertex -> coarse vertex (or -1); kept for block smoothers / debugging
+};
+
+struct Hierarchy {
+  std::vector<Level> levels;
+  std::vector<double> coarse_inv;   // dense (n_L*bs)^2 inverse of the coarsest matrix on its free dofs
+  int64_t coarse_n = 0;             // scalar size of coarse_inv
+  Options opts;
+  std::string log;
+};
+
+Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coords0, const Options& o);
+
+// smoother data for one matrix (also used stand-alone by CreateJacobiSmoother / CreateHybridGSS mirrors)
+void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv);
+int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color);
+
+}  // namespace amgh

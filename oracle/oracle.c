@@ -1,0 +1,527 @@
+/* oracle.c -- CPU restatement of the NgsAMG multigrid apply path.  See oracle.h for scope, status
+ * ("parity unpinned") and the reference lines each function follows.  TEST INFRASTRUCTURE ONLY. */
+#include "oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+#define MAXBS 6
+
+struct orc_handle {
+  int n_levels;
+  orc_level* lev;            /* copies of the descriptors (arrays are borrowed) */
+  int cycle, clev_inv;
+  double** x_level;          /* amg_matrix.cpp:19-26 */
+  double** rhs_level;
+  double** res_level;
+  /* coarsest level: Cholesky factor of A_L restricted to free dofs */
+  int64_t crs_n;             /* scalar size of the coarsest level */
+  int64_t crs_nf;            /* number of free scalar dofs */
+  int64_t* crs_idx;          /* free scalar dof indices */
+  double* crs_L;             /* nf x nf lower factor */
+  double* crs_tmp;
+};
+
+static char g_err[512];
+static int g_threads = 1;
+
+const char* orc_last_error(void) { return g_err; }
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
+static int fail(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); return 1; }
+
+static inline int64_t vlen(const orc_level* L) { return L->A.n_rows * L->A.br; }
+
+/* ---------------------------------------------------------------- sparse kernels (NGSolve's part) */
+
+/* y = A x (mode 0), y = b - A x (mode 1), y += s A x (mode 2)
+ * = SparseMatrix<TM>::Mult / MultAdd as used by dof_map.cpp:651,708 and base_smoother.hpp:132-142 */
+static void spmv(const orc_matrix* A, const double* x, double* y, int mode, double s, const double* b) {
+  const int br = A->br, bc = A->bc;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i < A->n_rows; i++) {
+    double acc[MAXBS] = {0, 0, 0, 0, 0, 0};
+    for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+      const double* a = A->val + k * br * bc;
+      const double* xv = x + (int64_t)A->col[k] * bc;
+      for (int r = 0; r < br; r++)
+        for (int c = 0; c < bc; c++) acc[r] += a[r * bc + c] * xv[c];
+    }
+    for (int r = 0; r < br; r++) {
+      if (mode == 0) y[i * br + r] = acc[r];
+      else if (mode == 1) y[i * br + r] = b[i * br + r] - acc[r];
+      else y[i * br + r] += s * acc[r];
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- Jacobi (base_smoother.cpp:61-114) */
+
+/* x += omega * Dinv * v */
+static void diag_add(const orc_level* L, double* x, const double* v) {
+  const int bs = L->A.br;
+  const int64_t n = L->A.n_rows;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i < n; i++) {
+    const double* d = L->dinv + i * bs * bs;
+    for (int r = 0; r < bs; r++) {
+      double t = 0;
+      for (int c = 0; c < bs; c++) t += d[r * bs + c] * v[i * bs + c];
+      x[i * bs + r] += L->omega * t;
+    }
+  }
+}
+
+static void jacobi_smooth(const orc_level* L, double* x, const double* b, double* res,
+                          int res_updated, int update_res, int x_zero) {
+  /* RichardsonSmoother::Smooth, base_smoother.cpp:61-74; SmoothBack is identical (:77-82) */
+  if (!res_updated && x_zero) diag_add(L, x, b);
+  else {
+    if (!res_updated) spmv(&L->A, x, res, 1, 0.0, b);
+    diag_add(L, x, res);
+  }
+  if (update_res) spmv(&L->A, x, res, 1, 0.0, b);
+}
+
+/* ---------------------------------------------------------------- Gauss-Seidel GSS3 (gssmoother.cpp) */
+
+static inline int is_free(const orc_level* L, int64_t k) { return !L->free || L->free[k]; }
+
+/* RHS form, gssmoother.cpp:209-212:  x_k += dinv_k (b_k - A_k: x) */
+static inline void gs_row_rhs(const orc_level* L, int64_t k, double* x, const double* b) {
+  const orc_matrix* A = &L->A;
+  const int bs = A->br;
+  double r[MAXBS] = {0, 0, 0, 0, 0, 0};
+  for (int64_t p = A->rowptr[k]; p < A->rowptr[k + 1]; p++) {
+    const double* a = A->val + p * bs * bs;
+    const double* xv = x + (int64_t)A->col[p] * bs;
+    for (int i = 0; i < bs; i++)
+      for (int j = 0; j < bs; j++) r[i] += a[i * bs + j] * xv[j];
+  }
+  double t[MAXBS];
+  for (int i = 0; i < bs; i++) t[i] = b[k * bs + i] - r[i];
+  const double* d = L->dinv + k * bs * bs;
+  for (int i = 0; i < bs; i++) {
+    double u = 0;
+    for (int j = 0; j < bs; j++) u += d[i * bs + j] * t[j];
+    x[k * bs + i] += u;
+  }
+}
+
+/* RES form, gssmoother.cpp:274-278:  w = -dinv_k res_k ; res += A_k:^T w ; x_k -= w */
+static inline void gs_row_res(const orc_level* L, int64_t k, double* x, double* res) {
+  const orc_matrix* A = &L->A;
+  const int bs = A->br;
+  const double* d = L->dinv + k * bs * bs;
+  double w[MAXBS];
+  for (int i = 0; i < bs; i++) {
+    double u = 0;
+    for (int j = 0; j < bs; j++) u += d[i * bs + j] * res[k * bs + j];
+    w[i] = -u;
+  }
+  for (int64_t p = A->rowptr[k]; p < A->rowptr[k + 1]; p++) {
+    const double* a = A->val + p * bs * bs;
+    double* rj = res + (int64_t)A->col[p] * bs;
+    for (int j = 0; j < bs; j++) {
+      double u = 0;
+      for (int i = 0; i < bs; i++) u += a[i * bs + j] * w[i];   /* Trans(A_kj) * w */
+      rj[j] += u;
+    }
+  }
+  for (int i = 0; i < bs; i++) x[k * bs + i] -= w[i];
+}
+
+/* sweep over the free rows; natural order (reference) or the given visiting order (colour-major = what
+ * the GPU multicolour kernel does); backwards = reversed */
+static void gs_sweep(const orc_level* L, double* x, const double* b, double* res, int res_form, int backwards) {
+  const int64_t n = L->A.n_rows;
+  if (L->gs_order) {
+    const int64_t m = L->gs_order_len;
+    for (int64_t q = 0; q < m; q++) {
+      int64_t k = L->gs_order[backwards ? m - 1 - q : q];
+      if (!is_free(L, k)) continue;
+      if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b);
+    }
+    return;
+  }
+  /* free range [first_free, next_free), gssmoother.cpp:111-139 -- equivalent to testing every row */
+  if (!backwards) {
+    for (int64_t k = 0; k < n; k++) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b); }
+  } else {
+    for (int64_t k = n - 1; k >= 0; k--) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b); }
+  }
+}
+
+static void gs_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
+                      int res_updated, int update_res, int x_zero) {
+  /* GSS3::Smooth / SmoothBack, gssmoother.cpp:350-398 */
+  if (res_updated) {
+    if (update_res) gs_sweep(L, x, b, res, 1, dir);
+    else gs_sweep(L, x, b, res, 0, dir);
+  } else {
+    if (update_res) {
+      /* CalcResiduum (base_smoother.hpp:132-142): res = b; if (!x_zero) res -= A x */
+      if (x_zero) memcpy(res, b, sizeof(double) * vlen(L));
+      else spmv(&L->A, x, res, 1, 0.0, b);
+      gs_sweep(L, x, b, res, 1, dir);
+    } else gs_sweep(L, x, b, res, 0, dir);
+  }
+}
+
+/* ---------------------------------------------------------------- smoother dispatch + ProxySmoother */
+
+static void base_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
+                        int res_updated, int update_res, int x_zero) {
+  if (L->sm_type == ORC_SM_JACOBI) jacobi_smooth(L, x, b, res, res_updated, update_res, x_zero);
+  else gs_smooth(L, dir, x, b, res, res_updated, update_res, x_zero);
+}
+
+/* BaseSmoother::SmoothSymm, base_smoother.hpp:79-85 */
+static void smooth_symm(const orc_level* L, double* x, const double* b, double* res, int ru, int ur, int xz) {
+  base_smooth(L, 0, x, b, res, ru, ur, xz);
+  base_smooth(L, 1, x, b, res, ur, ur, 0);
+}
+
+/* ProxySmoother (base_smoother.hpp:169-229), created iff sm_symm || sm_steps > 1 (amg_pc.cpp:1079-1082) */
+static void level_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
+                         int res_updated, int update_res, int x_zero) {
+  const int k = L->sm_steps < 1 ? 1 : L->sm_steps;
+  if (!L->sm_symm && k == 1) { base_smooth(L, dir, x, b, res, res_updated, update_res, x_zero); return; }
+  if (L->sm_symm) {            /* SmoothSymmK for both directions */
+    smooth_symm(L, x, b, res, res_updated, update_res, x_zero);
+    for (int j = 1; j < k; j++) smooth_symm(L, x, b, res, update_res, update_res, 0);
+  } else {                     /* SmoothK / SmoothBackK, base_smoother.hpp:87-103 */
+    base_smooth(L, dir, x, b, res, res_updated, update_res, x_zero);
+    for (int j = 1; j < k; j++) base_smooth(L, dir, x, b, res, update_res, update_res, 0);
+  }
+}
+
+/* ---------------------------------------------------------------- transfers (dof_map.cpp:636-709) */
+
+static void transfer_f2c(const orc_handle* h, int level, const double* xf, double* xc) {
+  spmv(&h->lev[level].PT, xf, xc, 0, 0.0, NULL);
+}
+static void add_c2f(const orc_handle* h, int level, double fac, double* xf, const double* xc) {
+  spmv(&h->lev[level].P, xc, xf, 2, fac, NULL);
+}
+
+/* ---------------------------------------------------------------- coarsest level */
+
+static void coarse_solve(const orc_handle* h, const double* rhs, double* x) {
+  const int64_t N = h->crs_n, nf = h->crs_nf;
+  for (int64_t i = 0; i < N; i++) x[i] = 0.0;
+  if (!h->clev_inv) return;    /* clev != inv: x_L = 0 (amg_matrix.cpp:242-246) */
+  double* t = h->crs_tmp;
+  const double* Lf = h->crs_L;
+  for (int64_t i = 0; i < nf; i++) {
+    double s = rhs[h->crs_idx[i]];
+    for (int64_t k = 0; k < i; k++) s -= Lf[i * nf + k] * t[k];
+    t[i] = s / Lf[i * nf + i];
+  }
+  for (int64_t i = nf - 1; i >= 0; i--) {
+    double s = t[i];
+    for (int64_t k = i + 1; k < nf; k++) s -= Lf[k * nf + i] * t[k];
+    t[i] = s / Lf[i * nf + i];
+  }
+  for (int64_t i = 0; i < nf; i++) x[h->crs_idx[i]] = t[i];
+}
+
+/* ---------------------------------------------------------------- cycles (amg_matrix.cpp) */
+
+static void smooth_v_from_level(orc_handle* h, int start, double* x, const double* b, double* res,
+                                int res_updated, int update_res, int x_zero);
+
+static void prep_level(orc_handle* h, int l) {
+  /* x_l = 0; r_l = b_l   (amg_matrix.cpp:193-202) */
+  const int64_t n = vlen(&h->lev[l]);
+  memset(h->x_level[l], 0, sizeof(double) * n);
+  memcpy(h->res_level[l], h->rhs_level[l], sizeof(double) * n);
+}
+
+static void cycle_v(orc_handle* h, double* x, const double* b) {
+  const int L = h->n_levels;
+  for (int l = 0; l + 1 < L; l++) {
+    double* xl = l == 0 ? x : h->x_level[l];
+    const double* bl = l == 0 ? b : h->rhs_level[l];
+    double* rl = h->res_level[l];
+    const int64_t n = vlen(&h->lev[l]);
+    memset(xl, 0, sizeof(double) * n);
+    memcpy(rl, bl, sizeof(double) * n);
+    level_smooth(&h->lev[l], 0, xl, bl, rl, 1, 1, 1);
+    transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
+  }
+  if (L == 1) { coarse_solve(h, b, x); return; }
+  coarse_solve(h, h->rhs_level[L - 1], h->x_level[L - 1]);
+  for (int l = L - 2; l >= 0; l--) {
+    double* xl = l == 0 ? x : h->x_level[l];
+    const double* bl = l == 0 ? b : h->rhs_level[l];
+    double* rl = h->res_level[l];
+    add_c2f(h, l, 1.0, xl, h->x_level[l + 1]);
+    level_smooth(&h->lev[l], 1, xl, bl, rl, 0, 0, 0);
+  }
+}
+
+/* plain W-cycle: the reference's lambda (amg_matrix.cpp:45-104) additionally runs a V-like pass at
+ * level 0 whose result it discards; the final result is the same. */
+static void w_rec(orc_handle* h, int l, double* x0, const double* b0) {
+  const int L = h->n_levels;
+  if (l + 1 < L) {
+    double* xl = l == 0 ? x0 : h->x_level[l];
+    const double* bl = l == 0 ? b0 : h->rhs_level[l];
+    double* rl = h->res_level[l];
+    const int64_t n = vlen(&h->lev[l]);
+    memset(xl, 0, sizeof(double) * n);
+    memcpy(rl, bl, sizeof(double) * n);
+    level_smooth(&h->lev[l], 0, xl, bl, rl, 1, 1, 1);
+    transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
+    w_rec(h, l + 1, x0, b0);
+    add_c2f(h, l, 1.0, xl, h->x_level[l + 1]);
+    level_smooth(&h->lev[l], 1, xl, bl, rl, 0, 1, 0);
+    level_smooth(&h->lev[l], 0, xl, bl, rl, 1, 1, 0);
+    transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
+    w_rec(h, l + 1, x0, b0);
+    add_c2f(h, l, 1.0, xl, h->x_level[l + 1]);
+    level_smooth(&h->lev[l], 1, xl, bl, rl, 0, 0, 0);
+  } else {
+    if (L == 1) coarse_solve(h, b0, x0);
+    else coarse_solve(h, h->rhs_level[L - 1], h->x_level[L - 1]);
+  }
+}
+
+static void cycle_bs(orc_handle* h, double* x, const double* b) {
+  const int L = h->n_levels;
+  for (int l = 0; l + 1 < L; l++) {
+    double* xl = l == 0 ? x : h->x_level[l];
+    const double* bl = l == 0 ? b : h->rhs_level[l];
+    double* rl = h->res_level[l];
+    const int64_t n = vlen(&h->lev[l]);
+    memset(xl, 0, sizeof(double) * n);
+    memcpy(rl, bl, sizeof(double) * n);
+    smooth_v_from_level(h, l, xl, bl, rl, 1, 1, 1);
+    transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
+  }
+  if (L == 1) { coarse_solve(h, b, x); return; }
+  coarse_solve(h, h->rhs_level[L - 1], h->x_level[L - 1]);
+  for (int l = L - 2; l >= 0; l--) {
+    double* xl = l == 0 ? x : h->x_level[l];
+    const double* bl = l == 0 ? b : h->rhs_level[l];
+    double* rl = h->res_level[l];
+    add_c2f(h, l, 1.0, xl, h->x_level[l + 1]);
+    smooth_v_from_level(h, l, xl, bl, rl, 0, 0, 0);
+  }
+}
+
+/* AMGMatrix::SmoothVFromLevel, amg_matrix.cpp:310-374 */
+static void smooth_v_from_level(orc_handle* h, int start, double* x, const double* b, double* res,
+                                int res_updated, int update_res, int x_zero) {
+  const int L = h->n_levels;
+  level_smooth(&h->lev[start], 0, x, b, res, res_updated, 1, x_zero);
+  transfer_f2c(h, start, res, h->rhs_level[start + 1]);
+  if (start + 2 < L)
+    for (int l = start + 1; l + 1 < L; l++) {
+      prep_level(h, l);
+      level_smooth(&h->lev[l], 0, h->x_level[l], h->rhs_level[l], h->res_level[l], 1, 1, 1);
+      transfer_f2c(h, l, h->res_level[l], h->rhs_level[l + 1]);
+    }
+  coarse_solve(h, h->rhs_level[L - 1], h->x_level[L - 1]);
+  if (start + 2 < L)
+    for (int l = L - 2; l > start; l--) {
+      add_c2f(h, l, 1.0, h->x_level[l], h->x_level[l + 1]);
+      level_smooth(&h->lev[l], 1, h->x_level[l], h->rhs_level[l], h->res_level[l], 0, 0, 0);
+    }
+  add_c2f(h, start, 1.0, x, h->x_level[start + 1]);
+  level_smooth(&h->lev[start], 1, x, b, res, 0, update_res, 0);
+}
+
+static void do_cycle(orc_handle* h, double* x, const double* b) {
+  /* AMGMatrix::Smooth dispatch, amg_matrix.hpp:37-43 */
+  if (h->cycle == ORC_CYCLE_W) w_rec(h, 0, x, b);
+  else if (h->cycle == ORC_CYCLE_BS) cycle_bs(h, x, b);
+  else cycle_v(h, x, b);
+}
+
+/* ---------------------------------------------------------------- public API */
+
+int orc_create(const orc_desc* d, orc_handle** out) {
+  if (!d || !out || d->n_levels < 1) return fail("orc_create: bad descriptor");
+  orc_handle* h = (orc_handle*)calloc(1, sizeof(orc_handle));
+  h->n_levels = d->n_levels;
+  h->cycle = d->cycle;
+  h->clev_inv = d->clev_inv;
+  h->lev = (orc_level*)malloc(sizeof(orc_level) * d->n_levels);
+  memcpy(h->lev, d->levels, sizeof(orc_level) * d->n_levels);
+  h->x_level = (double**)calloc(d->n_levels, sizeof(double*));
+  h->rhs_level = (double**)calloc(d->n_levels, sizeof(double*));
+  h->res_level = (double**)calloc(d->n_levels, sizeof(double*));
+  for (int l = 0; l < d->n_levels; l++) {
+    const orc_level* L = &h->lev[l];
+    if (L->A.br != L->A.bc || L->A.br > MAXBS || L->A.n_rows != L->A.n_cols) { orc_destroy(h); return fail("orc_create: bad level matrix"); }
+    if (l + 1 < d->n_levels) {
+      const orc_level* Lc = &h->lev[l + 1];
+      if (L->P.n_rows != L->A.n_rows || L->P.n_cols != Lc->A.n_rows || L->P.br != L->A.br || L->P.bc != Lc->A.br ||
+          L->PT.n_rows != L->P.n_cols || L->PT.n_cols != L->P.n_rows || L->PT.br != L->P.bc || L->PT.bc != L->P.br)
+        { orc_destroy(h); return fail("orc_create: P / PT shapes do not match the level matrices"); }
+    }
+    const int64_t n = vlen(L);
+    h->x_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
+    h->rhs_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
+    h->res_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
+  }
+  /* coarsest-level factor: dense Cholesky of the free-free part (exact solve, amg_pc.cpp:904-922) */
+  {
+    const orc_level* L = &h->lev[h->n_levels - 1];
+    const int bs = L->A.br;
+    const int64_t N = vlen(L);
+    h->crs_n = N;
+    h->crs_idx = (int64_t*)malloc(sizeof(int64_t) * (N > 0 ? N : 1));
+    int64_t* pos = (int64_t*)malloc(sizeof(int64_t) * (N > 0 ? N : 1));
+    int64_t nf = 0;
+    for (int64_t i = 0; i < L->A.n_rows; i++)
+      for (int c = 0; c < bs; c++) {
+        if (is_free(L, i)) { pos[i * bs + c] = nf; h->crs_idx[nf++] = i * bs + c; } else pos[i * bs + c] = -1;
+      }
+    h->crs_nf = nf;
+    h->crs_tmp = (double*)calloc(nf > 0 ? nf : 1, sizeof(double));
+    if (h->clev_inv) {
+      if (nf > 8192) { free(pos); orc_destroy(h); return fail("orc_create: coarsest level too large for the dense solve"); }
+      double* D = (double*)calloc((size_t)(nf > 0 ? nf * nf : 1), sizeof(double));
+      for (int64_t i = 0; i < L->A.n_rows; i++)
+        for (int64_t k = L->A.rowptr[i]; k < L->A.rowptr[i + 1]; k++) {
+          const int64_t j = L->A.col[k];
+          for (int r = 0; r < bs; r++)
+            for (int c = 0; c < bs; c++) {
+              const int64_t pr = pos[i * bs + r], pc = pos[j * bs + c];
+              if (pr >= 0 && pc >= 0) D[pr * nf + pc] = L->A.val[(k * bs + r) * bs + c];
+            }
+        }
+      for (int64_t j = 0; j < nf; j++) {
+        double dd = D[j * nf + j];
+        for (int64_t k = 0; k < j; k++) dd -= D[j * nf + k] * D[j * nf + k];
+        if (!(dd > 0.0)) { free(D); free(pos); orc_destroy(h); return fail("orc_create: coarsest matrix is not SPD on its free dofs"); }
+        dd = sqrt(dd);
+        D[j * nf + j] = dd;
+        for (int64_t i = j + 1; i < nf; i++) {
+          double s = D[i * nf + j];
+          for (int64_t k = 0; k < j; k++) s -= D[i * nf + k] * D[j * nf + k];
+          D[i * nf + j] = s / dd;
+        }
+      }
+      h->crs_L = D;
+    }
+    free(pos);
+  }
+  *out = h;
+  return 0;
+}
+
+void orc_destroy(orc_handle* h) {
+  if (!h) return;
+  for (int l = 0; l < h->n_levels; l++) {
+    if (h->x_level) free(h->x_level[l]);
+    if (h->rhs_level) free(h->rhs_level[l]);
+    if (h->res_level) free(h->res_level[l]);
+  }
+  free(h->x_level); free(h->rhs_level); free(h->res_level);
+  free(h->lev); free(h->crs_idx); free(h->crs_L); free(h->crs_tmp);
+  free(h);
+}
+
+int orc_apply(orc_handle* h, const double* b, double* x) {
+  if (!h) return fail("orc_apply: null handle");
+  do_cycle(h, x, b);
+  return 0;
+}
+
+int orc_apply_add(orc_handle* h, double s, const double* b, double* x) {
+  /* AMGMatrix::MultAdd, amg_matrix.cpp:385-389 */
+  if (!h) return fail("orc_apply_add: null handle");
+  do_cycle(h, h->x_level[0], b);
+  const int64_t n = vlen(&h->lev[0]);
+  for (int64_t i = 0; i < n; i++) x[i] += s * h->x_level[0][i];
+  return 0;
+}
+
+int orc_smooth_v_from_level(orc_handle* h, int level, double* x, const double* b, double* res,
+                            int res_updated, int update_res, int x_zero) {
+  if (!h || level < 0 || level + 1 >= h->n_levels) return fail("orc_smooth_v_from_level: bad level");
+  smooth_v_from_level(h, level, x, b, res, res_updated, update_res, x_zero);
+  return 0;
+}
+
+int orc_smooth(orc_handle* h, int level, int dir, double* x, const double* b, double* res,
+               int res_updated, int update_res, int x_zero) {
+  if (!h || level < 0 || level >= h->n_levels) return fail("orc_smooth: bad level");
+  level_smooth(&h->lev[level], dir, x, b, res, res_updated, update_res, x_zero);
+  return 0;
+}
+
+int orc_transfer_f2c(orc_handle* h, int level, const double* xf, double* xc) {
+  if (!h || level < 0 || level + 1 >= h->n_levels) return fail("orc_transfer_f2c: bad level");
+  transfer_f2c(h, level, xf, xc);
+  return 0;
+}
+
+int orc_add_c2f(orc_handle* h, int level, double fac, double* xf, const double* xc) {
+  if (!h || level < 0 || level + 1 >= h->n_levels) return fail("orc_add_c2f: bad level");
+  add_c2f(h, level, fac, xf, xc);
+  return 0;
+}
+
+int orc_coarse_solve(orc_handle* h, const double* rhs, double* x) {
+  if (!h) return fail("orc_coarse_solve: null handle");
+  coarse_solve(h, rhs, x);
+  return 0;
+}
+
+int orc_matvec(orc_handle* h, int level, const double* x, double* y) {
+  if (!h || level < 0 || level >= h->n_levels) return fail("orc_matvec: bad level");
+  spmv(&h->lev[level].A, x, y, 0, 0.0, NULL);
+  return 0;
+}
+
+static double dot(const double* a, const double* b, int64_t n) {
+  double s = 0;
+#pragma omp parallel for schedule(static) reduction(+ : s) num_threads(g_threads)
+  for (int64_t i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+
+int orc_pcg(orc_handle* h, const orc_matrix* Ain, const double* b, double* x, double tol, int maxit,
+            double* errs, int* iters) {
+  /* stand-in for ngsolve.krylovspace.CGSolver as the reference's tests drive it
+   * (tests/h1/amg_utils.py:337-363): err = sqrt(|<C r, r>|), stop at err <= tol * err_0 */
+  const orc_matrix* A = Ain ? Ain : (h ? &h->lev[0].A : NULL);
+  if (!A) return fail("orc_pcg: no matrix");
+  const int64_t n = A->n_rows * A->br;
+  double* d = (double*)malloc(sizeof(double) * n);
+  double* w = (double*)malloc(sizeof(double) * n);
+  double* s = (double*)malloc(sizeof(double) * n);
+  spmv(A, x, d, 1, 0.0, b);
+  if (h) do_cycle(h, w, d); else memcpy(w, d, sizeof(double) * n);
+  memcpy(s, w, sizeof(double) * n);
+  double wdn = dot(w, d, n);
+  double err0 = sqrt(fabs(wdn));
+  int it = 0;
+  if (errs) errs[0] = err0;
+  if (err0 > 0)
+    for (it = 1; it <= maxit; it++) {
+      spmv(A, s, w, 0, 0.0, NULL);
+      const double wd = wdn;
+      const double as_s = dot(s, w, n);
+      const double alpha = wd / as_s;
+      for (int64_t i = 0; i < n; i++) { x[i] += alpha * s[i]; d[i] -= alpha * w[i]; }
+      if (h) do_cycle(h, w, d); else memcpy(w, d, sizeof(double) * n);
+      wdn = dot(w, d, n);
+      const double beta = wdn / wd;
+      for (int64_t i = 0; i < n; i++) s[i] = beta * s[i] + w[i];
+      const double err = sqrt(fabs(wdn));
+      if (errs) errs[it] = err;
+      if (err <= tol * err0) break;
+    }
+  if (it > maxit) it = maxit;
+  if (iters) *iters = it;
+  free(d); free(w); free(s);
+  return 0;
+}
