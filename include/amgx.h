@@ -1,0 +1,129 @@
+/* amgx.h -- C ABI of the MI355X-native AMG apply path (libngsamg_hip.so).
+ *
+ * Drop-in boundary for the hot path of LukasKogler/NgsAMG: one preconditioner application
+ *     BaseAMGPC::Mult(b, x)            reference src/base/precond/amg_pc.cpp:467-470
+ *       -> AMGMatrix::Mult -> SmoothV  reference src/base/solve/amg_matrix.cpp:377-378, 160-307
+ * and the pieces reachable through the reference's Python surface (GetSmoother(level).Smooth,
+ * GetAMGMatrix().GetMatrix(level), DOFMap transfers).  An NGSolve-side subclass of ngcomp::Preconditioner
+ * (or the stand-alone Python module ngsamg_amd.NgsAMG) forwards to these entry points; INTEGRATION.md shows
+ * the binding.  Plain pointers and sizes only -- no torch / HIP types in the signatures (streams travel
+ * as void*).
+ *
+ * Lifetime: amgx_create copies every host array of the descriptor to the GPU once (the descriptor is
+ * borrowed during the call only).  A handle is not re-entrant (like AMGMatrix::Mult, which mutates its
+ * work vectors) but distinct handles are independent.
+ *
+ * Errors: every function returns 0 on success, non-zero otherwise; amgx_last_error(handle) (handle may
+ * be NULL for create-time errors) returns the message.  The shim rethrows it (reference: ngcore::Exception).
+ *
+ * All vectors are fp64, AoS block vectors (entry = bs*dof + comp; reference amg_matrix.cpp:494).
+ */
+#ifndef NGSAMG_AMGX_H
+#define NGSAMG_AMGX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* host (block-)CSR view: layout of NGSolve SparseMatrix<Mat<br,bc>> */
+typedef struct amgx_matrix {
+  int64_t n_rows, n_cols;     /* block rows / block columns                           */
+  int32_t br, bc;             /* block height / width (1, 2, 3, 6; P: 3x6, PT: 6x3)    */
+  const int64_t* rowptr;      /* [n_rows+1] (size_t firsti in the reference)          */
+  const int32_t* col;         /* [nnz] ascending per row                              */
+  const double* val;          /* [nnz*br*bc] row-major blocks                         */
+} amgx_matrix;
+
+/* smoother kinds = ngs_amg_sm_type (reference src/base/precond/amg_pc.cpp:1033-1138) */
+enum {
+  AMGX_SM_JACOBI = 0,         /* JacobiSmoother<TM>, base_smoother.cpp:61-114         */
+  AMGX_SM_GS = 1              /* Gauss-Seidel (GSS3, gssmoother.cpp:196-398) executed as multicolour GS */
+};
+enum { AMGX_CYCLE_V = 0, AMGX_CYCLE_W = 1, AMGX_CYCLE_BS = 2 };   /* ngs_amg_mg_cycle, amg_matrix.hpp:37-43 */
+enum { AMGX_CLEV_NONE = 0, AMGX_CLEV_INV = 1 };                   /* ngs_amg_clev,     amg_matrix.cpp:217-247 */
+
+/* flags for the vector arguments of the calls below */
+enum {
+  AMGX_HOST_PTR = 0,          /* vectors are host arrays: copied H2D / D2H inside the call            */
+  AMGX_DEVICE_PTR = 1,        /* vectors are device arrays on the handle's GPU (no copies)            */
+  AMGX_NO_GRAPH = 2           /* launch the kernels directly instead of replaying the captured graph  */
+};
+
+typedef struct amgx_level_desc {
+  amgx_matrix A;              /* level matrix (smoothers[l]->GetAMatrix())                           */
+  amgx_matrix P, PT;          /* ProlMap<TM>: P and explicit P^T (dof_map.hpp:252-334); empty on the coarsest */
+  const double* dinv;         /* [n*bs*bs] inverted block diagonal, 0 on non-free rows (gssmoother.cpp:143-170) */
+  const uint8_t* free_dofs;   /* [n] 1 = free block row, or NULL (all free)                           */
+  int32_t sm_type;            /* AMGX_SM_*                                                           */
+  double omega;               /* Jacobi damping, reference default 0.9 (base_smoother.hpp:279)       */
+  int32_t sm_steps;           /* ngs_amg_sm_steps (ProxySmoother, base_smoother.hpp:169-229)         */
+  int32_t sm_symm;            /* ngs_amg_sm_symm                                                     */
+  const int32_t* color;       /* [n] colour of each free row (required for AMGX_SM_GS), -1 otherwise  */
+  int32_t n_colors;
+} amgx_level_desc;
+
+typedef struct amgx_hierarchy_desc {
+  int32_t n_levels;
+  const amgx_level_desc* levels;
+  int32_t cycle;              /* AMGX_CYCLE_*                                                        */
+  int32_t clev;               /* AMGX_CLEV_*                                                         */
+  int64_t coarse_n;           /* scalar size of the coarsest level                                   */
+  const double* coarse_inv;   /* dense [coarse_n^2] inverse on the free dofs (crs_inv, amg_pc.cpp:843-928) */
+  int32_t device;             /* HIP device ordinal                                                  */
+  int32_t use_graph;          /* 1: capture each distinct (b, x) cycle into a hipGraph and replay it */
+} amgx_hierarchy_desc;
+
+typedef struct amgx_handle_t* amgx_handle;
+
+const char* amgx_last_error(amgx_handle h);
+
+int amgx_create(const amgx_hierarchy_desc* desc, amgx_handle* out);
+int amgx_destroy(amgx_handle h);
+
+/* All work of the handle is enqueued on ONE stream.  A new handle owns a private non-blocking stream; this
+ * call switches it to the caller's hipStream_t (NULL = the legacy default stream), so that the caller's own
+ * kernels and events on that stream order with the preconditioner without host synchronisation. */
+int amgx_set_stream(amgx_handle h, void* hip_stream);
+int amgx_synchronize(amgx_handle h);
+
+/* x = C b : BaseAMGPC::Mult / AMGMatrix::Mult (amg_pc.cpp:467-470, amg_matrix.cpp:377-378).
+ * b_status: 0 = DISTRIBUTED, 1 = CUMULATED (single GPU: both mean the same). */
+int amgx_apply(amgx_handle h, const double* b, double* x, int b_status, int flags);
+/* x += s * C b : AMGMatrix::MultAdd (amg_matrix.cpp:385-389) */
+int amgx_apply_add(amgx_handle h, double s, const double* b, double* x, int flags);
+
+/* smoothers[level]->Smooth (dir = 0) / SmoothBack (dir = 1) with the reference's flag contract
+ * (base_smoother.hpp:68-112); goes through the ProxySmoother when sm_steps > 1 or sm_symm. */
+int amgx_smooth(amgx_handle h, int level, int dir, double* x, const double* b, double* res,
+                int res_updated, int update_res, int x_zero, int flags);
+/* AMGMatrix::SmoothVFromLevel (amg_matrix.cpp:310-374) */
+int amgx_smooth_v_from_level(amgx_handle h, int level, double* x, const double* b, double* res,
+                             int res_updated, int update_res, int x_zero, int flags);
+/* y = A_level x  (GetMatrix(level).Mult) */
+int amgx_matvec(amgx_handle h, int level, const double* x, double* y, int flags);
+/* DOFMap::TransferF2C (x_coarse = P^T x_fine) and AddC2F (x_fine += fac * P x_coarse), dof_map.cpp:636-709 */
+int amgx_transfer_f2c(amgx_handle h, int level, const double* x_fine, double* x_coarse, int flags);
+int amgx_add_c2f(amgx_handle h, int level, double fac, double* x_fine, const double* x_coarse, int flags);
+/* crs_inv->Mult on the coarsest level */
+int amgx_coarse_solve(amgx_handle h, const double* rhs, double* x, int flags);
+
+/* GetNLevels / GetNDof / GetBlockSize (python_amg.hpp:15-103) */
+int amgx_n_levels(amgx_handle h);
+int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* nnz);
+/* device-format report per level matrix: which = 0 A, 1 P, 2 PT; fmt: 0 CSR-vector, 1 sliced-ELL;
+ * stored_entries counts padding (for the traffic model in DESIGN.md) */
+int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);
+
+/* measurement hook for bench.py: launches one hot-path kernel `reps` times on the handle's stream,
+ * bracketed by HIP events, and returns the average duration in milliseconds.
+ *   op = 0: residual SpMV  r = b - A_level x      (the dominant kernel of the Jacobi V-cycle)
+ *   op = 1: fused Jacobi post-smooth  x' = x + omega*dinv*(b - A_level x)
+ *   op = 2: restriction  b_c = P^T r      op = 3: prolongation  x += P x_c
+ *   op = 4: one whole cycle (amgx_apply on internal vectors) */
+int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -165,3 +165,71 @@ class Matrix:
         B = sp.bsr_matrix(A, blocksize=(bs, bs))
         B.sort_indices()
         return cls(B.shape[0] // bs, B.shape[1] // bs, bs, bs, B.indptr, B.indices, B.data)
+
+
+# ---------------------------------------------------------------------------------------------
+# device library (include/amgx.h)
+# ---------------------------------------------------------------------------------------------
+
+class amgx_matrix(C.Structure):
+    _fields_ = amgh_matrix._fields_
+
+
+class amgx_level_desc(C.Structure):
+    _fields_ = [("A", amgx_matrix), ("P", amgx_matrix), ("PT", amgx_matrix), ("dinv", c_f64p),
+                ("free_dofs", c_u8p), ("sm_type", C.c_int32), ("omega", C.c_double), ("sm_steps", C.c_int32),
+                ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32)]
+
+
+class amgx_hierarchy_desc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("levels", C.POINTER(amgx_level_desc)), ("cycle", C.c_int32),
+                ("clev", C.c_int32), ("coarse_n", C.c_int64), ("coarse_inv", c_f64p), ("device", C.c_int32),
+                ("use_graph", C.c_int32)]
+
+
+AMGX_SM_JACOBI, AMGX_SM_GS = 0, 1
+AMGX_CYCLE = {"V": 0, "W": 1, "BS": 2}
+AMGX_CLEV_NONE, AMGX_CLEV_INV = 0, 1
+AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
+
+AMGX_SYMBOLS = [
+    "amgx_last_error", "amgx_create", "amgx_destroy", "amgx_set_stream", "amgx_synchronize", "amgx_apply",
+    "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_matvec", "amgx_transfer_f2c",
+    "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info", "amgx_time_op",
+]
+
+AMGH_SYMBOLS = [
+    "amgh_last_error", "amgh_default_options", "amgh_setup", "amgh_n_levels", "amgh_level_get",
+    "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
+    "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble",
+]
+
+
+def hip():
+    """Load libngsamg_hip.so.  Raises if it is missing: the apply path has no fallback."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    lib = _load("libngsamg_hip.so")
+    vp = C.c_void_p
+    dp = C.c_void_p   # vectors travel as raw addresses (host numpy or device torch pointers)
+    lib.amgx_last_error.argtypes = [vp]
+    lib.amgx_last_error.restype = C.c_char_p
+    lib.amgx_create.argtypes = [C.POINTER(amgx_hierarchy_desc), C.POINTER(vp)]
+    lib.amgx_destroy.argtypes = [vp]
+    lib.amgx_set_stream.argtypes = [vp, vp]
+    lib.amgx_synchronize.argtypes = [vp]
+    lib.amgx_apply.argtypes = [vp, dp, dp, C.c_int, C.c_int]
+    lib.amgx_apply_add.argtypes = [vp, C.c_double, dp, dp, C.c_int]
+    lib.amgx_smooth.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.amgx_smooth_v_from_level.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.amgx_matvec.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.amgx_transfer_f2c.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.amgx_add_c2f.argtypes = [vp, C.c_int, C.c_double, dp, dp, C.c_int]
+    lib.amgx_coarse_solve.argtypes = [vp, dp, dp, C.c_int]
+    lib.amgx_n_levels.argtypes = [vp]
+    lib.amgx_level_info.argtypes = [vp, C.c_int, c_i64p, c_i32p, c_i64p]
+    lib.amgx_matrix_info.argtypes = [vp, C.c_int, C.c_int, c_i32p, c_i64p, c_i32p]
+    lib.amgx_time_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
+    _hip = lib
+    return lib

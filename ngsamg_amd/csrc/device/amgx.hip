@@ -1,0 +1,884 @@
+// MI355X-native AMG apply path: device hierarchy, cycle driver and the C ABI of include/amgx.h.
+//
+// Host-side structure mirrors the reference's solve layer (not its code):
+//   Handle                 <-> AMGMatrix                 (reference src/base/solve/amg_matrix.hpp:14-87)
+//   Handle::level_smooth   <-> BaseSmoother / ProxySmoother contract (src/base/smoothers/base_smoother.hpp:68-229)
+//   Handle::cycle_v/w/bs   <-> SmoothV / SmoothW / SmoothBS (src/base/solve/amg_matrix.cpp:37-307)
+//   Handle::smooth_v_from_level <-> SmoothVFromLevel      (amg_matrix.cpp:310-374)
+// Everything between the entry point and the result stays on the GPU; one application = a fixed sequence
+// of kernel launches on one HIP stream, captured once per (b, x) pair into a hipGraph and replayed.
+#include "../../../include/amgx.h"
+#include "kernels.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace amgx {
+
+struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIPCHK(call)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      throw ::amgx::Err(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+  }
+  void upload(const T* host, size_t count) {
+    alloc(count);
+    if (count) HIPCHK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+};
+
+enum Fmt : int { FMT_CSRVEC = 0, FMT_SELL = 1 };
+
+struct DevMatrix {
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int br = 1, bc = 1;
+  int fmt = FMT_CSRVEC;
+  int lanes = 1;                       // G of the CSR-vector kernels
+  // CSR
+  DevBuf<int32_t> rowptr, col;
+  DevBuf<double> val;
+  // SELL-64-pair
+  int n_slices = 0;
+  int64_t stored = 0;                  // stored entries incl. padding
+  DevBuf<int64_t> slice_ptr;
+  DevBuf<int32_t> scol;
+  DevBuf<double> sval;
+  bool empty() const { return n_rows == 0; }
+};
+
+struct DevGS {                          // colour-major data for multicolour Gauss-Seidel
+  int n_colors = 0;
+  // scalar: SELL copy of A in colour-major row order
+  std::vector<int> color_slice_ptr;     // [n_colors+1] slice ranges
+  DevBuf<int64_t> slice_ptr;
+  DevBuf<int32_t> scol, rowid;
+  DevBuf<double> sval;
+  // block: colour-major row list over the CSR of A
+  std::vector<int> color_row_ptr;       // [n_colors+1]
+  DevBuf<int32_t> rowlist;
+};
+
+struct DevLevel {
+  DevMatrix A, P, PT;
+  DevBuf<double> dinv;
+  DevGS gs;
+  int sm_type = AMGX_SM_JACOBI;
+  double omega = 0.9;
+  int sm_steps = 1, sm_symm = 0;
+  int64_t n = 0;                        // block rows
+  int bs = 1;
+  int64_t len() const { return n * bs; }
+  DevBuf<double> x, rhs, res, tmp;      // x_level / rhs_level / res_level (amg_matrix.cpp:19-26) + ping-pong buffer
+};
+
+// ---------------------------------------------------------------------------------------------------
+// host-side format construction
+// ---------------------------------------------------------------------------------------------------
+
+static int pick_lanes(double avg_len) {
+  int g = 2;
+  while (g < 64 && g < avg_len * 0.75) g <<= 1;
+  return g;
+}
+
+// SELL-64-pair image of the rows `rows[0..m)` of a scalar CSR matrix (row id < 0 => empty padding row).
+// Element (lane, j) of a slice of width w sits at  base + (j/2)*128 + lane*2 + (j&1)  for j < 2*(w/2)
+// and at  base + (w-1)*64 + lane  for the odd trailing column.  Padding: value 0, column = a valid index.
+static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, std::vector<int64_t>& slice_ptr,
+                       std::vector<int32_t>& scol, std::vector<double>& sval) {
+  const int64_t ns = (m + WAVE - 1) / WAVE;
+  slice_ptr.assign(ns + 1, 0);
+  for (int64_t s = 0; s < ns; ++s) {
+    int w = 0;
+    for (int l = 0; l < WAVE; ++l) {
+      const int64_t q = s * WAVE + l;
+      if (q >= m) break;
+      const int64_t r = rows ? rows[q] : q;
+      if (r < 0) continue;
+      w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+    }
+    slice_ptr[s + 1] = slice_ptr[s] + (int64_t)w * WAVE;
+  }
+  scol.assign(slice_ptr[ns], 0);
+  sval.assign(slice_ptr[ns], 0.0);
+  for (int64_t s = 0; s < ns; ++s) {
+    const int64_t base = slice_ptr[s];
+    const int w = (int)((slice_ptr[s + 1] - base) / WAVE);
+    const int wp = w & ~1;
+    for (int l = 0; l < WAVE; ++l) {
+      const int64_t q = s * WAVE + l;
+      int64_t r = -1;
+      if (q < m) r = rows ? rows[q] : q;
+      const int64_t rb = r >= 0 ? A.rowptr[r] : 0;
+      const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rb) : 0;
+      const int32_t padcol = r >= 0 ? (len ? A.col[rb] : 0) : 0;
+      for (int j = 0; j < w; ++j) {
+        const int64_t o = (j < wp) ? base + (int64_t)(j >> 1) * (2 * WAVE) + l * 2 + (j & 1) : base + (int64_t)(w - 1) * WAVE + l;
+        if (j < len) { scol[o] = A.col[rb + j]; sval[o] = A.val[rb + j]; }
+        else { scol[o] = padcol; sval[o] = 0.0; }
+      }
+    }
+  }
+}
+
+static void check_matrix(const amgx_matrix& A, const char* what) {
+  if (A.n_rows < 0 || A.n_cols < 0 || !A.rowptr) throw Err(std::string(what) + ": invalid matrix descriptor");
+  if (A.br < 1 || A.br > 6 || A.bc < 1 || A.bc > 6) throw Err(std::string(what) + ": block sizes must be in 1..6");
+  const int64_t nnz = A.rowptr[A.n_rows];
+  if (nnz > 0 && (!A.col || !A.val)) throw Err(std::string(what) + ": col / val missing");
+  if (nnz >= (int64_t)2147483647) throw Err(std::string(what) + ": more than 2^31-1 stored blocks are not supported on the device");
+  if (A.n_cols >= (int64_t)2147483647 / 8) throw Err(std::string(what) + ": too many columns for int32 indices");
+  for (int64_t i = 0; i < A.n_rows; ++i)
+    if (A.rowptr[i + 1] < A.rowptr[i]) throw Err(std::string(what) + ": rowptr is not monotone");
+  for (int64_t k = 0; k < nnz; ++k)
+    if (A.col[k] < 0 || A.col[k] >= A.n_cols) throw Err(std::string(what) + ": column index out of range");
+}
+
+static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true) {
+  check_matrix(A, what);
+  D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = A.br; D.bc = A.bc;
+  D.nnz = A.rowptr[A.n_rows];
+  const double avg = D.n_rows ? (double)D.nnz / (double)D.n_rows : 0.0;
+  D.lanes = pick_lanes(avg);
+  bool sell = false;
+  if (allow_sell && A.br == 1 && A.bc == 1 && D.n_rows > 0 && D.nnz > 0) {
+    // padding estimate
+    int64_t stored = 0;
+    for (int64_t s = 0; s * WAVE < A.n_rows; ++s) {
+      int w = 0;
+      for (int64_t r = s * WAVE; r < std::min<int64_t>(A.n_rows, (s + 1) * WAVE); ++r) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+      stored += (int64_t)w * WAVE;
+    }
+    sell = (double)stored <= 1.25 * (double)D.nnz;
+  }
+  if (sell) {
+    std::vector<int64_t> sp; std::vector<int32_t> sc; std::vector<double> sv;
+    build_sell(A, nullptr, A.n_rows, sp, sc, sv);
+    D.fmt = FMT_SELL;
+    D.n_slices = (int)(sp.size() - 1);
+    D.stored = sp.back();
+    D.slice_ptr.upload(sp); D.scol.upload(sc); D.sval.upload(sv);
+  } else {
+    D.fmt = FMT_CSRVEC;
+    D.stored = D.nnz;
+    std::vector<int32_t> rp(A.n_rows + 1);
+    for (int64_t i = 0; i <= A.n_rows; ++i) rp[i] = (int32_t)A.rowptr[i];
+    D.rowptr.upload(rp);
+    D.col.upload(A.col, D.nnz);
+    D.val.upload(A.val, (size_t)D.nnz * A.br * A.bc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the handle
+// ---------------------------------------------------------------------------------------------------
+
+struct Handle {
+  int device = 0;
+  std::vector<DevLevel> lev;
+  int cycle = AMGX_CYCLE_V, clev = AMGX_CLEV_INV;
+  int64_t coarse_n = 0;
+  DevBuf<double> coarse_inv;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  bool use_graph = true;
+  std::string err;
+  struct GraphKey { const double* b; double* x; int kind; bool operator<(const GraphKey& o) const { return std::tie(b, x, kind) < std::tie(o.b, o.x, o.kind); } };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  // staging for host-pointer calls
+  DevBuf<double> stage[3];
+
+  ~Handle() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+
+  int n_levels() const { return (int)lev.size(); }
+
+  // ------------------------------------------------------------------ primitive ops (all async on `stream`)
+  static int grid_for(int64_t threads) { return (int)std::max<int64_t>(1, (threads + BLOCK - 1) / BLOCK); }
+
+  template <int EP>
+  void spmv_ep(const DevMatrix& M, const double* x, double* y, const EpArgs& ep) {
+    if (M.n_rows == 0) return;
+    if (M.fmt == FMT_SELL) {
+      const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+      hipLaunchKernelGGL((sell_spmv_kernel<EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.slice_ptr.p, M.scol.p, M.sval.p, x, y, ep);
+    } else if (M.br == 1 && M.bc == 1) {
+      const int grid = grid_for(M.n_rows * M.lanes);
+#define LAUNCH_CSR(G) hipLaunchKernelGGL((csrvec_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
+      switch (M.lanes) {
+        case 2: LAUNCH_CSR(2); break;
+        case 4: LAUNCH_CSR(4); break;
+        case 8: LAUNCH_CSR(8); break;
+        case 16: LAUNCH_CSR(16); break;
+        case 32: LAUNCH_CSR(32); break;
+        default: LAUNCH_CSR(64); break;
+      }
+#undef LAUNCH_CSR
+    } else {
+      const int G = std::min(M.lanes, 16) < 2 ? 2 : std::min(M.lanes, 16);
+      const int grid = grid_for(M.n_rows * G);
+#define LAUNCH_B(BR, BC, GG) hipLaunchKernelGGL((bcsrvec_spmv_kernel<BR, BC, GG, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
+#define LAUNCH_BG(BR, BC)                                                                   \
+  switch (G) { case 2: LAUNCH_B(BR, BC, 2); break; case 4: LAUNCH_B(BR, BC, 4); break;     \
+               case 8: LAUNCH_B(BR, BC, 8); break; default: LAUNCH_B(BR, BC, 16); break; }
+      const int key = M.br * 10 + M.bc;
+      switch (key) {
+        case 22: LAUNCH_BG(2, 2); break;
+        case 33: LAUNCH_BG(3, 3); break;
+        case 66: LAUNCH_BG(6, 6); break;
+        case 36: LAUNCH_BG(3, 6); break;
+        case 63: LAUNCH_BG(6, 3); break;
+        case 23: LAUNCH_BG(2, 3); break;
+        case 32: LAUNCH_BG(3, 2); break;
+        case 13: LAUNCH_BG(1, 3); break;
+        case 31: LAUNCH_BG(3, 1); break;
+        case 16: LAUNCH_BG(1, 6); break;
+        case 61: LAUNCH_BG(6, 1); break;
+        case 12: LAUNCH_BG(1, 2); break;
+        case 21: LAUNCH_BG(2, 1); break;
+        default: throw Err("unsupported block shape " + std::to_string(M.br) + "x" + std::to_string(M.bc));
+      }
+#undef LAUNCH_BG
+#undef LAUNCH_B
+    }
+    HIPCHK(hipGetLastError());
+  }
+
+  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0}); }
+  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0}); }
+  // y = yin + s * M x
+  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s}); }
+  // xout = xin + omega * dinv * (b - A xin)
+  void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout) {
+    if (xin == xout) throw Err("jacobi_fused: in-place update is not allowed");
+    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega});
+  }
+
+  void zero(double* v, int64_t n) { if (n) HIPCHK(hipMemsetAsync(v, 0, n * sizeof(double), stream)); }
+  void copy(double* dst, const double* src, int64_t n) { if (n && dst != src) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, stream)); }
+
+  // x (+)= omega * dinv * v
+  void diag_apply(const DevLevel& L, const double* v, double* x, bool add) {
+    if (L.n == 0) return;
+    const int grid = grid_for(L.n);
+#define LAUNCH_D(BS)                                                                                                   \
+  if (add) hipLaunchKernelGGL((diag_apply_kernel<BS, true>), dim3(grid), dim3(BLOCK), 0, stream, L.n, L.dinv.p, v, x, L.omega); \
+  else hipLaunchKernelGGL((diag_apply_kernel<BS, false>), dim3(grid), dim3(BLOCK), 0, stream, L.n, L.dinv.p, v, x, L.omega)
+    switch (L.bs) {
+      case 1: LAUNCH_D(1); break;
+      case 2: LAUNCH_D(2); break;
+      case 3: LAUNCH_D(3); break;
+      case 6: LAUNCH_D(6); break;
+      default: throw Err("unsupported block size " + std::to_string(L.bs));
+    }
+#undef LAUNCH_D
+    HIPCHK(hipGetLastError());
+  }
+
+  void axpy(int64_t n, double s, const double* x, double* y) {
+    if (!n) return;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(BLOCK), 0, stream, n, s, x, y);
+    HIPCHK(hipGetLastError());
+  }
+
+  // one multicolour GS sweep (RHS form), forward: colours ascending, backward: descending
+  void gs_sweep(const DevLevel& L, int dir, double* x, const double* b) {
+    const DevGS& g = L.gs;
+    if (g.n_colors == 0 && L.n > 0) throw Err("Gauss-Seidel requested but the level has no colouring");
+    for (int q = 0; q < g.n_colors; ++q) {
+      const int c = dir == 0 ? q : g.n_colors - 1 - q;
+      if (L.bs == 1) {
+        const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
+        if (s1 == s0) continue;
+        const int grid = (s1 - s0 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        hipLaunchKernelGGL(gs_color_kernel, dim3(grid), dim3(BLOCK), 0, stream, s0, s1, g.slice_ptr.p, g.scol.p, g.sval.p, g.rowid.p, L.dinv.p, b, x);
+      } else {
+        const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
+        if (r1 == r0) continue;
+        const int G = std::max(2, std::min(L.A.lanes, 16));
+        const int grid = grid_for((int64_t)(r1 - r0) * G);
+#define LAUNCH_GS(BS, GG) hipLaunchKernelGGL((bgs_color_kernel<BS, GG>), dim3(grid), dim3(BLOCK), 0, stream, r0, r1, g.rowlist.p, L.A.rowptr.p, L.A.col.p, L.A.val.p, L.dinv.p, b, x)
+#define LAUNCH_GSG(BS) switch (G) { case 2: LAUNCH_GS(BS, 2); break; case 4: LAUNCH_GS(BS, 4); break; case 8: LAUNCH_GS(BS, 8); break; default: LAUNCH_GS(BS, 16); break; }
+        switch (L.bs) {
+          case 2: LAUNCH_GSG(2); break;
+          case 3: LAUNCH_GSG(3); break;
+          case 6: LAUNCH_GSG(6); break;
+          default: throw Err("unsupported block size for GS");
+        }
+#undef LAUNCH_GSG
+#undef LAUNCH_GS
+      }
+      HIPCHK(hipGetLastError());
+    }
+  }
+
+  void coarse_solve(const double* rhs, double* x) {
+    const DevLevel& L = lev.back();
+    if (clev != AMGX_CLEV_INV || coarse_n == 0) { zero(x, L.len()); return; }   // amg_matrix.cpp:242-246
+    const int grid = (int)((coarse_n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(BLOCK), 0, stream, (int)coarse_n, coarse_inv.p, rhs, x);
+    HIPCHK(hipGetLastError());
+  }
+
+  void transfer_f2c(int l, const double* xf, double* xc) { mult(lev[l].PT, xf, xc); }                      // dof_map.cpp:636-654
+  void add_c2f(int l, double fac, double* xf, const double* xc) { mult_add(lev[l].P, fac, xc, xf, xf); }   // dof_map.cpp:697-709
+
+  // ------------------------------------------------------------------ smoothers (flag contract: base_smoother.hpp:68-112)
+  void base_smooth(DevLevel& L, int dir, double* x, const double* b, double* res, bool res_updated, bool update_res, bool x_zero) {
+    if (L.sm_type == AMGX_SM_JACOBI) {
+      // RichardsonSmoother::Smooth, base_smoother.cpp:61-74 (SmoothBack identical)
+      if (!res_updated && x_zero) diag_apply(L, b, x, true);
+      else {
+        if (!res_updated) residual(L.A, x, b, res);
+        diag_apply(L, res, x, true);
+      }
+      if (update_res) residual(L.A, x, b, res);
+    } else {
+      // GSS3::Smooth / SmoothBack (gssmoother.cpp:350-398).  The reference keeps the residual current with
+      // row-transpose scatters (RES form); for symmetric A the gather (RHS) form followed by one residual
+      // SpMV gives the same x and res, and it has no write conflicts on a GPU.
+      gs_sweep(L, dir, x, b);
+      if (update_res) residual(L.A, x, b, res);
+    }
+  }
+
+  void smooth_symm(DevLevel& L, double* x, const double* b, double* res, bool ru, bool ur, bool xz) {
+    base_smooth(L, 0, x, b, res, ru, ur, xz);
+    base_smooth(L, 1, x, b, res, ur, ur, false);
+  }
+
+  // ProxySmoother (base_smoother.hpp:169-229), present iff sm_symm || sm_steps > 1 (amg_pc.cpp:1079-1082)
+  void level_smooth(DevLevel& L, int dir, double* x, const double* b, double* res, bool ru, bool ur, bool xz) {
+    const int k = std::max(1, L.sm_steps);
+    if (!L.sm_symm && k == 1) { base_smooth(L, dir, x, b, res, ru, ur, xz); return; }
+    if (L.sm_symm) {
+      smooth_symm(L, x, b, res, ru, ur, xz);
+      for (int j = 1; j < k; ++j) smooth_symm(L, x, b, res, ur, ur, false);
+    } else {
+      base_smooth(L, dir, x, b, res, ru, ur, xz);
+      for (int j = 1; j < k; ++j) base_smooth(L, dir, x, b, res, ur, ur, false);
+    }
+  }
+
+  bool plain(const DevLevel& L) const { return L.sm_steps <= 1 && !L.sm_symm; }
+
+  // pre-smoothing step of the cycles: x = 0; r = b; Smooth(x, b, r, 1, 1, 1)   (amg_matrix.cpp:193-206)
+  void pre_smooth(DevLevel& L, double* x, const double* b, double* r) {
+    if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
+      diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
+      residual(L.A, x, b, r);              // r = b - A x
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS) {
+      zero(x, L.len());
+      gs_sweep(L, 0, x, b);
+      residual(L.A, x, b, r);
+    } else {
+      zero(x, L.len());
+      copy(r, b, L.len());
+      level_smooth(L, 0, x, b, r, true, true, true);
+    }
+  }
+
+  // coarse-grid correction + post-smoothing: x += P x_c; SmoothBack(x, b, r, 0, 0, 0)   (amg_matrix.cpp:263-302)
+  void post_smooth(int l, double* x, const double* b, double* r, const double* xc) {
+    DevLevel& L = lev[l];
+    if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
+      mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
+      jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
+    } else {
+      add_c2f(l, 1.0, x, xc);
+      level_smooth(L, 1, x, b, r, false, false, false);
+    }
+  }
+
+  // ------------------------------------------------------------------ cycles
+  void cycle_v(double* x, const double* b) {
+    const int L = n_levels();
+    if (L == 1) { coarse_solve(b, x); return; }
+    for (int l = 0; l + 1 < L; ++l) {
+      double* xl = l == 0 ? x : lev[l].x.p;
+      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      pre_smooth(lev[l], xl, bl, lev[l].res.p);
+      transfer_f2c(l, lev[l].res.p, lev[l + 1].rhs.p);
+    }
+    coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
+    for (int l = L - 2; l >= 0; --l) {
+      double* xl = l == 0 ? x : lev[l].x.p;
+      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      post_smooth(l, xl, bl, lev[l].res.p, lev[l + 1].x.p);
+    }
+  }
+
+  // plain W-cycle (the reference additionally runs and discards a V-like pass at level 0, amg_matrix.cpp:46-64)
+  void w_rec(int l, double* x0, const double* b0) {
+    const int L = n_levels();
+    if (l + 1 < L) {
+      DevLevel& V = lev[l];
+      double* xl = l == 0 ? x0 : V.x.p;
+      const double* bl = l == 0 ? b0 : V.rhs.p;
+      double* rl = V.res.p;
+      pre_smooth(V, xl, bl, rl);
+      transfer_f2c(l, rl, lev[l + 1].rhs.p);
+      w_rec(l + 1, x0, b0);
+      add_c2f(l, 1.0, xl, lev[l + 1].x.p);
+      level_smooth(V, 1, xl, bl, rl, false, true, false);
+      level_smooth(V, 0, xl, bl, rl, true, true, false);
+      transfer_f2c(l, rl, lev[l + 1].rhs.p);
+      w_rec(l + 1, x0, b0);
+      post_smooth(l, xl, bl, rl, lev[l + 1].x.p);
+    } else {
+      if (L == 1) coarse_solve(b0, x0);
+      else coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
+    }
+  }
+
+  // AMGMatrix::SmoothVFromLevel, amg_matrix.cpp:310-374
+  void smooth_v_from_level(int start, double* x, const double* b, double* res, bool ru, bool ur, bool xz) {
+    const int L = n_levels();
+    level_smooth(lev[start], 0, x, b, res, ru, true, xz);
+    transfer_f2c(start, res, lev[start + 1].rhs.p);
+    if (start + 2 < L)
+      for (int l = start + 1; l + 1 < L; ++l) {
+        pre_smooth(lev[l], lev[l].x.p, lev[l].rhs.p, lev[l].res.p);
+        transfer_f2c(l, lev[l].res.p, lev[l + 1].rhs.p);
+      }
+    coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
+    if (start + 2 < L)
+      for (int l = L - 2; l > start; --l) post_smooth(l, lev[l].x.p, lev[l].rhs.p, lev[l].res.p, lev[l + 1].x.p);
+    add_c2f(start, 1.0, x, lev[start + 1].x.p);
+    level_smooth(lev[start], 1, x, b, res, false, ur, false);
+  }
+
+  // AMGMatrix::SmoothBS, amg_matrix.cpp:110-157
+  void cycle_bs(double* x, const double* b) {
+    const int L = n_levels();
+    if (L == 1) { coarse_solve(b, x); return; }
+    for (int l = 0; l + 1 < L; ++l) {
+      double* xl = l == 0 ? x : lev[l].x.p;
+      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      double* rl = lev[l].res.p;
+      zero(xl, lev[l].len());
+      copy(rl, bl, lev[l].len());
+      smooth_v_from_level(l, xl, bl, rl, true, true, true);
+      transfer_f2c(l, rl, lev[l + 1].rhs.p);
+    }
+    coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
+    for (int l = L - 2; l >= 0; --l) {
+      double* xl = l == 0 ? x : lev[l].x.p;
+      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      add_c2f(l, 1.0, xl, lev[l + 1].x.p);
+      smooth_v_from_level(l, xl, bl, lev[l].res.p, false, false, false);
+    }
+  }
+
+  void do_cycle(double* x, const double* b) {
+    if (cycle == AMGX_CYCLE_W) w_rec(0, x, b);
+    else if (cycle == AMGX_CYCLE_BS) cycle_bs(x, b);
+    else cycle_v(x, b);
+  }
+
+  // one application, optionally through a captured graph keyed by the vector addresses
+  void run_cycle(double* x, const double* b, bool graph_ok) {
+    // the legacy default stream cannot be captured: launch directly there
+    if (!(use_graph && graph_ok) || stream == nullptr) { do_cycle(x, b); return; }
+    GraphKey key{b, x, 0};
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try { do_cycle(x, b); }
+      catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(stream, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
+      HIPCHK(hipStreamEndCapture(stream, &g));
+      hipGraphExec_t ge = nullptr;
+      hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e != hipSuccess) throw Err(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+      if (graphs.size() >= 16) { for (auto& q : graphs) (void)hipGraphExecDestroy(q.second); graphs.clear(); }
+      it = graphs.emplace(key, ge).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, stream));
+  }
+
+  void drop_graphs() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------------------------------
+
+static void build_gs(const amgx_level_desc& d, DevLevel& L) {
+  const int64_t n = d.A.n_rows;
+  if (!d.color || d.n_colors <= 0) { if (n > 0) throw Err("AMGX_SM_GS needs a row colouring (color / n_colors)"); return; }
+  const int nc = d.n_colors;
+  // validate: rows of equal colour must not be coupled (otherwise the parallel sweep would race)
+  for (int64_t i = 0; i < n; ++i) {
+    const int ci = d.color[i];
+    if (ci >= nc) throw Err("colour index out of range");
+    if (ci < 0) continue;
+    for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+      const int64_t j = d.A.col[k];
+      if (j != i && d.color[j] == ci) throw Err("invalid colouring: two coupled rows share a colour");
+    }
+  }
+  std::vector<int64_t> cnt(nc + 1, 0);
+  for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) cnt[d.color[i] + 1]++;
+  DevGS& g = L.gs;
+  g.n_colors = nc;
+  if (d.A.br == 1) {
+    // colour-major row list, each colour padded to a multiple of 64 rows
+    std::vector<int64_t> cstart(nc + 1, 0);
+    for (int c = 0; c < nc; ++c) cstart[c + 1] = cstart[c] + ((cnt[c + 1] + WAVE - 1) / WAVE) * WAVE;
+    std::vector<int32_t> rows(cstart[nc], -1);
+    std::vector<int64_t> pos(cstart.begin(), cstart.end() - 1);
+    for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
+    g.color_slice_ptr.resize(nc + 1);
+    for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / WAVE);
+    std::vector<int64_t> sp; std::vector<int32_t> sc; std::vector<double> sv;
+    build_sell(d.A, rows.data(), (int64_t)rows.size(), sp, sc, sv);
+    g.slice_ptr.upload(sp); g.scol.upload(sc); g.sval.upload(sv); g.rowid.upload(rows);
+  } else {
+    g.color_row_ptr.assign(nc + 1, 0);
+    for (int c = 0; c < nc; ++c) g.color_row_ptr[c + 1] = g.color_row_ptr[c] + (int)cnt[c + 1];
+    std::vector<int32_t> rows(g.color_row_ptr[nc]);
+    std::vector<int> pos(g.color_row_ptr.begin(), g.color_row_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
+    g.rowlist.upload(rows);
+  }
+}
+
+static Handle* create(const amgx_hierarchy_desc* d) {
+  if (!d || d->n_levels < 1 || !d->levels) throw Err("amgx_create: empty hierarchy descriptor");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) throw Err("amgx_create: no HIP device available (the apply path has no CPU fallback)");
+  if (d->device < 0 || d->device >= ndev) throw Err("amgx_create: device ordinal out of range");
+  HIPCHK(hipSetDevice(d->device));
+  auto h = std::make_unique<Handle>();
+  h->device = d->device;
+  h->cycle = d->cycle;
+  h->clev = d->clev;
+  h->use_graph = d->use_graph != 0;
+  if (d->cycle < 0 || d->cycle > 2) throw Err("amgx_create: unknown cycle");
+  HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  h->lev.resize(d->n_levels);
+  for (int l = 0; l < d->n_levels; ++l) {
+    const amgx_level_desc& s = d->levels[l];
+    DevLevel& L = h->lev[l];
+    if (s.A.n_rows != s.A.n_cols || s.A.br != s.A.bc) throw Err("level matrix must be square with square blocks");
+    L.n = s.A.n_rows; L.bs = s.A.br;
+    L.sm_type = s.sm_type; L.omega = s.omega; L.sm_steps = s.sm_steps; L.sm_symm = s.sm_symm;
+    if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS) throw Err("unknown smoother type");
+    const bool last = (l + 1 == d->n_levels);
+    // block GS walks the CSR arrays of A, so keep A in CSR there
+    upload_matrix(s.A, L.A, "A", !(s.sm_type == AMGX_SM_GS && s.A.br > 1));
+    if (!last) {
+      const amgx_level_desc& c = d->levels[l + 1];
+      if (s.P.n_rows != s.A.n_rows || s.P.n_cols != c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
+        throw Err("P does not match the level matrices");
+      if (s.PT.n_rows != s.P.n_cols || s.PT.n_cols != s.P.n_rows || s.PT.br != s.P.bc || s.PT.bc != s.P.br)
+        throw Err("PT does not match P");
+      upload_matrix(s.P, L.P, "P");
+      upload_matrix(s.PT, L.PT, "PT");
+      if (!s.dinv) throw Err("dinv missing");
+      L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
+      if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
+    } else if (s.dinv) {
+      L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
+      if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
+    }
+    const size_t len = (size_t)std::max<int64_t>(1, L.len());
+    L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
+    HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));
+    HIPCHK(hipMemset(L.rhs.p, 0, len * sizeof(double)));
+    HIPCHK(hipMemset(L.res.p, 0, len * sizeof(double)));
+    HIPCHK(hipMemset(L.tmp.p, 0, len * sizeof(double)));
+  }
+  if (d->clev == AMGX_CLEV_INV) {
+    const DevLevel& L = h->lev.back();
+    if (d->coarse_n != L.len() || !d->coarse_inv) throw Err("clev = inv needs the dense coarse inverse of matching size");
+    h->coarse_n = d->coarse_n;
+    h->coarse_inv.upload(d->coarse_inv, (size_t)d->coarse_n * d->coarse_n);
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return h.release();
+}
+
+}  // namespace amgx
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+
+struct amgx_handle_t { amgx::Handle* h; };
+
+namespace {
+thread_local std::string g_create_err;
+
+template <class F>
+int guard(amgx_handle hh, F&& f) {
+  try {
+    if (!hh || !hh->h) throw amgx::Err("null handle");
+    HIPCHK(hipSetDevice(hh->h->device));
+    f(*hh->h);
+    return 0;
+  } catch (const std::exception& e) {
+    if (hh && hh->h) hh->h->err = e.what(); else g_create_err = e.what();
+    return 1;
+  }
+}
+
+// stage host vectors on the device when the caller passed host pointers
+struct Staged {
+  amgx::Handle& h;
+  bool host;
+  Staged(amgx::Handle& hh, int flags) : h(hh), host(!(flags & AMGX_DEVICE_PTR)) {}
+  const double* in(int slot, const double* p, int64_t n) {
+    if (!host || !p) return p;
+    if ((int64_t)h.stage[slot].n < n) h.stage[slot].alloc(n);
+    HIPCHK(hipMemcpyAsync(h.stage[slot].p, p, n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    return h.stage[slot].p;
+  }
+  double* inout(int slot, double* p, int64_t n, bool load) {
+    if (!host || !p) return p;
+    if ((int64_t)h.stage[slot].n < n) h.stage[slot].alloc(n);
+    if (load) HIPCHK(hipMemcpyAsync(h.stage[slot].p, p, n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+    return h.stage[slot].p;
+  }
+  void out(int slot, double* p, int64_t n) {
+    if (!host || !p) return;
+    HIPCHK(hipMemcpyAsync(p, h.stage[slot].p, n * sizeof(double), hipMemcpyDeviceToHost, h.stream));
+  }
+  void finish() { if (host) HIPCHK(hipStreamSynchronize(h.stream)); }
+};
+}  // namespace
+
+extern "C" {
+
+const char* amgx_last_error(amgx_handle h) { return (h && h->h) ? h->h->err.c_str() : g_create_err.c_str(); }
+
+int amgx_create(const amgx_hierarchy_desc* desc, amgx_handle* out) {
+  try {
+    if (!out) throw amgx::Err("amgx_create: null output");
+    amgx::Handle* h = amgx::create(desc);
+    *out = new amgx_handle_t{h};
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
+}
+
+int amgx_destroy(amgx_handle h) {
+  if (!h) return 0;
+  if (h->h) { (void)hipSetDevice(h->h->device); (void)hipDeviceSynchronize(); delete h->h; }
+  delete h;
+  return 0;
+}
+
+int amgx_set_stream(amgx_handle hh, void* s) {
+  return guard(hh, [&](amgx::Handle& h) {
+    hipStream_t ns = (hipStream_t)s;     // NULL = the legacy default stream (what torch uses unless told otherwise)
+    if (ns != h.stream) { HIPCHK(hipStreamSynchronize(h.stream)); h.drop_graphs(); h.stream = ns; }
+  });
+}
+
+int amgx_synchronize(amgx_handle hh) { return guard(hh, [&](amgx::Handle& h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
+
+int amgx_apply(amgx_handle hh, const double* b, double* x, int b_status, int flags) {
+  (void)b_status;   // single GPU: DISTRIBUTED == CUMULATED (b.Distribute() is a no-op, amg_matrix.cpp:164)
+  return guard(hh, [&](amgx::Handle& h) {
+    if (!b || !x) throw amgx::Err("amgx_apply: null vector");
+    if (b == x) throw amgx::Err("amgx_apply: b and x must not alias");
+    const int64_t n = h.lev[0].len();
+    Staged st(h, flags);
+    const double* db = st.in(0, b, n);
+    double* dx = st.inout(1, x, n, false);
+    h.run_cycle(dx, db, !(flags & AMGX_NO_GRAPH));
+    st.out(1, x, n);
+    st.finish();
+  });
+}
+
+int amgx_apply_add(amgx_handle hh, double s, const double* b, double* x, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (!b || !x) throw amgx::Err("amgx_apply_add: null vector");
+    const int64_t n = h.lev[0].len();
+    Staged st(h, flags);
+    const double* db = st.in(0, b, n);
+    double* dx = st.inout(1, x, n, true);
+    h.run_cycle(h.lev[0].x.p, db, !(flags & AMGX_NO_GRAPH));     // cycle into x_level[0] (amg_matrix.cpp:385-389)
+    h.axpy(n, s, h.lev[0].x.p, dx);
+    st.out(1, x, n);
+    st.finish();
+  });
+}
+
+int amgx_smooth(amgx_handle hh, int level, int dir, double* x, const double* b, double* res,
+                int res_updated, int update_res, int x_zero, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_smooth: level out of range");
+    amgx::DevLevel& L = h.lev[level];
+    if (!L.dinv.p) throw amgx::Err("amgx_smooth: level has no smoother");
+    if (!x || !b || !res) throw amgx::Err("amgx_smooth: null vector");
+    const int64_t n = L.len();
+    Staged st(h, flags);
+    double* dx = st.inout(0, x, n, true);
+    const double* db = st.in(1, b, n);
+    double* dr = st.inout(2, res, n, true);
+    h.level_smooth(L, dir, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
+    st.out(0, x, n);
+    st.out(2, res, n);
+    st.finish();
+  });
+}
+
+int amgx_smooth_v_from_level(amgx_handle hh, int level, double* x, const double* b, double* res,
+                             int res_updated, int update_res, int x_zero, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_smooth_v_from_level: level out of range");
+    const int64_t n = h.lev[level].len();
+    Staged st(h, flags);
+    double* dx = st.inout(0, x, n, true);
+    const double* db = st.in(1, b, n);
+    double* dr = st.inout(2, res, n, true);
+    h.smooth_v_from_level(level, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
+    st.out(0, x, n);
+    st.out(2, res, n);
+    st.finish();
+  });
+}
+
+int amgx_matvec(amgx_handle hh, int level, const double* x, double* y, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matvec: level out of range");
+    if (!x || !y || x == y) throw amgx::Err("amgx_matvec: bad vectors");
+    const int64_t n = h.lev[level].len();
+    Staged st(h, flags);
+    const double* dx = st.in(0, x, n);
+    double* dy = st.inout(1, y, n, false);
+    h.mult(h.lev[level].A, dx, dy);
+    st.out(1, y, n);
+    st.finish();
+  });
+}
+
+int amgx_transfer_f2c(amgx_handle hh, int level, const double* xf, double* xc, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_transfer_f2c: level out of range");
+    Staged st(h, flags);
+    const double* df = st.in(0, xf, h.lev[level].len());
+    double* dc = st.inout(1, xc, h.lev[level + 1].len(), false);
+    h.transfer_f2c(level, df, dc);
+    st.out(1, xc, h.lev[level + 1].len());
+    st.finish();
+  });
+}
+
+int amgx_add_c2f(amgx_handle hh, int level, double fac, double* xf, const double* xc, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_add_c2f: level out of range");
+    Staged st(h, flags);
+    double* df = st.inout(0, xf, h.lev[level].len(), true);
+    const double* dc = st.in(1, xc, h.lev[level + 1].len());
+    h.add_c2f(level, fac, df, dc);
+    st.out(0, xf, h.lev[level].len());
+    st.finish();
+  });
+}
+
+int amgx_coarse_solve(amgx_handle hh, const double* rhs, double* x, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    const int64_t n = h.lev.back().len();
+    Staged st(h, flags);
+    const double* dr = st.in(0, rhs, n);
+    double* dx = st.inout(1, x, n, false);
+    h.coarse_solve(dr, dx);
+    st.out(1, x, n);
+    st.finish();
+  });
+}
+
+int amgx_n_levels(amgx_handle h) { return (h && h->h) ? h->h->n_levels() : 0; }
+
+int amgx_level_info(amgx_handle hh, int level, int64_t* n, int32_t* bs, int64_t* nnz) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_level_info: level out of range");
+    if (n) *n = h.lev[level].n;
+    if (bs) *bs = h.lev[level].bs;
+    if (nnz) *nnz = h.lev[level].A.nnz;
+  });
+}
+
+int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t* stored, int32_t* lanes) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matrix_info: level out of range");
+    const amgx::DevMatrix& M = which == 0 ? h.lev[level].A : (which == 1 ? h.lev[level].P : h.lev[level].PT);
+    if (fmt) *fmt = M.fmt;
+    if (stored) *stored = M.stored;
+    if (lanes) *lanes = M.lanes;
+  });
+}
+
+int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_time_op: level out of range");
+    if (reps < 1 || !avg_ms) throw amgx::Err("amgx_time_op: bad arguments");
+    amgx::DevLevel& L = h.lev[level];
+    const bool has_c = level + 1 < h.n_levels();
+    if ((op == 2 || op == 3) && !has_c) throw amgx::Err("amgx_time_op: no transfer on the coarsest level");
+    if (op == 1 && (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI)) throw amgx::Err("amgx_time_op: level has no Jacobi smoother");
+    auto launch = [&]() {
+      switch (op) {
+        case 0: h.residual(L.A, L.x.p, L.rhs.p, L.res.p); break;
+        case 1: h.jacobi_fused(L, L.tmp.p, L.rhs.p, L.x.p); break;
+        case 2: h.transfer_f2c(level, L.res.p, h.lev[level + 1].rhs.p); break;
+        case 3: h.mult_add(L.P, 1.0, h.lev[level + 1].x.p, L.x.p, L.tmp.p); break;
+        case 4: h.run_cycle(h.lev[0].x.p, h.lev[0].rhs.p, true); break;
+        default: throw amgx::Err("amgx_time_op: unknown op");
+      }
+    };
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    launch();                                    // warm-up (and graph capture for op 4)
+    HIPCHK(hipStreamSynchronize(h.stream));
+    HIPCHK(hipEventRecord(e0, h.stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIPCHK(hipEventRecord(e1, h.stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+  });
+}
+
+}  // extern "C"

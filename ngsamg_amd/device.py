@@ -1,0 +1,241 @@
+"""Device-resident AMG matrix: Python handle over the C ABI of include/amgx.h.
+
+Mirrors the reference's ``AMGMatrix`` (reference src/base/solve/amg_matrix.hpp:14-87, pybind surface
+src/base/solve/python_solve.cpp:55-109): ``Mult`` / ``MultAdd`` run one multigrid cycle, ``GetSmoother(level)``
+exposes ``Smooth`` / ``SmoothBack`` with the reference's flag contract, ``GetMap()`` the grid transfers.
+
+Vectors may be numpy arrays (host: one H2D and one D2H copy per call, like a CPU caller of the reference)
+or torch CUDA tensors (device resident: no copies; the work is enqueued on torch's current stream).
+There is no CPU fallback: without the HIP library or without a GPU, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NgsAMGError
+
+_SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS}
+
+
+def _is_torch(v):
+    return hasattr(v, "data_ptr") and hasattr(v, "is_cuda")
+
+
+class _Vec:
+    """Resolve a vector argument into (address, flags) and keep it alive for the call."""
+
+    def __init__(self, v, n, name, writable=False):
+        self.torch = _is_torch(v)
+        if self.torch:
+            import torch
+            if not v.is_cuda:
+                raise NgsAMGError(f"{name}: torch tensors must live on the GPU")
+            if v.dtype != torch.float64 or not v.is_contiguous() or v.numel() != n:
+                raise NgsAMGError(f"{name}: need a contiguous float64 tensor with {n} entries")
+            self.obj = v
+            self.addr = v.data_ptr()
+        else:
+            a = v if isinstance(v, np.ndarray) else np.asarray(v, dtype=np.float64)
+            if a.dtype != np.float64 or not a.flags.c_contiguous or a.size != n:
+                if writable:
+                    raise NgsAMGError(f"{name}: need a contiguous float64 array with {n} entries")
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                if a.size != n:
+                    raise NgsAMGError(f"{name}: need {n} entries, got {a.size}")
+            self.obj = a
+            self.addr = a.ctypes.data
+
+
+class DeviceAMGMatrix:
+    def __init__(self, hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False, mg_cycle="V",
+                 clev="inv", device=0, use_graph=True):
+        lib = _lib.hip()
+        self._lib = lib
+        self.hierarchy = hierarchy
+        levels = hierarchy.levels
+        n = len(levels)
+        types = sm_type if isinstance(sm_type, (list, tuple)) else [sm_type] * n
+        if len(types) != n:
+            raise NgsAMGError("sm_type list must have one entry per level")
+        arr = (_lib.amgx_level_desc * n)()
+        self._keep = [arr]
+        for i, lv in enumerate(levels):
+            d = arr[i]
+            d.A = lv.A.desc(_lib.amgx_matrix)
+            if lv.P is not None:
+                d.P = lv.P.desc(_lib.amgx_matrix)
+                d.PT = lv.PT.desc(_lib.amgx_matrix)
+            d.dinv = _lib.ptr(lv.dinv, C.c_double)
+            d.free_dofs = _lib.ptr(lv.free, C.c_uint8)
+            if types[i] not in _SM:
+                raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs)")
+            d.sm_type = _SM[types[i]]
+            d.omega = float(omega)
+            d.sm_steps = int(sm_steps)
+            d.sm_symm = int(bool(sm_symm))
+            d.color = _lib.ptr(lv.color, C.c_int32)
+            d.n_colors = int(lv.n_colors)
+        desc = _lib.amgx_hierarchy_desc()
+        desc.n_levels = n
+        desc.levels = arr
+        if mg_cycle not in _lib.AMGX_CYCLE:
+            raise NgsAMGError(f"unknown mg_cycle '{mg_cycle}' (V | W | BS)")
+        desc.cycle = _lib.AMGX_CYCLE[mg_cycle]
+        if clev == "inv" and hierarchy.coarse_n == 0:
+            raise NgsAMGError("clev = inv but the hierarchy has no coarse inverse")
+        desc.clev = _lib.AMGX_CLEV_INV if clev == "inv" else _lib.AMGX_CLEV_NONE
+        desc.coarse_n = hierarchy.coarse_n if clev == "inv" else 0
+        desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
+        desc.device = int(device)
+        desc.use_graph = int(bool(use_graph))
+        self._h = C.c_void_p()
+        if lib.amgx_create(C.byref(desc), C.byref(self._h)) != 0:
+            raise NgsAMGError(lib.amgx_last_error(None).decode())
+        self.sizes = [lv.A.n_rows * lv.A.br for lv in levels]
+        self.n_levels = n
+        self._stream = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.amgx_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise NgsAMGError(self._lib.amgx_last_error(self._h).decode())
+
+    def _flags(self, *vecs, graph=True):
+        t = [v.torch for v in vecs]
+        if any(t) and not all(t):
+            raise NgsAMGError("mixing host arrays and device tensors in one call is not supported")
+        f = _lib.AMGX_DEVICE_PTR if all(t) and t else _lib.AMGX_HOST_PTR
+        if all(t) and t:
+            import torch
+            s = int(torch.cuda.current_stream().cuda_stream)
+            if s != self._stream:
+                self._ck(self._lib.amgx_set_stream(self._h, C.c_void_p(s)))
+                self._stream = s
+        if not graph:
+            f |= _lib.AMGX_NO_GRAPH
+        return f
+
+    def synchronize(self):
+        self._ck(self._lib.amgx_synchronize(self._h))
+
+    def _size(self, level):
+        if not (0 <= level < self.n_levels):
+            raise NgsAMGError(f"level {level} out of range (0..{self.n_levels - 1})")
+        return self.sizes[level]
+
+    # AMGMatrix::Mult / MultAdd ---------------------------------------------------------------
+    def Mult(self, b, x, graph=True):
+        vb, vx = _Vec(b, self.sizes[0], "b"), _Vec(x, self.sizes[0], "x", True)
+        self._ck(self._lib.amgx_apply(self._h, vb.addr, vx.addr, 0, self._flags(vb, vx, graph=graph)))
+        return x
+
+    def MultAdd(self, s, b, x, graph=True):
+        vb, vx = _Vec(b, self.sizes[0], "b"), _Vec(x, self.sizes[0], "x", True)
+        self._ck(self._lib.amgx_apply_add(self._h, float(s), vb.addr, vx.addr, self._flags(vb, vx, graph=graph)))
+        return x
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+    def apply(self, b):
+        """convenience: returns a new vector C b of the same kind as b"""
+        if _is_torch(b):
+            import torch
+            x = torch.empty_like(b)
+        else:
+            x = np.empty(self.sizes[0])
+        return self.Mult(b, x)
+
+    # smoothers ---------------------------------------------------------------------------------
+    def Smooth(self, level, x, b, res, res_updated=False, update_res=False, x_zero=False, back=False):
+        n = self._size(level)
+        vx, vb, vr = _Vec(x, n, "x", True), _Vec(b, n, "b"), _Vec(res, n, "res", True)
+        self._ck(self._lib.amgx_smooth(self._h, level, 1 if back else 0, vx.addr, vb.addr, vr.addr,
+                                       int(res_updated), int(update_res), int(x_zero), self._flags(vx, vb, vr)))
+
+    def SmoothVFromLevel(self, level, x, b, res, res_updated=False, update_res=False, x_zero=False):
+        n = self._size(level)
+        vx, vb, vr = _Vec(x, n, "x", True), _Vec(b, n, "b"), _Vec(res, n, "res", True)
+        self._ck(self._lib.amgx_smooth_v_from_level(self._h, level, vx.addr, vb.addr, vr.addr, int(res_updated),
+                                                    int(update_res), int(x_zero), self._flags(vx, vb, vr)))
+
+    # matrices / transfers ---------------------------------------------------------------------
+    def MatVec(self, level, x, y):
+        n = self._size(level)
+        vx, vy = _Vec(x, n, "x"), _Vec(y, n, "y", True)
+        self._ck(self._lib.amgx_matvec(self._h, level, vx.addr, vy.addr, self._flags(vx, vy)))
+        return y
+
+    def TransferF2C(self, level, x_fine, x_coarse):
+        vf, vc = _Vec(x_fine, self._size(level), "x_fine"), _Vec(x_coarse, self._size(level + 1), "x_coarse", True)
+        self._ck(self._lib.amgx_transfer_f2c(self._h, level, vf.addr, vc.addr, self._flags(vf, vc)))
+        return x_coarse
+
+    def AddC2F(self, level, fac, x_fine, x_coarse):
+        vf, vc = _Vec(x_fine, self._size(level), "x_fine", True), _Vec(x_coarse, self._size(level + 1), "x_coarse")
+        self._ck(self._lib.amgx_add_c2f(self._h, level, float(fac), vf.addr, vc.addr, self._flags(vf, vc)))
+        return x_fine
+
+    def CoarseSolve(self, rhs, x):
+        n = self.sizes[-1]
+        vr, vx = _Vec(rhs, n, "rhs"), _Vec(x, n, "x", True)
+        self._ck(self._lib.amgx_coarse_solve(self._h, vr.addr, vx.addr, self._flags(vr, vx)))
+        return x
+
+    # queries ------------------------------------------------------------------------------------
+    def GetNLevels(self, rank=0):
+        return self._lib.amgx_n_levels(self._h)
+
+    def level_info(self, level):
+        n, bs, nnz = C.c_int64(), C.c_int32(), C.c_int64()
+        self._ck(self._lib.amgx_level_info(self._h, level, C.byref(n), C.byref(bs), C.byref(nnz)))
+        return n.value, bs.value, nnz.value
+
+    def matrix_info(self, level, which):
+        fmt, stored, lanes = C.c_int32(), C.c_int64(), C.c_int32()
+        self._ck(self._lib.amgx_matrix_info(self._h, level, {"A": 0, "P": 1, "PT": 2}[which], C.byref(fmt),
+                                            C.byref(stored), C.byref(lanes)))
+        return {"fmt": "sell" if fmt.value == 1 else "csrvec", "stored": stored.value, "lanes": lanes.value}
+
+    def time_op(self, level, op, reps=20):
+        ms = C.c_double()
+        self._ck(self._lib.amgx_time_op(self._h, level, int(op), int(reps), C.byref(ms)))
+        return ms.value
+
+
+# ---------------------------------------------------------------------------------------------
+# byte model of SURVEY.md section 8d / BASELINE.md (algorithmic bytes per cycle)
+# ---------------------------------------------------------------------------------------------
+
+def matrix_bytes(M):
+    """B(M) = nnz*(8*br*bc + 4) + 4*(n+1): fp64 values, int32 columns, int32 row pointers."""
+    if M is None:
+        return 0
+    return M.nnz * (8 * M.br * M.bc + 4) + 4 * (M.n_rows + 1)
+
+
+def vcycle_bytes(hierarchy):
+    """Algorithmic bytes of one Jacobi V(1,1) cycle:
+    per level 2 B(A) + B(P) + B(PT) + 16 b^2 n + 15 V_l + 2 V_{l+1}; coarsest 8 (n b)^2 + 2 V."""
+    total = 0
+    per_level = []
+    L = hierarchy.levels
+    for i, lv in enumerate(L):
+        V = 8 * lv.bs * lv.n
+        if i + 1 < len(L):
+            Vc = 8 * L[i + 1].bs * L[i + 1].n
+            b = 2 * matrix_bytes(lv.A) + matrix_bytes(lv.P) + matrix_bytes(lv.PT) + 16 * lv.bs * lv.bs * lv.n + 15 * V + 2 * Vc
+        else:
+            b = 8 * (lv.n * lv.bs) ** 2 + 2 * V
+        per_level.append(b)
+        total += b
+    return total, per_level

@@ -1,0 +1,166 @@
+"""GPU parity tests: every call goes through the C ABI (include/amgx.h) and is compared with the CPU oracle
+on the same seeded inputs.  Tolerances: Jacobi cycles 1e-12 relative (summation order only),
+GS with identical ordering 1e-10."""
+import numpy as np
+import pytest
+
+from tests.problems import poisson_case, rhs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _dev(H, **kw):
+    from ngsamg_amd.device import DeviceAMGMatrix
+    return DeviceAMGMatrix(H, device=0, **kw)
+
+
+CASES = [((33, 33), "left|top", 5), ((17, 17, 17), "right|top", 20), ((40, 23), "right", 10), ((9, 30, 13), ".*", 20)]
+
+
+@pytest.mark.parametrize("shape,diri,mcs", CASES)
+@pytest.mark.parametrize("sm,osm,tol", [("jacobi", "jacobi", 1e-12), ("gs", "gs_mc", 1e-10)])
+@pytest.mark.parametrize("cycle", ["V", "W", "BS"])
+def test_cycle_matches_oracle_host_vectors(shape, diri, mcs, sm, osm, tol, cycle):
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case(shape, diri, mcs)
+    b = rhs(p)
+    ref = Oracle(H.levels, sm_type=osm, cycle=cycle).apply(b)
+    dev = _dev(H, sm_type=sm, mg_cycle=cycle)
+    x = np.full(p.n, np.nan)
+    dev.Mult(b, x)
+    assert _rel(x, ref) < tol
+    # MultAdd: x += s * C b
+    y = np.ones(p.n)
+    dev.MultAdd(-0.5, b, y)
+    assert _rel(y, 1.0 - 0.5 * ref) < tol
+
+
+@pytest.mark.parametrize("sm,osm,tol", [("jacobi", "jacobi", 1e-12), ("gs", "gs_mc", 1e-10)])
+def test_cycle_device_vectors_graph_and_direct(sm, osm, tol):
+    import torch
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((17, 17, 17), "right|top", 20)
+    b = rhs(p, 3)
+    ref = Oracle(H.levels, sm_type=osm).apply(b)
+    dev = _dev(H, sm_type=sm)
+    bd = torch.from_numpy(b).cuda()
+    for graph in (True, True, False):      # capture, replay, direct launches
+        xd = torch.full_like(bd, float("nan"))
+        dev.Mult(bd, xd, graph=graph)
+        torch.cuda.synchronize()
+        assert _rel(xd.cpu().numpy(), ref) < tol
+    # a different right-hand side through the same captured graph object
+    b2 = rhs(p, 4)
+    bd.copy_(torch.from_numpy(b2))
+    dev.Mult(bd, xd)
+    torch.cuda.synchronize()
+    assert _rel(xd.cpu().numpy(), Oracle(H.levels, sm_type=osm).apply(b2)) < tol
+
+
+@pytest.mark.parametrize("sm,osm", [("jacobi", "jacobi"), ("gs", "gs_mc")])
+@pytest.mark.parametrize("steps,symm", [(1, False), (2, False), (1, True), (2, True)])
+def test_smoother_flag_contract(sm, osm, steps, symm):
+    """Smooth / SmoothBack for every (res_updated, update_res, x_zero) combination, incl. ProxySmoother."""
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((33, 33), "left|top", 5)
+    orc = Oracle(H.levels, sm_type=osm, sm_steps=steps, sm_symm=symm)
+    dev = _dev(H, sm_type=sm, sm_steps=steps, sm_symm=symm)
+    rng = np.random.default_rng(5)
+    A = H.levels[0].A.to_scipy()
+    for back in (False, True):
+        for ru in (False, True):
+            for ur in (False, True):
+                for xz in (False, True):
+                    b = rhs(p, 7)
+                    x = np.zeros(p.n) if xz else rng.standard_normal(p.n) * p.free
+                    res = (b - A @ x) if ru else rng.standard_normal(p.n)
+                    xo, ro = x.copy(), res.copy()
+                    orc.smooth(0, xo, b, ro, ru, ur, xz, back)
+                    xg, rg = x.copy(), res.copy()
+                    dev.Smooth(0, xg, b, rg, ru, ur, xz, back)
+                    assert _rel(xg, xo) < 1e-10, (back, ru, ur, xz)
+                    if ur:
+                        assert _rel(rg, ro) < 1e-9, (back, ru, ur, xz)
+
+
+def test_matvec_transfers_coarse_solve():
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((17, 17, 17), "right|top", 20)
+    orc = Oracle(H.levels, sm_type="jacobi")
+    dev = _dev(H, sm_type="jacobi")
+    rng = np.random.default_rng(11)
+    for l in range(H.n_levels):
+        x = rng.standard_normal(dev.sizes[l])
+        y = np.empty_like(x)
+        dev.MatVec(l, x, y)
+        assert _rel(y, orc.matvec(l, x)) < 1e-13
+    for l in range(H.n_levels - 1):
+        xf = rng.standard_normal(dev.sizes[l])
+        xc = np.empty(dev.sizes[l + 1])
+        dev.TransferF2C(l, xf, xc)
+        assert _rel(xc, orc.transfer_f2c(l, xf)) < 1e-13
+        xc = rng.standard_normal(dev.sizes[l + 1])
+        a, b_ = xf.copy(), xf.copy()
+        dev.AddC2F(l, 0.7, a, xc)
+        orc.add_c2f(l, 0.7, b_, xc)
+        assert _rel(a, b_) < 1e-13
+    r = rng.standard_normal(dev.sizes[-1])
+    xs = np.empty_like(r)
+    dev.CoarseSolve(r, xs)
+    assert _rel(xs, orc.coarse_solve(r)) < 1e-10
+
+
+def test_smooth_v_from_level():
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((17, 17, 17), "right|top", 20)
+    for sm, osm in (("jacobi", "jacobi"), ("gs", "gs_mc")):
+        orc = Oracle(H.levels, sm_type=osm)
+        dev = _dev(H, sm_type=sm)
+        for l in range(H.n_levels - 1):
+            n = dev.sizes[l]
+            rng = np.random.default_rng(l)
+            b = rng.standard_normal(n)
+            xo, ro = np.zeros(n), b.copy()
+            orc.smooth_v_from_level(l, xo, b, ro, True, True, True)
+            xg, rg = np.zeros(n), b.copy()
+            dev.SmoothVFromLevel(l, xg, b, rg, True, True, True)
+            assert _rel(xg, xo) < 1e-10
+            assert _rel(rg, ro) < 1e-9
+
+
+def test_pcg_iteration_parity_cfg1():
+    """cfg 1: 2D Poisson 224^2, GS V(1,1), max_coarse_size 5, tol 1e-12 -- iteration count must match the
+    oracle (+-1) and the final relative residual within 10x."""
+    import torch
+    from oracle.pyoracle import Oracle
+    from ngsamg_amd.krylov import CGSolver
+    p, H = poisson_case((224, 224), "left|top", 5)
+    _, it_ref, errs_ref = Oracle(H.levels, sm_type="gs_mc").pcg(p.load, tol=1e-12, maxit=100)
+    _, it_seq, _ = Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-12, maxit=100)
+    dev = _dev(H, sm_type="gs")
+    cg = CGSolver(dev, dev, tol=1e-12, maxsteps=100)
+    cg.Solve(torch.from_numpy(p.load).cuda())
+    assert abs(cg.iterations - it_ref) <= 1
+    assert cg.errors[-1] < 1e-12 * cg.errors[0] * 10
+    assert cg.iterations < 100
+    # multicolour GS (GPU ordering) vs the reference's sequential ordering: within +15 %
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)) + 1
+
+
+def test_create_errors():
+    from ngsamg_amd._lib import NgsAMGError
+    p, H = poisson_case((33, 33), "left|top", 5)
+    with pytest.raises(NgsAMGError):
+        _dev(H, sm_type="nonsense")
+    with pytest.raises(NgsAMGError):
+        _dev(H, mg_cycle="X")
+    dev = _dev(H, sm_type="jacobi")
+    with pytest.raises(NgsAMGError):
+        dev.Mult(np.zeros(3), np.zeros(p.n))
+    b = np.zeros(p.n)
+    with pytest.raises(NgsAMGError):
+        dev.MatVec(99, b, b.copy())
