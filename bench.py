@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- V-cycle applications per second of the MI355X-native NgsAMG apply path.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg 2"): 3D P1 Poisson on the unit cube, 215^3 vertices
+(9 938 375 DOF, ~15 nnz/row), jittered Kuhn tetrahedra (seed 1), Dirichlet on right|top, Jacobi smoother
+(omega 0.9), V(1,1), max_coarse_size 50.  One "step" = one preconditioner application x = C b
+(amgx_apply, i.e. BaseAMGPC::Mult of the reference) with b and x resident in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): round 1 runs one independent cfg-2 problem per
+rank (weak scaling, no halo exchange yet -- the rank-partitioned fine levels of SURVEY.md 8e are not built
+yet; this is stated in the JSON line's config).
+
+Prints ONE JSON line on rank 0 (contract of the driver) with the extra objects "roofline" (dominant kernel:
+level-0 residual SpMV r = b - A x, HIP-event timed) and "cpu_baseline" (the CPU oracle = restatement of the
+reference's cycle, timed on this box's host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nv", type=int, default=215, help="vertices per direction (215 = cfg 2)")
+    ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "gs"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    ge.build_host()
+    ge.build_hip()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the apply path has no CPU fallback")
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    from ngsamg_amd import fem
+    from ngsamg_amd._lib import Matrix
+    from ngsamg_amd.hierarchy import Hierarchy
+    from ngsamg_amd.device import DeviceAMGMatrix, vcycle_bytes, matrix_bytes
+
+    # ---- host setup (cold path, not timed) -------------------------------------------------------------
+    t0 = time.time()
+    nv = args.nv
+    prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
+    A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
+    t1 = time.time()
+    H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
+    t2 = time.time()
+    amg = DeviceAMGMatrix(H, sm_type=args.smoother, omega=0.9, mg_cycle="V", clev="inv", device=device,
+                          use_graph=not args.no_graph)
+    t3 = time.time()
+    if rank == 0:
+        log(f"assembly {t1 - t0:.1f}s, hierarchy {t2 - t1:.1f}s, upload {t3 - t2:.1f}s")
+        log(H.summary().replace("\n", "\n[bench] "))
+    cycle_bytes, per_level = vcycle_bytes(H)
+
+    # ---- timed region: K applications, inputs resident in HBM ------------------------------------------
+    rng = np.random.default_rng(0)
+    b_host = rng.standard_normal(prob.n) * prob.free
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        b = torch.from_numpy(b_host).to(f"cuda:{device}")
+        x = torch.empty_like(b)
+        for _ in range(args.warmup):
+            amg.Mult(b, x)
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            amg.Mult(b, x)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        te = time.perf_counter()
+    elapsed = te - ts
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    x_norm = float(torch.linalg.norm(x).item())
+    applies_per_s = world * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline of the dominant kernel: level-0 residual SpMV r = b - A x ---------------------------
+    # algorithmic bytes per launch: B(A_0) + 3 V_0
+    lv0 = H.levels[0]
+    spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.n * lv0.bs
+    with torch.cuda.stream(stream):
+        amg.Mult(b, x)
+        stream.synchronize()
+    k_ms = amg.time_op(0, 0, reps=50)
+    achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_spmv_l0.json")
+    if os.path.exists(tpath) and nv == 215:
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "sell_spmv_kernel<EP_RES> (level 0: r = b - A x)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(spmv_bytes),
+                "cycle_algorithmic_bytes": int(cycle_bytes),
+                "cycle_achieved_GBs": round(cycle_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                "cycle_frac": round(cycle_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- CPU baseline: the oracle (restatement of the reference's cycle) on this box's cores ----------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        ge.build_oracle()
+        from oracle.pyoracle import Oracle      # measured as the CPU baseline, never part of the product path
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = min(cores, 64)                   # more threads than memory channels only adds OpenMP overhead
+        orc = Oracle(H.levels, sm_type="jacobi" if args.smoother == "jacobi" else "gs", omega=0.9, threads=cores)
+        xo = np.zeros(prob.n)
+        tc0 = time.perf_counter()
+        orc.apply(b_host, xo)                    # warm-up + duration estimate
+        one = time.perf_counter() - tc0
+        reps = int(max(2, min(200, args.cpu_seconds / max(one, 1e-6))))
+        tc0 = time.perf_counter()
+        for _ in range(reps):
+            orc.apply(b_host, xo)
+        cpu_t = (time.perf_counter() - tc0) / reps
+        parity = float(np.linalg.norm(x.cpu().numpy() - xo) / np.linalg.norm(xo))
+        cpu = {"value": round(1.0 / cpu_t, 3), "unit": "applies/s", "cores": cores, "kind": "port",
+               "sample": f"{reps} V-cycle applications of the same {prob.n}-DOF hierarchy (oracle/oracle.c, OpenMP over rows)",
+               "GBs_algorithmic": round(cycle_bytes / cpu_t / 1e9, 1), "gpu_vs_oracle_rel_err": parity}
+        log(f"cpu baseline: {1.0 / cpu_t:.2f} applies/s on {cores} threads; GPU-vs-oracle rel. error {parity:.2e}")
+
+    if rank == 0:
+        out = {
+            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF, Jacobi V(1,1))",
+            "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2: 3D P1 Poisson {nv}^3 = {prob.n} DOF, jittered Kuhn tets (seed 1), "
+                                   f"Dirichlet right|top, {args.smoother} omega=0.9, V(1,1), max_coarse_size=50",
+                       "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
+                       "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent per-rank problems (weak; halo exchange not built yet)"},
+            "x_norm": x_norm,
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

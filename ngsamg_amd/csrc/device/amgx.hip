@@ -864,6 +864,14 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
         default: throw amgx::Err("amgx_time_op: unknown op");
       }
     };
+    if (op != 4) {   // time on non-trivial data (the work vectors are otherwise zero in device-pointer mode)
+      auto fill = [&](double* v, int64_t n, uint64_t seed) {
+        if (n) hipLaunchKernelGGL(amgx::fill_kernel, dim3(amgx::Handle::grid_for(n)), dim3(amgx::BLOCK), 0, h.stream, n, seed, v);
+      };
+      fill(L.x.p, L.len(), 1); fill(L.rhs.p, L.len(), 2); fill(L.res.p, L.len(), 3); fill(L.tmp.p, L.len(), 4);
+      if (has_c) fill(h.lev[level + 1].x.p, h.lev[level + 1].len(), 5);
+      HIPCHK(hipGetLastError());
+    }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));

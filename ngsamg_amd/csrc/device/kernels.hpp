@@ -291,6 +291,17 @@ __global__ __launch_bounds__(BLOCK) void axpy_kernel(int64_t n, double s, const 
   if (i < n) y[i] += s * x[i];
 }
 
+// deterministic pseudo-random fill in [-1, 1) (measurement hook: kernels are timed on non-trivial data)
+__global__ __launch_bounds__(BLOCK) void fill_kernel(int64_t n, uint64_t seed, double* v) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  v[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
 // dense y = M x, one wave per row (coarsest-level inverse, n <= a few hundred)
 __global__ __launch_bounds__(BLOCK) void dense_gemv_kernel(int n, const double* __restrict__ M,
                                                            const double* __restrict__ x, double* y) {

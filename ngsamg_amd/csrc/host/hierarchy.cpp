@@ -114,7 +114,7 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
   }
   Graph C;
   C.n = nn;
-  const int nt = omp_get_max_threads();
+  const int nt = std::min(omp_get_max_threads(), 32);   // each thread owns dense markers of size n_cols: bound the memory
   std::vector<std::vector<int32_t>> tadj(nt);
   std::vector<std::vector<double>> tw(nt);
   std::vector<int64_t> len(nn, 0), tstart(nt + 1);
@@ -259,7 +259,18 @@ BCSR prolongation_weights(const Graph& G0, const std::vector<int32_t>& agg, int6
         for (auto& c : cand) if (c.first == I) { c.second += 1.0 - o.sp_omega; found = true; break; }
         if (!found) cand.push_back({I, 1.0 - o.sp_omega});
       }
-      std::sort(cand.begin(), cand.end(), [](auto& a, auto& b) { return a.second > b.second || (a.second == b.second && a.first < b.first); });
+      // The vertex's own aggregate is always kept ("hierarchic" prolongation): otherwise an aggregate whose
+      // members all prefer their neighbours would end up with an empty column of P, i.e. a zero row in P^T A P.
+      {
+        bool found = false;
+        for (auto& c : cand) if (c.first == I) { found = true; break; }
+        if (!found) cand.push_back({I, 0.0});
+        for (auto& c : cand) if (c.first == I) c.second = std::max(c.second, o.sp_min_frac);
+      }
+      std::sort(cand.begin(), cand.end(), [I](auto& a, auto& b) {
+        if ((a.first == I) != (b.first == I)) return a.first == I;      // own aggregate first
+        return a.second > b.second || (a.second == b.second && a.first < b.first);
+      });
       int keep = 0;
       double s = 0;
       for (auto& c : cand) {
@@ -385,13 +396,17 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     if (lev + 1 >= o.max_levels) break;
     if (lev > 0 && nf <= o.max_coarse_size) break;
     if (lev == 0 && nfree <= o.max_coarse_size && nfree == nf) break;
+    double t0 = omp_get_wtime();
     Graph G = strength_graph(F.A, F.free, dim, o.energy);
     const double target = (lev == 0) ? o.first_aaf : o.aaf;
     std::vector<int32_t> agg;
     int rounds = 0;
+    double t1 = omp_get_wtime();
     int64_t nc = aggregate(G, F.free, target, o, agg, rounds);
+    double t2 = omp_get_wtime();
     if (nc == 0 || nc >= nfree) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
     BCSR W = prolongation_weights(G, agg, nc, o);
+    double t3 = omp_get_wtime();
     const int bs_f = F.A.br;
     const int bs_c = (o.energy == 1) ? dim + nrot : bs_f;
     // coarse coordinates = mean of the aggregate's members
@@ -403,10 +418,15 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       for (int64_t I = 0; I < nc; I++) for (int d = 0; d < dim; d++) xc[I * dim + d] /= std::max(1, cnt[I]);
     }
     F.P = block_prolongation(W, bs_f, bs_c, dim, o.energy, F.coords, xc);
+    double t4 = omp_get_wtime();
     F.PT = transpose(F.P);
     F.agg = agg;
     Level C;
+    double t5 = omp_get_wtime();
     C.A = restrict_matrix(F.PT, F.A, F.P);
+    double t6 = omp_get_wtime();
+    log << "  time: graph " << t1 - t0 << " agg " << t2 - t1 << " weights " << t3 - t2 << " blockP " << t4 - t3
+        << " transpose " << t5 - t4 << " rap " << t6 - t5 << "\n";
     C.free.assign(nc, 1);
     C.coords = std::move(xc);
     log << "  rounds=" << rounds << " nc=" << nc << " P nnz=" << F.P.nnz() << "\n";

@@ -43,7 +43,7 @@ static BCSR matmul_impl(const BCSR& A, const BCSR& B) {
   C.n_rows = A.n_rows; C.n_cols = B.n_cols; C.br = A.br; C.bc = B.bc;
   const int br = A.br, bk = A.bc, bc = B.bc, cbs = br * bc;
   const int64_t n = A.n_rows;
-  const int nt = omp_get_max_threads();
+  const int nt = std::min(omp_get_max_threads(), 32);   // each thread owns dense markers of size n_cols: bound the memory
   std::vector<std::vector<int32_t>> tcol(nt);
   std::vector<std::vector<double>> tval(nt);
   std::vector<int64_t> rowlen(n, 0);
