@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ops", action="store_true", help="print HIP-event timings of the individual kernels per level")
     args = ap.parse_args()
 
     import torch
@@ -141,6 +142,21 @@ def main():
                 "cycle_algorithmic_bytes": int(cycle_bytes),
                 "cycle_achieved_GBs": round(cycle_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 "cycle_frac": round(cycle_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    if args.ops and rank == 0:
+        names = {0: "residual r=b-Ax", 1: "jacobi fused", 2: "restrict PT r", 3: "prolong x+P xc"}
+        for l in range(H.n_levels):
+            for op in range(4):
+                if op >= 2 and l + 1 >= H.n_levels:
+                    continue
+                if l + 1 >= H.n_levels and op == 1:
+                    continue
+                ms = amg.time_op(l, op, reps=50)
+                M = H.levels[l].A if op < 2 else (H.levels[l].PT if op == 2 else H.levels[l].P)
+                by = matrix_bytes(M) + 8 * H.levels[l].n * H.levels[l].bs * (3 if op == 0 else 4 if op == 1 else 1 if op == 2 else 2)
+                info = amg.matrix_info(l, "A" if op < 2 else ("PT" if op == 2 else "P"))
+                log(f"level {l} {names[op]:18s} {ms * 1e3:9.1f} us  {by / ms / 1e6:8.1f} GB/s  fmt={info['fmt']} lanes={info['lanes']}")
+        log(f"whole cycle (graph) {amg.time_op(0, 4, reps=50) * 1e3:.1f} us")
 
     # ---- CPU baseline: the oracle (restatement of the reference's cycle) on this box's cores ----------
     cpu = None

@@ -151,9 +151,11 @@ class Matrix:
 
     def to_scipy(self):
         import scipy.sparse as sp
+        # copies: the arrays may be zero-copy views into the native hierarchy and must not be edited through scipy
         if self.br == 1 and self.bc == 1:
-            return sp.csr_matrix((self.val, self.col, self.rowptr), shape=self.shape)
-        return sp.bsr_matrix((self.val.reshape(-1, self.br, self.bc), self.col, self.rowptr), shape=self.shape).tocsr()
+            return sp.csr_matrix((self.val.copy(), self.col.copy(), self.rowptr.copy()), shape=self.shape)
+        return sp.bsr_matrix((self.val.reshape(-1, self.br, self.bc).copy(), self.col.copy(), self.rowptr.copy()),
+                             shape=self.shape).tocsr()
 
     @classmethod
     def from_scipy(cls, A, bs=1):

@@ -10,6 +10,7 @@
 #include "../../../include/amgx.h"
 #include "kernels.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -101,10 +102,19 @@ struct DevLevel {
 // host-side format construction
 // ---------------------------------------------------------------------------------------------------
 
+// lanes per row of the CSR-vector kernels: the widest group that still keeps >= 80 % of its lanes busy
+// (a row of length L costs ceil(L/G) steps of G lanes), else the most efficient one
 static int pick_lanes(double avg_len) {
-  int g = 2;
-  while (g < 64 && g < avg_len * 0.75) g <<= 1;
-  return g;
+  if (avg_len <= 2.0) return 2;
+  int best = 2;
+  double best_eff = 0.0;
+  for (int g = 64; g >= 2; g >>= 1) {
+    const double steps = std::ceil(avg_len / g);
+    const double eff = avg_len / (steps * g);
+    if (eff >= 0.8) return g;
+    if (eff > best_eff) { best_eff = eff; best = g; }
+  }
+  return best;
 }
 
 // SELL-64-pair image of the rows `rows[0..m)` of a scalar CSR matrix (row id < 0 => empty padding row).
@@ -175,7 +185,10 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
       for (int64_t r = s * WAVE; r < std::min<int64_t>(A.n_rows, (s + 1) * WAVE); ++r) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
       stored += (int64_t)w * WAVE;
     }
-    sell = (double)stored <= 1.25 * (double)D.nnz;
+    // one thread per row only pays when there are enough rows to fill the chip with waves, or the rows are
+    // so short that lane groups would idle; long rows of small matrices go to the CSR-vector kernels
+    const bool enough_rows = D.n_rows >= (int64_t)1 << 20 || avg <= 6.0;
+    sell = enough_rows && (double)stored <= 1.25 * (double)D.nnz;
   }
   if (sell) {
     std::vector<int64_t> sp; std::vector<int32_t> sc; std::vector<double> sv;

@@ -20,10 +20,10 @@ def poisson_case(shape, dirichlet="right|top", max_coarse_size=20):
 
 
 @functools.lru_cache(maxsize=None)
-def elasticity_case(shape, rotations=False, max_coarse_size=20):
+def elasticity_case(shape, rotations=False, max_coarse_size=20, first_aaf=None):
     p = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.5, rotations=rotations)
     H = Hierarchy(to_matrix(p), p.free, p.coords, dim=len(shape), energy=1, max_coarse_size=max_coarse_size,
-                  regularize_cmats=0 if rotations else 1)
+                  regularize_cmats=0 if rotations else 1, first_aaf=first_aaf)
     return p, H
 
 

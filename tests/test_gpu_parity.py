@@ -164,3 +164,86 @@ def test_create_errors():
     b = np.zeros(p.n)
     with pytest.raises(NgsAMGError):
         dev.MatVec(99, b, b.copy())
+
+
+# ---------------------------------------------------------------------------------------------
+# golden fixtures (committed data) and block (elasticity) hierarchies
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["poisson2d_9", "poisson2d_17", "poisson3d_5", "poisson3d_9", "elast3d_4_bs3", "elast3d_4_bs6"])
+@pytest.mark.parametrize("sm,osm,tol", [("jacobi", "jacobi", 1e-12), ("gs", "gs_mc", 1e-10)])
+def test_gpu_matches_golden_fixture(name, sm, osm, tol):
+    from tests import golden_io
+    z, levels = golden_io.load(name)
+    H = golden_io.FixtureHierarchy(levels)
+    b = z["b"]
+    for cyc in ("V", "W", "BS"):
+        dev = _dev(H, sm_type=sm, mg_cycle=cyc)
+        x = np.empty_like(b)
+        dev.Mult(b, x)
+        # the fixture's coarse solve is the oracle's Cholesky, the GPU multiplies with the explicit inverse
+        assert _rel(x, z[f"{osm}_{cyc}"]) < max(tol, 1e-11), cyc
+    dev = _dev(H, sm_type=sm, sm_steps=2, sm_symm=True)
+    x = np.empty_like(b)
+    dev.Mult(b, x)
+    assert _rel(x, z[f"{osm}_V_symm2"]) < max(tol, 1e-11)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("sm,osm,tol", [("jacobi", "jacobi", 1e-12), ("gs", "gs_mc", 1e-10)])
+def test_elasticity_cycle_matches_oracle(rot, sm, osm, tol):
+    """cfg 3 / cfg 5 shapes at test size: BCSR(3) fine level with 3x6 prolongation blocks and BCSR(6) coarse
+    levels (displacement formulation, pseudo-inverse diagonals), resp. BCSR(6) on every level."""
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    p, H = elasticity_case((13, 11, 9), rot, 5, 0.12)
+    assert H.n_levels >= 3
+    b = rhs(p, 1)
+    for cyc in ("V", "W"):
+        ref = Oracle(H.levels, sm_type=osm, cycle=cyc).apply(b)
+        dev = _dev(H, sm_type=sm, mg_cycle=cyc)
+        x = np.empty_like(b)
+        dev.Mult(b, x)
+        assert _rel(x, ref) < max(tol, 1e-11)
+    # stage checks on every level: matvec, transfers, smoother flags
+    orc = Oracle(H.levels, sm_type=osm)
+    dev = _dev(H, sm_type=sm)
+    rng = np.random.default_rng(3)
+    for l in range(H.n_levels):
+        v = rng.standard_normal(dev.sizes[l])
+        y = np.empty_like(v)
+        dev.MatVec(l, v, y)
+        assert _rel(y, orc.matvec(l, v)) < 1e-13
+    for l in range(H.n_levels - 1):
+        xf = rng.standard_normal(dev.sizes[l])
+        xc = np.empty(dev.sizes[l + 1])
+        dev.TransferF2C(l, xf, xc)
+        assert _rel(xc, orc.transfer_f2c(l, xf)) < 1e-13
+        xc = rng.standard_normal(dev.sizes[l + 1])
+        a, c = xf.copy(), xf.copy()
+        dev.AddC2F(l, 1.0, a, xc)
+        orc.add_c2f(l, 1.0, c, xc)
+        assert _rel(a, c) < 1e-13
+        n = dev.sizes[l]
+        bb = rng.standard_normal(n)
+        for back in (False, True):
+            x0 = rng.standard_normal(n)
+            xo, ro = x0.copy(), np.zeros(n)
+            orc.smooth(l, xo, bb, ro, False, True, False, back)
+            xg, rg = x0.copy(), np.zeros(n)
+            dev.Smooth(l, xg, bb, rg, False, True, False, back)
+            assert _rel(xg, xo) < 1e-10 and _rel(rg, ro) < 1e-9
+
+
+def test_pcg_elasticity_iteration_parity():
+    import torch
+    from oracle.pyoracle import Oracle
+    from ngsamg_amd.krylov import CGSolver
+    from tests.problems import elasticity_case
+    p, H = elasticity_case((13, 9, 9), False, 10)
+    _, it_ref, errs = Oracle(H.levels, sm_type="gs_mc").pcg(p.load, tol=1e-6, maxit=100)
+    dev = _dev(H, sm_type="gs")
+    cg = CGSolver(dev, dev, tol=1e-6, maxsteps=100)
+    cg.Solve(torch.from_numpy(p.load).cuda())
+    assert abs(cg.iterations - it_ref) <= 1
+    assert cg.errors[-1] < 1e-6 * cg.errors[0] * 10 and cg.iterations < 60
