@@ -115,6 +115,10 @@ int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* 
  * stored_entries counts padding (for the traffic model in DESIGN.md) */
 int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);
 
+/* bytes of matrix data (values, indices, pointers, in the device encoding) that one SpMV with this matrix
+ * streams from HBM -- the model value behind "traffic" in DESIGN.md */
+int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes);
+
 /* measurement hook for bench.py: launches one hot-path kernel `reps` times on the handle's stream,
  * bracketed by HIP events, and returns the average duration in milliseconds.
  *   op = 0: residual SpMV  r = b - A_level x      (the dominant kernel of the Jacobi V-cycle)

@@ -197,7 +197,8 @@ AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
 AMGX_SYMBOLS = [
     "amgx_last_error", "amgx_create", "amgx_destroy", "amgx_set_stream", "amgx_synchronize", "amgx_apply",
     "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_matvec", "amgx_transfer_f2c",
-    "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info", "amgx_time_op",
+    "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
+    "amgx_matrix_stream_bytes", "amgx_time_op",
 ]
 
 AMGH_SYMBOLS = [
@@ -232,6 +233,7 @@ def hip():
     lib.amgx_n_levels.argtypes = [vp]
     lib.amgx_level_info.argtypes = [vp, C.c_int, c_i64p, c_i32p, c_i64p]
     lib.amgx_matrix_info.argtypes = [vp, C.c_int, C.c_int, c_i32p, c_i64p, c_i32p]
+    lib.amgx_matrix_stream_bytes.argtypes = [vp, C.c_int, C.c_int, c_i64p]
     lib.amgx_time_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
     _hip = lib
     return lib

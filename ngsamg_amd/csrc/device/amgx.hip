@@ -11,6 +11,8 @@
 #include "kernels.hpp"
 #include <algorithm>
 #include <cmath>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -67,9 +69,15 @@ struct DevMatrix {
   // SELL-64-pair
   int n_slices = 0;
   int64_t stored = 0;                  // stored entries incl. padding
-  DevBuf<int64_t> slice_ptr;
-  DevBuf<int32_t> scol;
-  DevBuf<double> sval;
+  int64_t stream_bytes = 0;            // bytes of matrix data one SpMV reads from HBM (values + indices + pointers)
+  struct Sell {
+    DevBuf<int64_t> slice_ptr;
+    DevBuf<int32_t> col32, cbase;
+    DevBuf<uint16_t> col16;
+    DevBuf<double> val;
+    int rowrel = 0;
+    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel}; }
+  } sell;
   bool empty() const { return n_rows == 0; }
 };
 
@@ -77,9 +85,8 @@ struct DevGS {                          // colour-major data for multicolour Gau
   int n_colors = 0;
   // scalar: SELL copy of A in colour-major row order
   std::vector<int> color_slice_ptr;     // [n_colors+1] slice ranges
-  DevBuf<int64_t> slice_ptr;
-  DevBuf<int32_t> scol, rowid;
-  DevBuf<double> sval;
+  DevMatrix::Sell sell;
+  DevBuf<int32_t> rowid;
   // block: colour-major row list over the CSR of A
   std::vector<int> color_row_ptr;       // [n_colors+1]
   DevBuf<int32_t> rowlist;
@@ -120,10 +127,21 @@ static int pick_lanes(double avg_len) {
 // SELL-64-pair image of the rows `rows[0..m)` of a scalar CSR matrix (row id < 0 => empty padding row).
 // Element (lane, j) of a slice of width w sits at  base + (j/2)*128 + lane*2 + (j&1)  for j < 2*(w/2)
 // and at  base + (w-1)*64 + lane  for the odd trailing column.  Padding: value 0, column = a valid index.
-static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, std::vector<int64_t>& slice_ptr,
-                       std::vector<int32_t>& scol, std::vector<double>& sval) {
+// Column indices are stored as 32-bit values and, for every slice where it is possible, additionally as
+// 16-bit deltas  col = (rowrel ? row : 0) + cbase[column] + d  (see kernels.hpp, SellMat).
+struct HostSell {
+  std::vector<int64_t> slice_ptr;
+  std::vector<int32_t> col32, cbase;
+  std::vector<uint16_t> col16;
+  std::vector<double> val;
+  int64_t n_comp_slices = 0, stream_bytes = 0;
+  int rowrel = 0;
+};
+
+static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, HostSell& S) {
   const int64_t ns = (m + WAVE - 1) / WAVE;
-  slice_ptr.assign(ns + 1, 0);
+  S.rowrel = rowrel ? 1 : 0;
+  S.slice_ptr.assign(ns + 1, 0);
   for (int64_t s = 0; s < ns; ++s) {
     int w = 0;
     for (int l = 0; l < WAVE; ++l) {
@@ -133,28 +151,81 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, std
       if (r < 0) continue;
       w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
     }
-    slice_ptr[s + 1] = slice_ptr[s] + (int64_t)w * WAVE;
+    S.slice_ptr[s + 1] = S.slice_ptr[s] + (int64_t)w * WAVE;
   }
-  scol.assign(slice_ptr[ns], 0);
-  sval.assign(slice_ptr[ns], 0.0);
+  const int64_t stored = S.slice_ptr[ns];
+  S.col32.assign(stored, 0);
+  S.col16.assign(stored, 0);
+  S.cbase.assign(stored / WAVE, 0);
+  S.val.assign(stored, 0.0);
+  S.n_comp_slices = 0;
+  S.stream_bytes = 8 * (ns + 1);
+  std::vector<int64_t> t(WAVE);
   for (int64_t s = 0; s < ns; ++s) {
-    const int64_t base = slice_ptr[s];
-    const int w = (int)((slice_ptr[s + 1] - base) / WAVE);
+    const int64_t base = S.slice_ptr[s];
+    const int w = (int)((S.slice_ptr[s + 1] - base) / WAVE);
     const int wp = w & ~1;
-    for (int l = 0; l < WAVE; ++l) {
-      const int64_t q = s * WAVE + l;
-      int64_t r = -1;
-      if (q < m) r = rows ? rows[q] : q;
-      const int64_t rb = r >= 0 ? A.rowptr[r] : 0;
-      const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rb) : 0;
-      const int32_t padcol = r >= 0 ? (len ? A.col[rb] : 0) : 0;
-      for (int j = 0; j < w; ++j) {
-        const int64_t o = (j < wp) ? base + (int64_t)(j >> 1) * (2 * WAVE) + l * 2 + (j & 1) : base + (int64_t)(w - 1) * WAVE + l;
-        if (j < len) { scol[o] = A.col[rb + j]; sval[o] = A.val[rb + j]; }
-        else { scol[o] = padcol; sval[o] = 0.0; }
+    auto off = [&](int l, int j) { return (j < wp) ? base + (int64_t)(j >> 1) * (2 * WAVE) + l * 2 + (j & 1) : base + (int64_t)(w - 1) * WAVE + l; };
+    bool comp = true;
+    for (int j = 0; j < w; ++j) {
+      // pass 1: real entries -> 32-bit columns, column base for the 16-bit form
+      int64_t cb = INT64_MAX;
+      for (int l = 0; l < WAVE; ++l) {
+        const int64_t q = s * WAVE + l;
+        const int64_t r = (q < m) ? (rows ? rows[q] : q) : -1;
+        if (r < 0) continue;
+        const int64_t rb = A.rowptr[r];
+        const int len = (int)(A.rowptr[r + 1] - rb);
+        if (j < len) {
+          const int64_t o = off(l, j);
+          S.col32[o] = A.col[rb + j];
+          S.val[o] = A.val[rb + j];
+          cb = std::min<int64_t>(cb, (int64_t)A.col[rb + j] - (rowrel ? r : 0));
+        }
+      }
+      if (cb == INT64_MAX) cb = 0;
+      if (cb < INT32_MIN / 2 || cb > INT32_MAX / 2) comp = false;
+      S.cbase[base / WAVE + j] = (int32_t)cb;
+      // pass 2: deltas and padding
+      for (int l = 0; l < WAVE; ++l) {
+        const int64_t q = s * WAVE + l;
+        const int64_t r = (q < m) ? (rows ? rows[q] : q) : -1;
+        const int64_t o = off(l, j);
+        const int64_t rb = r >= 0 ? A.rowptr[r] : 0;
+        const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rb) : 0;
+        // the row id the kernel will use for this lane: plain SELL = position, colour-major = rowid (lanes with r < 0 exit early)
+        const int64_t rk = rows ? r : q;
+        const int64_t rr = rowrel ? rk : 0;
+        if (j < len) {
+          const int64_t d = (int64_t)A.col[rb + j] - rr - cb;
+          if (d < 0 || d > 65535) comp = false; else S.col16[o] = (uint16_t)d;
+        } else {
+          // padding (value 0): any valid column; prefer one reachable in both encodings
+          const int32_t padcol = (r >= 0 && len) ? A.col[rb] : 0;
+          S.col32[o] = padcol;
+          S.val[o] = 0.0;
+          if (rows && r < 0) { S.col16[o] = 0; continue; }      // lane never executes
+          int64_t d = (int64_t)padcol - rr - cb;
+          if (d < 0 || d > 65535) {
+            d = std::max<int64_t>(0, -(rr + cb));                 // smallest delta that gives a column >= 0
+            if (d > 65535 || rr + cb + d >= A.n_cols) comp = false;
+          }
+          if (comp) S.col16[o] = (uint16_t)d;
+        }
       }
     }
+    if (comp && w > 0) { S.slice_ptr[s] |= 1; S.n_comp_slices++; S.stream_bytes += (int64_t)w * WAVE * 10 + 4 * w; }
+    else S.stream_bytes += (int64_t)w * WAVE * 12;
   }
+}
+
+static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
+  const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
+  D.rowrel = S.rowrel;
+  D.slice_ptr.upload(S.slice_ptr);
+  D.val.upload(S.val);
+  if (S.n_comp_slices < ns) D.col32.upload(S.col32);               // only read by 32-bit slices
+  if (S.n_comp_slices > 0) { D.col16.upload(S.col16); D.cbase.upload(S.cbase); }
 }
 
 static void check_matrix(const amgx_matrix& A, const char* what) {
@@ -191,15 +262,17 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
     sell = enough_rows && (double)stored <= 1.25 * (double)D.nnz;
   }
   if (sell) {
-    std::vector<int64_t> sp; std::vector<int32_t> sc; std::vector<double> sv;
-    build_sell(A, nullptr, A.n_rows, sp, sc, sv);
+    HostSell S;
+    build_sell(A, nullptr, A.n_rows, A.n_rows == A.n_cols, S);
     D.fmt = FMT_SELL;
-    D.n_slices = (int)(sp.size() - 1);
-    D.stored = sp.back();
-    D.slice_ptr.upload(sp); D.scol.upload(sc); D.sval.upload(sv);
+    D.n_slices = (int)(S.slice_ptr.size() - 1);
+    D.stored = S.slice_ptr.back() & ~(int64_t)63;
+    D.stream_bytes = S.stream_bytes;
+    upload_sell(S, D.sell);
   } else {
     D.fmt = FMT_CSRVEC;
     D.stored = D.nnz;
+    D.stream_bytes = D.nnz * (8 * (int64_t)A.br * A.bc + 4) + 4 * (A.n_rows + 1);
     std::vector<int32_t> rp(A.n_rows + 1);
     for (int64_t i = 0; i <= A.n_rows; ++i) rp[i] = (int32_t)A.rowptr[i];
     D.rowptr.upload(rp);
@@ -241,7 +314,7 @@ struct Handle {
     if (M.n_rows == 0) return;
     if (M.fmt == FMT_SELL) {
       const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-      hipLaunchKernelGGL((sell_spmv_kernel<EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.slice_ptr.p, M.scol.p, M.sval.p, x, y, ep);
+      hipLaunchKernelGGL((sell_spmv_kernel<EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.sell.view(), x, y, ep);
     } else if (M.br == 1 && M.bc == 1) {
       const int grid = grid_for(M.n_rows * M.lanes);
 #define LAUNCH_CSR(G) hipLaunchKernelGGL((csrvec_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
@@ -331,7 +404,7 @@ struct Handle {
         const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
         if (s1 == s0) continue;
         const int grid = (s1 - s0 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        hipLaunchKernelGGL(gs_color_kernel, dim3(grid), dim3(BLOCK), 0, stream, s0, s1, g.slice_ptr.p, g.scol.p, g.sval.p, g.rowid.p, L.dinv.p, b, x);
+        hipLaunchKernelGGL(gs_color_kernel, dim3(grid), dim3(BLOCK), 0, stream, s0, s1, g.sell.view(), g.rowid.p, L.dinv.p, b, x);
       } else {
         const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
         if (r1 == r0) continue;
@@ -575,9 +648,10 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
     g.color_slice_ptr.resize(nc + 1);
     for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / WAVE);
-    std::vector<int64_t> sp; std::vector<int32_t> sc; std::vector<double> sv;
-    build_sell(d.A, rows.data(), (int64_t)rows.size(), sp, sc, sv);
-    g.slice_ptr.upload(sp); g.scol.upload(sc); g.sval.upload(sv); g.rowid.upload(rows);
+    HostSell S;
+    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, S);
+    upload_sell(S, g.sell);
+    g.rowid.upload(rows);
   } else {
     g.color_row_ptr.assign(nc + 1, 0);
     for (int c = 0; c < nc; ++c) g.color_row_ptr[c + 1] = g.color_row_ptr[c] + (int)cnt[c + 1];
@@ -856,6 +930,14 @@ int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t
     if (fmt) *fmt = M.fmt;
     if (stored) *stored = M.stored;
     if (lanes) *lanes = M.lanes;
+  });
+}
+
+int amgx_matrix_stream_bytes(amgx_handle hh, int level, int which, int64_t* bytes) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels() || !bytes) throw amgx::Err("amgx_matrix_stream_bytes: bad arguments");
+    const amgx::DevMatrix& M = which == 0 ? h.lev[level].A : (which == 1 ? h.lev[level].P : h.lev[level].PT);
+    *bytes = M.stream_bytes;
   });
 }
 

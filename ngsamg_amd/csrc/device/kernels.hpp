@@ -14,10 +14,13 @@
 //       long rows (P^T, coarse level matrices) and for all block (3x3, 6x6, 3x6, 6x3) matrices.
 //   colour-major SELL copy of A for multicolour Gauss-Seidel (slices never cross a colour).
 //
-// The blockIdx -> row-block mapping is XCD-aware: hardware deals workgroups round-robin over the 8 XCDs
-// (MI355X_MICROARCH.md "Workgroup dispatch"), so logical block = f(blockIdx) is chosen such that each XCD
-// walks one contiguous eighth of the rows and the x-gathers of neighbouring rows hit that XCD's own L2.
-// This is a speed-only assumption; any placement gives the same result.
+// blockIdx -> row-block mapping: measured on MI355X (profiles/r01/spmv_lab_round*.log), an XCD-aware remap
+// (each XCD walking one contiguous eighth of the rows) is 5-6 % SLOWER than the natural round-robin order
+// for these streaming kernels: the x-gathers are served by the Infinity Cache either way, and eight distant
+// HBM streams are worse than one front advancing through the matrix.  The remap helper is kept (it is a
+// speed-only choice, any placement gives the same result) but the kernels use the natural order.
+// The matrix streams (values, column indices) are read exactly once per launch and are loaded
+// non-temporally so that they do not evict the vectors from L2 / Infinity Cache (+6...13 % measured).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,36 +62,78 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SELL-64-pair view.  Column indices come in two encodings, chosen per slice at build time:
+//   32-bit:  col32[o]                                         (bit 0 of slice_ptr[s] clear)
+//   16-bit:  col = (rowrel ? row : 0) + cbase[column] + col16[o]   (bit 0 set)
+// where `column` = (base >> 6) + j numbers the 64-entry columns of all slices.  On FEM matrices the offset
+// col - row is (nearly) the same for all 64 rows of a slice column, so the 16-bit form almost always applies
+// and the index stream shrinks from 4 to ~2 bytes per entry (-13 % kernel time measured).
+struct SellMat {
+  const int64_t* slice_ptr;   // [n_slices+1] element offset (multiple of 64) | encoding flag in bit 0
+  const int32_t* col32;
+  const uint16_t* col16;
+  const int32_t* cbase;
+  const double* val;
+  int rowrel;
+};
+
+template <class T>
+__device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
+
+// dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
+__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x) {
+  const int64_t sp0 = M.slice_ptr[s];
+  const int64_t base = sp0 & ~(int64_t)63;
+  const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
+  const int np = w >> 1;
+  const double* __restrict__ vb = M.val + base;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (sp0 & 1) {
+    const uint32_t* __restrict__ cp = reinterpret_cast<const uint32_t*>(M.col16 + base);
+    const int32_t* __restrict__ cb = M.cbase + (base >> 6);
+    const int r0 = M.rowrel ? row : 0;
+#pragma unroll 4
+    for (int p = 0; p < np; ++p) {
+      const double v0 = ld_nt(vb + (p * WAVE + lane) * 2), v1 = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
+      const uint32_t c = ld_nt(cp + p * WAVE + lane);
+      const int c0 = r0 + cb[2 * p] + (int)(c & 0xffffu);
+      const int c1 = r0 + cb[2 * p + 1] + (int)(c >> 16);
+      acc0 += v0 * x[c0];
+      acc1 += v1 * x[c1];
+    }
+    if (w & 1) {
+      const int64_t o = (int64_t)(w - 1) * WAVE + lane;
+      const int c0 = r0 + cb[w - 1] + (int)ld_nt(M.col16 + base + o);
+      acc0 += ld_nt(vb + o) * x[c0];
+    }
+  } else {
+    const int32_t* __restrict__ cp = M.col32 + base;
+#pragma unroll 4
+    for (int p = 0; p < np; ++p) {
+      const double v0 = ld_nt(vb + (p * WAVE + lane) * 2), v1 = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
+      const int c0 = ld_nt(cp + (p * WAVE + lane) * 2), c1 = ld_nt(cp + (p * WAVE + lane) * 2 + 1);
+      acc0 += v0 * x[c0];
+      acc1 += v1 * x[c1];
+    }
+    if (w & 1) {
+      const int64_t o = (int64_t)(w - 1) * WAVE + lane;
+      acc0 += ld_nt(vb + o) * x[ld_nt(cp + o)];
+    }
+  }
+  return acc0 + acc1;
+}
+
 // SELL-64-pair, scalar, one thread per row, one wave per slice
 template <int EP>
-__global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_slices,
-                                                          const int64_t* __restrict__ slice_ptr,
-                                                          const int32_t* __restrict__ cols,
-                                                          const double* __restrict__ vals,
+__global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_slices, SellMat M,
                                                           const double* __restrict__ x, double* y, EpArgs ep) {
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & (WAVE - 1);
-  const int s = lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  // the slice index is wave-uniform: tell the compiler, so slice pointers and column bases use scalar loads
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
-  const int64_t base = slice_ptr[s];
-  const int w = (int)((slice_ptr[s + 1] - base) >> 6);
-  const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base);
-  const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base);
-  const int np = w >> 1;
-  double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 4
-  for (int p = 0; p < np; ++p) {
-    const double2 v = v2[p * WAVE + lane];
-    const int2 c = c2[p * WAVE + lane];
-    acc0 += v.x * x[c.x];
-    acc1 += v.y * x[c.y];
-  }
-  if (w & 1) {
-    const int64_t o = base + (int64_t)(w - 1) * WAVE + lane;
-    acc0 += vals[o] * x[cols[o]];
-  }
-  const int64_t row = (int64_t)s * WAVE + lane;
-  if (row < n_rows) store_scalar<EP>(row, acc0 + acc1, y, ep);
+  const int row = s * WAVE + lane;
+  const double acc = sell_row_dot(M, s, lane, row, x);
+  if (row < n_rows) store_scalar<EP>(row, acc, y, ep);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -98,13 +143,14 @@ __global__ __launch_bounds__(BLOCK) void csrvec_spmv_kernel(int64_t n_rows, cons
                                                             const int32_t* __restrict__ cols,
                                                             const double* __restrict__ vals,
                                                             const double* __restrict__ x, double* y, EpArgs ep) {
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t t = (int64_t)lb * BLOCK + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t row = t / G;
   const int sub = (int)(t % G);
   double acc = 0.0;
   if (row < n_rows) {
     const int e = rowptr[row + 1];
+    // plain (cached) loads on purpose: a 128-B line of a row is touched in two consecutive steps of the lane
+    // group, so the non-temporal policy of the SELL kernels doubles the HBM traffic here (measured: 2x slower)
     for (int k = rowptr[row] + sub; k < e; k += G) acc += vals[k] * x[cols[k]];
   }
 #pragma unroll
@@ -119,8 +165,7 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
                                                              const int32_t* __restrict__ cols,
                                                              const double* __restrict__ vals,
                                                              const double* __restrict__ x, double* y, EpArgs ep) {
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t t = (int64_t)lb * BLOCK + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t row = t / G;
   const int sub = (int)(t % G);
   double acc[BR];
@@ -176,37 +221,17 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
 // multicolour Gauss-Seidel, scalar: one colour per launch, colour-major SELL copy of A.
 //   x_k += dinv_k * (b_k - A_k: x)        (RHS form, reference gssmoother.cpp:209-212)
 // Rows of one colour have no mutual couplings, so the in-place update is race-free.
-__global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int slice_end,
-                                                         const int64_t* __restrict__ slice_ptr,
-                                                         const int32_t* __restrict__ cols,
-                                                         const double* __restrict__ vals,
+__global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int slice_end, SellMat M,
                                                          const int32_t* __restrict__ rowid,
                                                          const double* __restrict__ dinv,
                                                          const double* __restrict__ b, double* x) {
-  const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & (WAVE - 1);
-  const int s = slice_begin + lb * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int s = __builtin_amdgcn_readfirstlane(slice_begin + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= slice_end) return;
   const int row = rowid[(int64_t)s * WAVE + lane];
   if (row < 0) return;
-  const int64_t base = slice_ptr[s];
-  const int w = (int)((slice_ptr[s + 1] - base) >> 6);
-  const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vals + base);
-  const int2* __restrict__ c2 = reinterpret_cast<const int2*>(cols + base);
-  const int np = w >> 1;
-  double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 4
-  for (int p = 0; p < np; ++p) {
-    const double2 v = v2[p * WAVE + lane];
-    const int2 c = c2[p * WAVE + lane];
-    acc0 += v.x * x[c.x];
-    acc1 += v.y * x[c.y];
-  }
-  if (w & 1) {
-    const int64_t o = base + (int64_t)(w - 1) * WAVE + lane;
-    acc0 += vals[o] * x[cols[o]];
-  }
-  x[row] += dinv[row] * (b[row] - (acc0 + acc1));
+  const double acc = sell_row_dot(M, s, lane, row, x);
+  x[row] += dinv[row] * (b[row] - acc);
 }
 
 // multicolour Gauss-Seidel, block BS x BS: CSR rows through a colour-major row list, G lanes per row

@@ -204,7 +204,10 @@ class DeviceAMGMatrix:
         fmt, stored, lanes = C.c_int32(), C.c_int64(), C.c_int32()
         self._ck(self._lib.amgx_matrix_info(self._h, level, {"A": 0, "P": 1, "PT": 2}[which], C.byref(fmt),
                                             C.byref(stored), C.byref(lanes)))
-        return {"fmt": "sell" if fmt.value == 1 else "csrvec", "stored": stored.value, "lanes": lanes.value}
+        nb = C.c_int64()
+        self._ck(self._lib.amgx_matrix_stream_bytes(self._h, level, {"A": 0, "P": 1, "PT": 2}[which], C.byref(nb)))
+        return {"fmt": "sell" if fmt.value == 1 else "csrvec", "stored": stored.value, "lanes": lanes.value,
+                "stream_bytes": nb.value}
 
     def time_op(self, level, op, reps=20):
         ms = C.c_double()
