@@ -94,6 +94,7 @@ struct DevGS {                          // colour-major data for multicolour Gau
 
 struct DevLevel {
   DevMatrix A, P, PT;
+  DevMatrix Apre;                       // scalar Jacobi levels: A * diag(omega * dinv), see EP_PRE in kernels.hpp
   DevBuf<double> dinv;
   DevGS gs;
   int sm_type = AMGX_SM_JACOBI;
@@ -138,19 +139,36 @@ struct HostSell {
   int rowrel = 0;
 };
 
-static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, HostSell& S) {
-  const int64_t ns = (m + WAVE - 1) / WAVE;
+// G = lanes per row (1, 2, 4, 8, 16).  G == 1: one thread per row, slices of 64 rows, odd widths allowed.
+// G > 1 ("SELL-G"): slices of 64/G rows; entry e of a row belongs to lane g = (e/2) % G of the row's lane
+// group at step p = (e/2) / G, so every step of a wave still reads one contiguous 1 KiB + 512 B (or 256 B) line
+// set; the G partial sums are combined by a wave shuffle reduction in the kernel.
+static int64_t sell_stored(const amgx_matrix& A, int G) {
+  const int R = WAVE / G;
+  int64_t stored = 0;
+  for (int64_t r0 = 0; r0 < A.n_rows; r0 += R) {
+    int mx = 0;
+    for (int64_t r = r0; r < std::min<int64_t>(A.n_rows, r0 + R); ++r) mx = std::max<int>(mx, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+    const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
+    stored += (int64_t)w * WAVE;
+  }
+  return stored;
+}
+
+static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, int G, HostSell& S) {
+  const int R = WAVE / G;
+  const int64_t ns = (m + R - 1) / R;
   S.rowrel = rowrel ? 1 : 0;
   S.slice_ptr.assign(ns + 1, 0);
+  auto row_of = [&](int64_t q) -> int64_t { return (q < m) ? (rows ? rows[q] : q) : -1; };
   for (int64_t s = 0; s < ns; ++s) {
-    int w = 0;
-    for (int l = 0; l < WAVE; ++l) {
-      const int64_t q = s * WAVE + l;
-      if (q >= m) break;
-      const int64_t r = rows ? rows[q] : q;
-      if (r < 0) continue;
-      w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+    int mx = 0;
+    for (int r = 0; r < R; ++r) {
+      const int64_t rr = row_of(s * R + r);
+      if (rr < 0) continue;
+      mx = std::max<int>(mx, (int)(A.rowptr[rr + 1] - A.rowptr[rr]));
     }
+    const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
     S.slice_ptr[s + 1] = S.slice_ptr[s] + (int64_t)w * WAVE;
   }
   const int64_t stored = S.slice_ptr[ns];
@@ -160,27 +178,28 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
   S.val.assign(stored, 0.0);
   S.n_comp_slices = 0;
   S.stream_bytes = 8 * (ns + 1);
-  std::vector<int64_t> t(WAVE);
   for (int64_t s = 0; s < ns; ++s) {
     const int64_t base = S.slice_ptr[s];
     const int w = (int)((S.slice_ptr[s + 1] - base) / WAVE);
     const int wp = w & ~1;
     auto off = [&](int l, int j) { return (j < wp) ? base + (int64_t)(j >> 1) * (2 * WAVE) + l * 2 + (j & 1) : base + (int64_t)(w - 1) * WAVE + l; };
+    // (lane l, column j) -> entry index within the lane's row
+    auto entry = [&](int l, int j) { return (G == 1) ? j : 2 * ((j >> 1) * G + (l % G)) + (j & 1); };
     bool comp = true;
     for (int j = 0; j < w; ++j) {
       // pass 1: real entries -> 32-bit columns, column base for the 16-bit form
       int64_t cb = INT64_MAX;
       for (int l = 0; l < WAVE; ++l) {
-        const int64_t q = s * WAVE + l;
-        const int64_t r = (q < m) ? (rows ? rows[q] : q) : -1;
+        const int64_t r = row_of(s * R + l / G);
         if (r < 0) continue;
         const int64_t rb = A.rowptr[r];
         const int len = (int)(A.rowptr[r + 1] - rb);
-        if (j < len) {
+        const int e = entry(l, j);
+        if (e < len) {
           const int64_t o = off(l, j);
-          S.col32[o] = A.col[rb + j];
-          S.val[o] = A.val[rb + j];
-          cb = std::min<int64_t>(cb, (int64_t)A.col[rb + j] - (rowrel ? r : 0));
+          S.col32[o] = A.col[rb + e];
+          S.val[o] = A.val[rb + e];
+          cb = std::min<int64_t>(cb, (int64_t)A.col[rb + e] - (rowrel ? r : 0));
         }
       }
       if (cb == INT64_MAX) cb = 0;
@@ -188,16 +207,17 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
       S.cbase[base / WAVE + j] = (int32_t)cb;
       // pass 2: deltas and padding
       for (int l = 0; l < WAVE; ++l) {
-        const int64_t q = s * WAVE + l;
-        const int64_t r = (q < m) ? (rows ? rows[q] : q) : -1;
+        const int64_t q = s * R + l / G;
+        const int64_t r = row_of(q);
         const int64_t o = off(l, j);
         const int64_t rb = r >= 0 ? A.rowptr[r] : 0;
         const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rb) : 0;
+        const int e = entry(l, j);
         // the row id the kernel will use for this lane: plain SELL = position, colour-major = rowid (lanes with r < 0 exit early)
         const int64_t rk = rows ? r : q;
         const int64_t rr = rowrel ? rk : 0;
-        if (j < len) {
-          const int64_t d = (int64_t)A.col[rb + j] - rr - cb;
+        if (e < len) {
+          const int64_t d = (int64_t)A.col[rb + e] - rr - cb;
           if (d < 0 || d > 65535) comp = false; else S.col16[o] = (uint16_t)d;
         } else {
           // padding (value 0): any valid column; prefer one reachable in both encodings
@@ -247,24 +267,20 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   D.nnz = A.rowptr[A.n_rows];
   const double avg = D.n_rows ? (double)D.nnz / (double)D.n_rows : 0.0;
   D.lanes = pick_lanes(avg);
-  bool sell = false;
+  // scalar matrices: sliced ELL with G lanes per row; G = the smallest power of two that yields >= 2^20
+  // threads (enough waves to fill 256 CUs), accepted if the padding stays below 35 %
+  int sellG = 0;
   if (allow_sell && A.br == 1 && A.bc == 1 && D.n_rows > 0 && D.nnz > 0) {
-    // padding estimate
-    int64_t stored = 0;
-    for (int64_t s = 0; s * WAVE < A.n_rows; ++s) {
-      int w = 0;
-      for (int64_t r = s * WAVE; r < std::min<int64_t>(A.n_rows, (s + 1) * WAVE); ++r) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
-      stored += (int64_t)w * WAVE;
-    }
-    // one thread per row only pays when there are enough rows to fill the chip with waves, or the rows are
-    // so short that lane groups would idle; long rows of small matrices go to the CSR-vector kernels
-    const bool enough_rows = D.n_rows >= (int64_t)1 << 20 || avg <= 6.0;
-    sell = enough_rows && (double)stored <= 1.25 * (double)D.nnz;
+    int G = 1;
+    while (G < 16 && D.n_rows * G < ((int64_t)1 << 20) && avg > 3.0 * G) G <<= 1;
+    for (int g = G; g >= 1; g >>= 1)
+      if ((double)sell_stored(A, g) <= 1.35 * (double)D.nnz) { sellG = g; break; }
   }
-  if (sell) {
+  if (sellG) {
     HostSell S;
-    build_sell(A, nullptr, A.n_rows, A.n_rows == A.n_cols, S);
+    build_sell(A, nullptr, A.n_rows, A.n_rows == A.n_cols, sellG, S);
     D.fmt = FMT_SELL;
+    D.lanes = sellG;
     D.n_slices = (int)(S.slice_ptr.size() - 1);
     D.stored = S.slice_ptr.back() & ~(int64_t)63;
     D.stream_bytes = S.stream_bytes;
@@ -314,7 +330,15 @@ struct Handle {
     if (M.n_rows == 0) return;
     if (M.fmt == FMT_SELL) {
       const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-      hipLaunchKernelGGL((sell_spmv_kernel<EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.sell.view(), x, y, ep);
+#define LAUNCH_SELL(G) hipLaunchKernelGGL((sell_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.sell.view(), x, y, ep)
+      switch (M.lanes) {
+        case 1: LAUNCH_SELL(1); break;
+        case 2: LAUNCH_SELL(2); break;
+        case 4: LAUNCH_SELL(4); break;
+        case 8: LAUNCH_SELL(8); break;
+        default: LAUNCH_SELL(16); break;
+      }
+#undef LAUNCH_SELL
     } else if (M.br == 1 && M.bc == 1) {
       const int grid = grid_for(M.n_rows * M.lanes);
 #define LAUNCH_CSR(G) hipLaunchKernelGGL((csrvec_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
@@ -327,6 +351,8 @@ struct Handle {
         default: LAUNCH_CSR(64); break;
       }
 #undef LAUNCH_CSR
+    } else if constexpr (EP == EP_PRE) {
+      throw Err("EP_PRE is only built for scalar matrices");
     } else {
       const int G = std::min(M.lanes, 16) < 2 ? 2 : std::min(M.lanes, 16);
       const int grid = grid_for(M.n_rows * G);
@@ -357,14 +383,14 @@ struct Handle {
     HIPCHK(hipGetLastError());
   }
 
-  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0}); }
-  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0}); }
+  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr}); }
+  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr}); }
   // y = yin + s * M x
-  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s}); }
+  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr}); }
   // xout = xin + omega * dinv * (b - A xin)
   void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout) {
     if (xin == xout) throw Err("jacobi_fused: in-place update is not allowed");
-    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega});
+    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr});
   }
 
   void zero(double* v, int64_t n) { if (n) HIPCHK(hipMemsetAsync(v, 0, n * sizeof(double), stream)); }
@@ -477,7 +503,10 @@ struct Handle {
 
   // pre-smoothing step of the cycles: x = 0; r = b; Smooth(x, b, r, 1, 1, 1)   (amg_matrix.cpp:193-206)
   void pre_smooth(DevLevel& L, double* x, const double* b, double* r) {
-    if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
+    if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Apre.empty()) {
+      // one pass: r = b - A' b, x = omega * Dinv * b   (A' = A * omega*Dinv built at create time)
+      spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x});
+    } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
       residual(L.A, x, b, r);              // r = b - A x
     } else if (plain(L) && L.sm_type == AMGX_SM_GS) {
@@ -649,7 +678,7 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     g.color_slice_ptr.resize(nc + 1);
     for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / WAVE);
     HostSell S;
-    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, S);
+    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, 1, S);
     upload_sell(S, g.sell);
     g.rowid.upload(rows);
   } else {
@@ -699,6 +728,15 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       if (!s.dinv) throw Err("dinv missing");
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
+      if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
+        // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
+        const int64_t nnz = s.A.rowptr[s.A.n_rows];
+        std::vector<double> sv((size_t)nnz);
+        for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
+        amgx_matrix As = s.A;
+        As.val = sv.data();
+        upload_matrix(As, L.Apre, "A (pre-smoothing image)");
+      }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);

@@ -35,7 +35,9 @@ enum Epilogue : int {
   EP_MULT = 0,   // y = A x
   EP_RES = 1,    // y = b - A x
   EP_AXPY = 2,   // y = yin + s * A x        (yin may alias y)
-  EP_JAC = 3     // y = yin + omega * dinv * (b - A yin)   with x == yin gathered, y != yin
+  EP_JAC = 3,    // y = yin + omega * dinv * (b - A yin)   with x == yin gathered, y != yin
+  EP_PRE = 4     // Jacobi pre-smoothing from x = 0 in one pass over the column-scaled image A' = A * omega*Dinv:
+                 //   y = b - A' b  (= b - A x with x = omega*Dinv*b),  y2 = omega * dinv * b  (= x)
 };
 
 struct EpArgs {
@@ -43,6 +45,7 @@ struct EpArgs {
   const double* yin;
   const double* dinv;
   double s;      // AXPY factor or Jacobi omega
+  double* y2;    // second output of EP_PRE
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
@@ -58,7 +61,12 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
   if (EP == EP_MULT) y[row] = acc;
   else if (EP == EP_RES) y[row] = ep.b[row] - acc;
   else if (EP == EP_AXPY) y[row] = ep.yin[row] + ep.s * acc;
-  else y[row] = ep.yin[row] + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
+  else if (EP == EP_JAC) y[row] = ep.yin[row] + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
+  else {
+    const double bi = ep.b[row];
+    y[row] = bi - acc;
+    ep.y2[row] = ep.s * (ep.dinv[row] * bi);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -123,17 +131,19 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
   return acc0 + acc1;
 }
 
-// SELL-64-pair, scalar, one thread per row, one wave per slice
-template <int EP>
+// SELL-64-pair, scalar, G lanes per row (G = 1: one thread per row), one wave per slice of 64/G rows
+template <int G, int EP>
 __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_slices, SellMat M,
                                                           const double* __restrict__ x, double* y, EpArgs ep) {
   const int lane = threadIdx.x & (WAVE - 1);
   // the slice index is wave-uniform: tell the compiler, so slice pointers and column bases use scalar loads
   const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
-  const int row = s * WAVE + lane;
-  const double acc = sell_row_dot(M, s, lane, row, x);
-  if (row < n_rows) store_scalar<EP>(row, acc, y, ep);
+  const int row = s * (WAVE / G) + lane / G;
+  double acc = sell_row_dot(M, s, lane, row, x);
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  if ((lane % G) == 0 && row < n_rows) store_scalar<EP>(row, acc, y, ep);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
     } else if (EP == EP_AXPY) {
 #pragma unroll
       for (int r = 0; r < BR; ++r) yo[r] = ep.yin[row * BR + r] + ep.s * acc[r];
-    } else {
+    } else if (EP == EP_JAC) {
       // Jacobi: only square blocks reach this branch (BR == BC)
       double tt[BR];
 #pragma unroll
