@@ -32,7 +32,7 @@ typedef struct amgh_matrix {
 typedef struct amgh_options {
   int32_t max_levels;        /* ngs_amg_max_levels        (10)                        */
   int64_t max_coarse_size;   /* ngs_amg_max_coarse_size   (50)                        */
-  double first_aaf;          /* ngs_amg_first_aaf         (0.05 3D / 0.1 2D)          */
+  double first_aaf;          /* ngs_amg_first_aaf         (0.05 3D / 0.1 2D; elasticity 0.1 / 0.15, own) */
   double aaf;                /* ngs_amg_aaf               (2^-dim)                    */
   int32_t enable_sp;         /* ngs_amg_enable_sp         (1)                         */
   double sp_omega;           /* ngs_amg_sp_omega          (1.0)                       */

@@ -1,0 +1,508 @@
+"""Python surface of the reference's pybind module ``NgsAMG`` (legacy alias ``ngs_amg``), re-hosted on the
+MI355X apply path.
+
+Class / method / kwarg names follow the reference (reference src/base/python/python_amg.hpp:12-105,
+src/h1/python_h1.cpp:24-48, src/elasticity/python_elasticity.cpp, src/base/solve/python_solve.cpp:55-109,
+src/base/coarsening/python_coarse.cpp:15-121, src/base/smoothers/python_smoothers.cpp:35-387).  NGSolve is
+not available here, so the classes work in the reference's "strictly algebraic" mode: they take the
+assembled finest matrix (ngsamg_amd.Matrix or scipy.sparse) plus a free-dof mask instead of a BilinearForm,
+and vectors are numpy arrays (host) or torch CUDA tensors (device resident).
+
+    pre = NgsAMG.h1_scal(mat, freedofs, ngs_amg_max_coarse_size=5)      # == Preconditioner(mat, "ngs_amg.h1_scal", ...)
+    pre.Mult(b, x)                                                      # one V-cycle on the GPU
+
+Flags carry the reference's ``ngs_amg_`` prefix (amg_pc.hpp:168); unknown flags are ignored, like NGSolve's
+Flags object does.  Errors surface as RuntimeError (NgsAMGError), like ngcore::Exception does.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import Matrix, NgsAMGError
+from .hierarchy import Hierarchy
+from .device import DeviceAMGMatrix
+
+PREFIX = "ngs_amg_"
+
+
+def _flags(kwargs):
+    out = {}
+    for k, v in kwargs.items():
+        out[k[len(PREFIX):] if k.startswith(PREFIX) else k] = v
+    return out
+
+
+def _as_matrix(mat, bs):
+    if isinstance(mat, Matrix):
+        return mat
+    if hasattr(mat, "tocsr"):
+        return Matrix.from_scipy(mat, bs)
+    raise NgsAMGError("mat must be an ngsamg_amd.Matrix or a scipy.sparse matrix")
+
+
+class BaseSmoother:
+    """smoothers[level] of an AMGMatrix (reference base_smoother.hpp:43-156): Smooth / SmoothBack with the
+    (res_updated, update_res, x_zero) contract, executed by the HIP kernels."""
+
+    def __init__(self, amg, level):
+        self._amg, self._level = amg, level
+
+    def _res(self, x, res):
+        if res is not None:
+            return res
+        if hasattr(x, "is_cuda"):
+            import torch
+            return torch.zeros_like(x)
+        return np.zeros_like(x)
+
+    def Smooth(self, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        self._amg._dev.Smooth(self._level, x, rhs, self._res(x, res), res_updated, update_res, x_zero, back=False)
+
+    def SmoothBack(self, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        self._amg._dev.Smooth(self._level, x, rhs, self._res(x, res), res_updated, update_res, x_zero, back=True)
+
+    def SmoothK(self, steps, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        res = self._res(x, res)
+        self.Smooth(x, rhs, res, res_updated, update_res, x_zero)          # base_smoother.hpp:87-94
+        for _ in range(steps - 1):
+            self.Smooth(x, rhs, res, update_res, update_res, False)
+
+    def SmoothBackK(self, steps, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        res = self._res(x, res)
+        self.SmoothBack(x, rhs, res, res_updated, update_res, x_zero)
+        for _ in range(steps - 1):
+            self.SmoothBack(x, rhs, res, update_res, update_res, False)
+
+    def GetMatrix(self):
+        return LevelMatrix(self._amg, self._level)
+
+    sys_mat = property(GetMatrix)
+
+
+class LevelMatrix:
+    """GetMatrix(level): y = A_level x on the GPU."""
+
+    def __init__(self, amg, level):
+        self._amg, self._level = amg, level
+        self.host = amg._hier.levels[level].A
+
+    @property
+    def height(self):
+        return self.host.n_rows * self.host.br
+
+    width = height
+
+    def Mult(self, x, y):
+        return self._amg._dev.MatVec(self._level, x, y)
+
+    def CreateVector(self):
+        return np.zeros(self.height)
+
+
+class BaseDOFMapStep:
+    """ProlMap step l -> l+1 (reference dof_map.hpp:252-334)."""
+
+    def __init__(self, amg, level):
+        self._amg, self._level = amg, level
+
+    def TransferF2C(self, x_fine, x_coarse):
+        return self._amg._dev.TransferF2C(self._level, x_fine, x_coarse)
+
+    def AddC2F(self, fac, x_fine, x_coarse):
+        return self._amg._dev.AddC2F(self._level, fac, x_fine, x_coarse)
+
+    def TransferC2F(self, x_fine, x_coarse):
+        if hasattr(x_fine, "zero_"):
+            x_fine.zero_()
+        else:
+            x_fine[...] = 0.0
+        return self._amg._dev.AddC2F(self._level, 1.0, x_fine, x_coarse)
+
+    F2C = TransferF2C
+    C2F = TransferC2F
+
+    def GetProl(self):
+        return self._amg._hier.levels[self._level].P
+
+
+class DOFMap:
+    """Container of the grid-transfer steps (reference dof_map.hpp:87-169)."""
+
+    def __init__(self, amg):
+        self._amg = amg
+
+    def GetNLevels(self):
+        return self._amg._hier.n_levels
+
+    def GetNSteps(self):
+        return self._amg._hier.n_levels - 1
+
+    def GetStep(self, k):
+        if not 0 <= k < self.GetNSteps():
+            raise NgsAMGError(f"DOFMap has no step {k}")
+        return BaseDOFMapStep(self._amg, k)
+
+    def CreateVector(self, level):
+        L = self._amg._hier.levels[level]
+        return np.zeros(L.n * L.bs)
+
+    def TransferF2C(self, level, x_fine, x_coarse):
+        return self.GetStep(level).TransferF2C(x_fine, x_coarse)
+
+    def AddC2F(self, level, fac, x_fine, x_coarse):
+        return self.GetStep(level).AddC2F(fac, x_fine, x_coarse)
+
+    def TransferAtoB(self, la, lb, vin, vout):
+        """move a host vector from level la to level lb through all steps in between (dof_map.cpp:500-573)"""
+        cur = np.array(vin, dtype=np.float64)
+        if la > lb:
+            for l in range(la - 1, lb - 1, -1):
+                nxt = self.CreateVector(l)
+                self.GetStep(l).TransferC2F(nxt, cur)
+                cur = nxt
+        else:
+            for l in range(la, lb):
+                nxt = self.CreateVector(l + 1)
+                self.GetStep(l).TransferF2C(cur, nxt)
+                cur = nxt
+        vout[...] = cur
+        return vout
+
+
+class AMGMatrix:
+    """The multigrid cycle as a matrix (reference amg_matrix.hpp:14-87)."""
+
+    def __init__(self, hier, dev):
+        self._hier, self._dev = hier, dev
+
+    @property
+    def height(self):
+        return self._dev.sizes[0]
+
+    width = height
+
+    def Mult(self, b, x):
+        return self._dev.Mult(b, x)
+
+    def MultAdd(self, s, b, x):
+        return self._dev.MultAdd(s, b, x)
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+    def GetMap(self):
+        return DOFMap(self)
+
+    def GetNLevels(self, rank=0):
+        return self._hier.n_levels
+
+    def GetNDof(self, level, rank=0):
+        L = self._hier.levels[level]
+        return L.n, L.bs
+
+    def GetSmoother(self, level=0):
+        if not 0 <= level < self._hier.n_levels - 1:
+            raise NgsAMGError(f"only have {self._hier.n_levels - 1} smoothers")
+        return BaseSmoother(self, level)
+
+    def GetMatrix(self, level=0):
+        return LevelMatrix(self, level)
+
+    def SmoothVFromLevel(self, level, x, b, res, res_updated=False, update_res=False, x_zero=False):
+        return self._dev.SmoothVFromLevel(level, x, b, res, res_updated, update_res, x_zero)
+
+    def CINV(self, sol, rhs):
+        """restrict rhs to the coarsest level, solve there, prolongate back (amg_matrix.cpp:406-431)"""
+        m = self.GetMap()
+        L = self._hier.n_levels
+        cur = np.array(rhs, dtype=np.float64)
+        for l in range(L - 1):
+            nxt = m.CreateVector(l + 1)
+            m.TransferF2C(l, cur, nxt)
+            cur = nxt
+        xs = np.zeros_like(cur)
+        self._dev.CoarseSolve(cur, xs)
+        m.TransferAtoB(L - 1, 0, xs, sol)
+        return sol
+
+    def GetBF(self, vec, level=0, dof=0, comp=0, rank=0):
+        """basis function (level, dof, comp) prolongated to the finest level (amg_matrix.cpp:434-511)"""
+        n, bs = self.GetNDof(level)
+        if comp >= bs or dof >= n:
+            raise NgsAMGError("GetBF: invalid dof / component")
+        e = np.zeros(n * bs)
+        e[bs * dof + comp] = 1.0
+        return self.GetMap().TransferAtoB(level, 0, e, vec)
+
+
+class _AMGPreconditioner:
+    """Common part of h1_scal / h1_2d / h1_3d / elast_2d / elast_3d (reference BaseAMGPC, amg_pc.hpp:26-228)."""
+    _bs = 1
+    _dim = 3
+    _energy = 0
+    _name = "amg"
+
+    def __init__(self, mat=None, freedofs=None, coords=None, device=0, **kwargs):
+        self.flags = _flags(kwargs)
+        self._freedofs = None
+        self._coords = coords
+        self._device = device
+        self._amg = None
+        self.finest_mat = None
+        if mat is not None:                       # strict-algebraic constructor (python_h1.cpp:24-33)
+            self.InitLevel(freedofs)
+            self.FinalizeLevel(mat)
+
+    # ---- lifecycle (amg_pc.cpp:375-434) -----------------------------------------------------------
+    def InitLevel(self, freedofs=None):
+        self._freedofs = None if freedofs is None else np.ascontiguousarray(np.asarray(freedofs).astype(np.uint8))
+
+    def FinalizeLevel(self, mat=None):
+        if mat is None:
+            raise NgsAMGError("FinalizeLevel: no matrix given")          # amg_pc.cpp:430
+        A = _as_matrix(mat, self._bs)
+        if A.br != self._bs and not (self._energy == 1 and A.br in (self._dim, self._dim + self._dim * (self._dim - 1) // 2)):
+            raise NgsAMGError(f"{self._name}: matrix block size {A.br} does not fit (expected {self._bs})")
+        f = self.flags
+        dim = int(f.get("dim", self._dim))
+        opts = {k: f[k] for k in ("max_levels", "max_coarse_size", "first_aaf", "aaf", "enable_sp", "sp_omega",
+                                  "sp_max_per_row", "sp_min_frac", "soc_thresh", "max_rounds", "log_level") if k in f}
+        if self._energy == 1:
+            rots = A.br > dim
+            opts["regularize_cmats"] = int(f.get("regularize_cmats", not rots))   # elasticity_pc_impl.hpp:134-139
+            if self._coords is None:
+                raise NgsAMGError(f"{self._name}: vertex coordinates are needed (coords=...)")
+        elif "regularize_cmats" in f:
+            opts["regularize_cmats"] = int(f["regularize_cmats"])
+        self.finest_mat = A
+        hier = Hierarchy(A, self._freedofs, self._coords, dim=dim, energy=self._energy, **opts)
+        sm_type = str(f.get("sm_type", "gs")).lower()                     # amg_pc.hpp:63
+        spec = f.get("sm_type_spec")
+        if sm_type not in ("gs", "jacobi"):
+            sm_type = "gs"                                                # bgs / dyn_block_gs ... fall back to gs (amg_pc_vertex_impl.hpp:587-593)
+        types = [sm_type] * hier.n_levels
+        if spec:
+            for i, t in enumerate(spec[: hier.n_levels]):
+                types[i] = t if t in ("gs", "jacobi") else "gs"
+        clev = str(f.get("clev", "inv")).lower()
+        dev = DeviceAMGMatrix(hier, sm_type=types, omega=float(f.get("sm_omega", 0.9)),
+                              sm_steps=int(f.get("sm_steps", 1)), sm_symm=bool(f.get("sm_symm", False)),
+                              mg_cycle=str(f.get("mg_cycle", "V")).upper(), clev="inv" if clev == "inv" else "none",
+                              device=self._device, use_graph=bool(f.get("use_graph", True)))
+        self._amg = AMGMatrix(hier, dev)
+        if f.get("do_test", False):
+            self.Test()
+        return self
+
+    def Update(self):
+        pass                                                              # amg_pc_vertex.hpp:74
+
+    def _need(self):
+        if self._amg is None:
+            raise NgsAMGError("preconditioner not finalized (call FinalizeLevel)")   # amg_pc.cpp:446
+        return self._amg
+
+    # ---- BaseMatrix interface (amg_pc.cpp:443-488) ---------------------------------------------------
+    def Mult(self, b, x):
+        return self._need().Mult(b, x)
+
+    def MultAdd(self, s, b, x):
+        return self._need().MultAdd(s, b, x)
+
+    MultTrans = Mult
+    MultTransAdd = MultAdd
+
+    @property
+    def height(self):
+        return self._need().height
+
+    width = height
+
+    def IsComplex(self):
+        return False
+
+    def CreateRowVector(self):
+        return np.zeros(self.height)
+
+    CreateColVector = CreateRowVector
+
+    # ---- queries (python_amg.hpp:28-101) ------------------------------------------------------------
+    def GetNLevels(self, rank=0):
+        return self._need().GetNLevels(rank)
+
+    def GetNProcs(self, level=0):
+        return 1
+
+    def GetBlockSize(self, level=0):
+        return self._need().GetNDof(level)[1]
+
+    def GetNDof(self, level, rank=0):
+        return self._need().GetNDof(level)[0]
+
+    def GetNDBS(self, level, rank=0):
+        return self._need().GetNDof(level)
+
+    def GetBF(self, vec=None, level=0, dof=0, comp=0, rank=0):
+        vec = np.zeros(self.height) if vec is None else vec
+        return self._need().GetBF(vec, level, dof, comp, rank)
+
+    def CINV(self, sol=None, rhs=None):
+        return self._need().CINV(sol, rhs)
+
+    def GetMap(self):
+        return self._need().GetMap()
+
+    def GetSmoother(self, level=0):
+        return self._need().GetSmoother(level)
+
+    def GetAMGMatrix(self):
+        return self._need()
+
+    def GetHierarchy(self):
+        return self._need()._hier
+
+    def Test(self, maxit=60):
+        """kappa(C A) estimate by Lanczos on the preconditioned operator, like Preconditioner::Test() /
+        ngs_amg_do_test (reference utils_sparseLA.cpp:1317-1360; eigenvalue cut-off 5e-5)."""
+        amg = self._need()
+        n = amg.height
+        free = np.repeat(amg._hier.levels[0].free.astype(bool), amg._hier.levels[0].bs)
+        rng = np.random.default_rng(0)
+        v = rng.standard_normal(n) * free
+        A = amg.GetMatrix(0)
+        alphas, betas = [], []
+        w, z = np.zeros(n), np.zeros(n)
+        # Lanczos for C A in the A-inner product
+        A.Mult(v, w)
+        v /= np.sqrt(np.dot(v, w))
+        v_old = np.zeros(n)
+        beta = 0.0
+        for _ in range(min(maxit, n)):
+            A.Mult(v, w)
+            amg.Mult(w * free, z)
+            z *= free
+            A.Mult(z, w)
+            alpha = np.dot(v, w)
+            z -= alpha * v + beta * v_old
+            A.Mult(z, w)
+            b2 = np.dot(z, w)
+            alphas.append(alpha)
+            if b2 <= 1e-28:
+                break
+            beta = np.sqrt(b2)
+            betas.append(beta)
+            v_old, v = v, z / beta
+        k = len(alphas)
+        T = np.diag(alphas) + np.diag(betas[: k - 1], 1) + np.diag(betas[: k - 1], -1)
+        ev = np.linalg.eigvalsh(T)
+        ev = ev[ev > 5e-5]
+        self.lam_min, self.lam_max = float(ev.min()), float(ev.max())
+        self.kappa = self.lam_max / self.lam_min
+        return self.lam_min, self.lam_max, self.kappa
+
+
+class h1_scal(_AMGPreconditioner):
+    _bs, _dim, _energy, _name = 1, 3, 0, "h1_scal"
+
+
+class h1_2d(_AMGPreconditioner):
+    _bs, _dim, _energy, _name = 2, 2, 0, "h1_2d"
+
+
+class h1_3d(_AMGPreconditioner):
+    _bs, _dim, _energy, _name = 3, 3, 0, "h1_3d"
+
+
+class elast_2d(_AMGPreconditioner):
+    _bs, _dim, _energy, _name = 3, 2, 1, "elast_2d"
+
+
+class elast_3d(_AMGPreconditioner):
+    _bs, _dim, _energy, _name = 6, 3, 1, "elast_3d"
+
+
+# ---- registry (reference RegisterPreconditioner<T>("NgsAMG.<name>"), amg_register.hpp:80-98) ------------
+_REGISTRY = {}
+for _cls in (h1_scal, h1_2d, h1_3d, elast_2d, elast_3d):
+    for _prefix in ("NgsAMG.", "ngs_amg."):
+        _REGISTRY[_prefix + _cls._name] = _cls
+
+
+def Preconditioner(mat, name, freedofs=None, **flags):
+    """Stand-in for ``ngsolve.Preconditioner(a, "ngs_amg.h1_scal", **flags)`` in strictly algebraic mode."""
+    if name not in _REGISTRY:
+        raise NgsAMGError(f"unknown preconditioner '{name}' (known: {sorted(_REGISTRY)})")
+    return _REGISTRY[name](mat, freedofs, **flags)
+
+
+# ---- stand-alone smoothers (python_smoothers.cpp:144-387) -------------------------------------------------
+
+class _SingleLevel:
+    """hierarchy-like object with one level, so a smoother can live on its own handle"""
+
+    def __init__(self, A, free, pinv):
+        import ctypes as C
+        lib = _lib.host()
+        n, bs = A.n_rows, A.br
+        free = np.ones(n, dtype=np.uint8) if free is None else np.ascontiguousarray(np.asarray(free).astype(np.uint8))
+        dinv = np.zeros(n * bs * bs)
+        d = A.desc()
+        _lib.hcheck(lib.amgh_calc_dinv(C.byref(d), _lib.ptr(free, C.c_uint8), int(bool(pinv)), _lib.ptr(dinv, C.c_double)))
+        color = np.zeros(n, dtype=np.int32)
+        nc = C.c_int32()
+        _lib.hcheck(lib.amgh_coloring(C.byref(d), _lib.ptr(free, C.c_uint8), _lib.ptr(color, C.c_int32), C.byref(nc)))
+        from .hierarchy import Level
+        self.levels = [Level(A=A, P=None, PT=None, free=free, dinv=dinv, coords=None, color=color,
+                             n_colors=int(nc.value), agg=None)]
+        self.coarse_n = 0
+        self.coarse_inv = np.empty(0)
+        self.n_levels = 1
+
+
+class _StandaloneSmoother(BaseSmoother):
+    def __init__(self, mat, freedofs, sm_type, pinv=False, nsteps=1, symm=False, omega=0.9, device=0):
+        A = _as_matrix(mat, 1)
+        hier = _SingleLevel(A, freedofs, pinv)
+        dev = DeviceAMGMatrix(hier, sm_type=sm_type, omega=omega, sm_steps=nsteps, sm_symm=symm, clev="none", device=device)
+        super().__init__(AMGMatrix(hier, dev), 0)
+
+
+def CreateJacobiSmoother(mat, freedofs=None, omega=0.9, device=0):
+    return _StandaloneSmoother(mat, freedofs, "jacobi", omega=omega, device=device)
+
+
+def CreateHybridGSS(mat, freedofs=None, pinv=False, NG_MPI_overlap=True, NG_MPI_thread=False, symm=False,
+                    symm_loc=False, nsteps=1, nsteps_loc=1, device=0):
+    """single GPU: the hybrid smoother degenerates to (multicolour) Gauss-Seidel on the local matrix"""
+    return _StandaloneSmoother(mat, freedofs, "gs", pinv=pinv, nsteps=nsteps, symm=symm, device=device)
+
+
+class ProxySmoother(BaseSmoother):
+    """k-step / symmetric wrapper (reference base_smoother.hpp:169-229)"""
+
+    def __init__(self, smoother, nsteps=1, symm=False):
+        self._sm, self._n, self._symm = smoother, nsteps, symm
+
+    def _symm_k(self, x, rhs, res, ru, ur, xz):
+        res = self._sm._res(x, res)
+        self._sm.Smooth(x, rhs, res, ru, ur, xz)
+        self._sm.SmoothBack(x, rhs, res, ur, ur, False)
+        for _ in range(self._n - 1):
+            self._sm.Smooth(x, rhs, res, ur, ur, False)
+            self._sm.SmoothBack(x, rhs, res, ur, ur, False)
+
+    def Smooth(self, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        if self._symm:
+            self._symm_k(x, rhs, res, res_updated, update_res, x_zero)
+        else:
+            self._sm.SmoothK(self._n, x, rhs, res, res_updated, update_res, x_zero)
+
+    def SmoothBack(self, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        if self._symm:
+            self._symm_k(x, rhs, res, res_updated, update_res, x_zero)
+        else:
+            self._sm.SmoothBackK(self._n, x, rhs, res, res_updated, update_res, x_zero)
+
+    def GetMatrix(self):
+        return self._sm.GetMatrix()

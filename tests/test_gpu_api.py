@@ -1,0 +1,135 @@
+"""The reference's own pytest drivers, re-hosted: ``Preconditioner(a, "ngs_amg.h1_scal", **flags)`` + CG with
+``assert cg.errors[-1] < tol*cg.errors[0]`` and ``assert cg.iterations < ms`` (reference tests/h1/amg_utils.py:337-363,
+tests/h1/simple/test_2d_lo.py, tests/h1/simple/test_vec.py, tests/elasticity/mdim/simple/test_3d_lo.py).
+Meshes are the build's structured grids instead of netgen meshes, so the budgets are the build's own."""
+import numpy as np
+import pytest
+
+from ngsamg_amd import fem, Matrix, NgsAMGError
+
+pytestmark = pytest.mark.gpu
+
+
+def Solve(mat, rhs, c, ms=100, tol=1e-12):
+    import torch
+    from ngsamg_amd.krylov import CGSolver
+    c.Test()
+    cg = CGSolver(mat=c.GetAMGMatrix()._dev, pre=c, maxsteps=ms, tol=tol)
+    sol = cg.Solve(torch.from_numpy(np.ascontiguousarray(rhs)).cuda())
+    assert cg.errors[-1] < tol * cg.errors[0]
+    assert cg.iterations < ms
+    return sol.cpu().numpy(), cg
+
+
+def _mat(p):
+    return Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+
+
+def test_2d_lo():
+    from ngsamg_amd import ngs_amg
+    p = fem.poisson_fast((101, 101), dirichlet="left|top")
+    c = ngs_amg.Preconditioner(_mat(p), "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2)
+    sol, cg = Solve(_mat(p), p.load, c, ms=45)
+    A = p.to_scipy()
+    f = p.free.astype(bool)
+    assert np.linalg.norm((A @ sol - p.load)[f]) < 1e-9 * np.linalg.norm(p.load)
+    assert c.GetNLevels() >= 3 and c.GetBlockSize(0) == 1 and c.GetNDof(0) == p.n
+    assert 1.0 <= c.kappa < 10.0
+
+
+def test_3d_lo_both_names_and_jacobi():
+    from ngsamg_amd import NgsAMG
+    p = fem.poisson_fast((25, 25, 25), dirichlet="right|top")
+    for name, kw, ms in (("NgsAMG.h1_scal", {}, 40), ("ngs_amg.h1_scal", {"ngs_amg_sm_type": "jacobi"}, 60),
+                         ("NgsAMG.h1_scal", {"ngs_amg_mg_cycle": "W"}, 30), ("NgsAMG.h1_scal", {"ngs_amg_sm_symm": True}, 30)):
+        c = NgsAMG.Preconditioner(_mat(p), name, freedofs=p.free, **kw)
+        Solve(_mat(p), p.load, c, ms=ms, tol=1e-10)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_vec_h1(dim):
+    """h1_2d / h1_3d: vector-valued H1 (reference tests/h1/simple/test_vec.py): block-diagonal Laplacian"""
+    from ngsamg_amd import NgsAMG
+    shape = (41, 41) if dim == 2 else (15, 15, 15)
+    p = fem.poisson_fast(shape, dirichlet="left|top")
+    val = p.val[:, None, None] * np.eye(dim)[None]
+    A = Matrix(p.n, p.n, dim, dim, p.rowptr, p.col, val)
+    cls = NgsAMG.h1_2d if dim == 2 else NgsAMG.h1_3d
+    c = cls(A, p.free, ngs_amg_max_coarse_size=10, ngs_amg_dim=dim)
+    rhs = np.repeat(p.load, dim) * np.tile(np.arange(1, dim + 1), p.n)
+    Solve(A, rhs, c, ms=50, tol=1e-10)
+    assert c.GetBlockSize(0) == dim and c.GetBlockSize(1) == dim
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_elast_3d_lo(rot):
+    """reference tests/elasticity/mdim/simple/test_3d_lo.py: beam 10x1x1, mu=1, lam=0, tol 1e-6, ms 40"""
+    from ngsamg_amd import NgsAMG
+    p = fem.elasticity_fast((41, 6, 6), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=(10.0, 1.0, 1.0))
+    c = NgsAMG.elast_3d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=10)
+    Solve(_mat(p), p.load, c, ms=60, tol=1e-6)
+    assert c.GetBlockSize(0) == (6 if rot else 3) and c.GetBlockSize(1) == 6
+
+
+def test_smoother_map_and_cinv_surface():
+    from ngsamg_amd import NgsAMG
+    from oracle.pyoracle import Oracle
+    p = fem.poisson_fast((17, 17, 17))
+    c = NgsAMG.h1_scal(_mat(p), p.free, ngs_amg_max_coarse_size=20)
+    H = c.GetHierarchy()
+    orc = Oracle(H.levels, sm_type="gs_mc")
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n) * p.free
+    sm = c.GetSmoother(0)
+    x, xo = np.zeros(p.n), np.zeros(p.n)
+    sm.SmoothK(2, x, b, None, False, True, True)
+    ro = np.zeros(p.n)
+    orc.smooth(0, xo, b, ro, False, True, True)
+    orc.smooth(0, xo, b, ro, True, True, False)
+    assert np.linalg.norm(x - xo) < 1e-10 * np.linalg.norm(xo)
+    # DOFMap round trip and CINV
+    m = c.GetMap()
+    assert m.GetNLevels() == c.GetNLevels()
+    xc = m.CreateVector(1)
+    m.GetStep(0).TransferF2C(b, xc)
+    assert np.linalg.norm(xc - orc.transfer_f2c(0, b)) < 1e-12 * np.linalg.norm(xc)
+    sol = np.zeros(p.n)
+    c.CINV(sol, b)
+    # Galerkin coarse-grid correction: P_all A_L^-1 P_all^T b
+    ref = b.copy()
+    for l in range(H.n_levels - 1):
+        ref = orc.transfer_f2c(l, ref)
+    ref = orc.coarse_solve(ref)
+    for l in range(H.n_levels - 2, -1, -1):
+        up = np.zeros(H.levels[l].n)
+        orc.add_c2f(l, 1.0, up, ref)
+        ref = up
+    assert np.linalg.norm(sol - ref) < 1e-9 * np.linalg.norm(ref)
+    bf = c.GetBF(level=1, dof=3, comp=0)
+    assert abs(bf.max() - 1.0) < 0.5 and bf.min() >= -1e-12       # a hat-like, non-negative coarse basis function
+    # stand-alone smoothers
+    A = _mat(p)
+    js = NgsAMG.CreateJacobiSmoother(A, p.free)
+    x1 = np.zeros(p.n)
+    js.Smooth(x1, b, None, False, False, True)
+    assert np.allclose(x1, 0.9 * H.levels[0].dinv * b, rtol=1e-14, atol=1e-14)
+    gs = NgsAMG.CreateHybridGSS(A, p.free)
+    x2, x3 = np.zeros(p.n), np.zeros(p.n)
+    gs.Smooth(x2, b)
+    Oracle(H.levels[:1], sm_type="gs_mc", clev="none").smooth(0, x3, b, np.zeros(p.n), False, False, False)
+    assert np.linalg.norm(x2 - x3) < 1e-10 * np.linalg.norm(x3)
+
+
+def test_error_behaviour():
+    from ngsamg_amd import NgsAMG
+    p = fem.poisson_fast((9, 9))
+    with pytest.raises(NgsAMGError):
+        NgsAMG.Preconditioner(_mat(p), "ngs_amg.nonsense")
+    c = NgsAMG.h1_scal()
+    with pytest.raises(NgsAMGError):
+        c.Mult(np.zeros(3), np.zeros(3))                    # not finalized (reference amg_pc.cpp:446)
+    with pytest.raises(NgsAMGError):
+        c.FinalizeLevel(None)                               # reference amg_pc.cpp:430
+    e = fem.elasticity_fast((4, 4, 4))
+    with pytest.raises(NgsAMGError):
+        NgsAMG.elast_3d(_mat(e), e.free)                    # coordinates missing
