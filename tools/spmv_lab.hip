@@ -162,6 +162,29 @@ __global__ __launch_bounds__(256) void k_read(int64_t n2, const double2* __restr
   if (s == 123.456) out[0] = s;
 }
 
+// read-only calibration kernels for the FETCH_SIZE counter: 8 B / lane and 4 B / lane (nt) streams
+__global__ __launch_bounds__(256) void k_read8(int64_t n, const double* __restrict__ a, double* out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  double s = 0;
+  for (; i < n; i += stride) s += a[i];
+  if (s == 123.456) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_read4nt(int64_t n, const uint32_t* __restrict__ a, double* out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  uint32_t s = 0;
+  for (; i < n; i += stride) s += __builtin_nontemporal_load(a + i);
+  if (s == 123456u) out[0] = s;
+}
+__global__ __launch_bounds__(256) void k_read16nt(int64_t n2, const double* __restrict__ a, double* out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  double s = 0;
+  for (; i < n2; i += stride) s += __builtin_nontemporal_load(a + 2 * i) + __builtin_nontemporal_load(a + 2 * i + 1);
+  if (s == 123.456) out[0] = s;
+}
+
 int main(int argc, char** argv) {
   const int nv = argc > 1 ? atoi(argv[1]) : 215;
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
@@ -272,6 +295,9 @@ int main(int argc, char** argv) {
   vars.push_back({"persist 2048 blocks nt", [&](int q) { hipLaunchKernelGGL((k_sell_persist<256, true>), dim3(2048), dim3(256), 0, st, n, (int)ns, d_sp, d_sc, d_sv, d_x[q], d_b[q], d_y[q]); }, alg_bytes, {}});
   vars.push_back({"persist 1024 blocks", [&](int q) { hipLaunchKernelGGL((k_sell_persist<256, false>), dim3(1024), dim3(256), 0, st, n, (int)ns, d_sp, d_sc, d_sv, d_x[q], d_b[q], d_y[q]); }, alg_bytes, {}});
   vars.push_back({"read-only 1.2GB double2", [&](int q) { hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, st, stored / 2, (const double2*)d_sv, d_y[q]); }, (double)stored * 8, {}});
+  vars.push_back({"calib read 8B/lane 1.27GB", [&](int q) { hipLaunchKernelGGL(k_read8, dim3(4096), dim3(256), 0, st, stored, (const double*)d_sv, d_y[q]); }, (double)stored * 8, {}});
+  vars.push_back({"calib read 4B/lane nt 0.63GB", [&](int q) { hipLaunchKernelGGL(k_read4nt, dim3(4096), dim3(256), 0, st, stored, (const uint32_t*)d_sc, d_y[q]); }, (double)stored * 4, {}});
+  vars.push_back({"calib read 16B/lane nt 1.27GB", [&](int q) { hipLaunchKernelGGL(k_read16nt, dim3(4096), dim3(256), 0, st, stored / 2, (const double*)d_sv, d_y[q]); }, (double)stored * 8, {}});
   vars.push_back({"read-only 8192 blocks", [&](int q) { hipLaunchKernelGGL(k_read, dim3(8192), dim3(256), 0, st, stored / 2, (const double2*)d_sv, d_y[q]); }, (double)stored * 8, {}});
 
   for (int mode = 0; mode < 2; ++mode) {       // 0: same vector set every launch (warm x/b), 1: rotate 4 sets (cold)
