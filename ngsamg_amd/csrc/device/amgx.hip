@@ -14,6 +14,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -92,7 +93,17 @@ struct DevGS {                          // colour-major data for multicolour Gau
   DevBuf<int32_t> rowlist;
 };
 
+struct DevRestrict {                    // column-blocked P^T (see restrict_chunk_kernel)
+  int n_chunks = 0;
+  int64_t n_slots = 0;
+  DevBuf<int32_t> chunk_slot, slot_ptr, optr, oidx;
+  DevBuf<double> w, part;
+  DevBuf<uint16_t> fi;
+  bool empty() const { return n_chunks == 0; }
+};
+
 struct DevLevel {
+  DevRestrict R;
   DevMatrix A, P, PT;
   DevMatrix Apre;                       // scalar Jacobi levels: A * diag(omega * dinv), see EP_PRE in kernels.hpp
   DevBuf<double> dinv;
@@ -297,6 +308,43 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   }
 }
 
+static void build_restrict(const amgx_matrix& P, DevRestrict& R) {
+  const int64_t nf = P.n_rows, nc = P.n_cols;
+  const int CH = RESTRICT_CHUNK;
+  const int64_t nch = (nf + CH - 1) / CH;
+  std::vector<int32_t> chunk_slot(nch + 1, 0), slot_ptr(1, 0), slot_col;
+  std::vector<double> w;
+  std::vector<uint16_t> fi;
+  w.reserve(P.rowptr[nf]); fi.reserve(P.rowptr[nf]);
+  struct Trip { int32_t J; uint16_t i; double w; };
+  std::vector<Trip> t;
+  for (int64_t c = 0; c < nch; ++c) {
+    t.clear();
+    const int64_t r0 = c * CH, r1 = std::min<int64_t>(nf, r0 + CH);
+    for (int64_t i = r0; i < r1; ++i)
+      for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) t.push_back({P.col[k], (uint16_t)(i - r0), P.val[k]});
+    std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.J < b.J; });
+    for (size_t q = 0; q < t.size(); ++q) {
+      if (q == 0 || t[q].J != t[q - 1].J) { if (q) slot_ptr.push_back((int32_t)w.size()); slot_col.push_back(t[q].J); }
+      w.push_back(t[q].w); fi.push_back(t[q].i);
+    }
+    if (!t.empty()) slot_ptr.push_back((int32_t)w.size());
+    if ((int64_t)t.size() > RESTRICT_MAX_ENTRIES) return;      // rows too long for the LDS product buffer: keep the P^T form
+    chunk_slot[c + 1] = (int32_t)slot_col.size();
+  }
+  const int64_t ns = (int64_t)slot_col.size();
+  if ((int64_t)slot_ptr.size() != ns + 1) throw Err("build_restrict: internal slot count mismatch");
+  std::vector<int32_t> optr(nc + 1, 0), oidx(ns);
+  for (int64_t sidx = 0; sidx < ns; ++sidx) optr[slot_col[sidx] + 1]++;
+  for (int64_t J = 0; J < nc; ++J) optr[J + 1] += optr[J];
+  std::vector<int32_t> pos(optr.begin(), optr.end() - 1);
+  for (int64_t sidx = 0; sidx < ns; ++sidx) oidx[pos[slot_col[sidx]]++] = (int32_t)sidx;   // ascending chunk order per row
+  R.n_chunks = (int)nch; R.n_slots = ns;
+  R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr); R.oidx.upload(oidx);
+  R.w.upload(w); R.fi.upload(fi);
+  R.part.alloc((size_t)std::max<int64_t>(1, ns));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the handle
 // ---------------------------------------------------------------------------------------------------
@@ -353,6 +401,16 @@ struct Handle {
 #undef LAUNCH_CSR
     } else if constexpr (EP == EP_PRE) {
       throw Err("EP_PRE is only built for scalar matrices");
+    } else if (M.br == 6 && M.bc == 6) {
+      // 6x6: row-per-lane kernel; W lane groups per block row chosen from the average row length
+      const double avg = M.n_rows ? (double)M.nnz / (double)M.n_rows : 0.0;
+      const int W = avg >= 48.0 ? 4 : (avg >= 20.0 ? 2 : 1);
+      const int rpw = WAVE / (6 * W);
+      const int64_t waves = (M.n_rows + rpw - 1) / rpw;
+      const int grid = (int)std::max<int64_t>(1, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+      if (W == 4) hipLaunchKernelGGL((bcsr6_spmv_kernel<4, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
+      else if (W == 2) hipLaunchKernelGGL((bcsr6_spmv_kernel<2, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
+      else hipLaunchKernelGGL((bcsr6_spmv_kernel<1, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
     } else {
       const int G = std::min(M.lanes, 16) < 2 ? 2 : std::min(M.lanes, 16);
       const int grid = grid_for(M.n_rows * G);
@@ -459,7 +517,15 @@ struct Handle {
     HIPCHK(hipGetLastError());
   }
 
-  void transfer_f2c(int l, const double* xf, double* xc) { mult(lev[l].PT, xf, xc); }                      // dof_map.cpp:636-654
+  void transfer_f2c(int l, const double* xf, double* xc) {                                               // dof_map.cpp:636-654
+    const DevRestrict& R = lev[l].R;
+    if (R.empty()) { mult(lev[l].PT, xf, xc); return; }
+    hipLaunchKernelGGL(restrict_chunk_kernel, dim3(R.n_chunks), dim3(BLOCK), 0, stream, lev[l].n, R.chunk_slot.p, R.slot_ptr.p,
+                       R.w.p, R.fi.p, xf, R.part.p);
+    hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                       R.oidx.p, R.part.p, xc);
+    HIPCHK(hipGetLastError());
+  }
   void add_c2f(int l, double fac, double* xf, const double* xc) { mult_add(lev[l].P, fac, xc, xf, xf); }   // dof_map.cpp:697-709
 
   // ------------------------------------------------------------------ smoothers (flag contract: base_smoother.hpp:68-112)
@@ -725,6 +791,15 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         throw Err("PT does not match P");
       upload_matrix(s.P, L.P, "P");
       upload_matrix(s.PT, L.PT, "PT");
+      // big scalar levels restrict through the column-blocked form (the P^T gather is TA/L2-bound there)
+      {
+        // Measured non-win (profiles/r01/restrict_blocked.txt): 121 + 22 us vs 134 us for the P^T gather at cfg 2,
+        // so the blocked form is OFF unless AMGX_RESTRICT_MIN_ROWS asks for it (kept for the fused-residual plan).
+        int64_t min_rows = INT64_MAX;
+        if (const char* e = std::getenv("AMGX_RESTRICT_MIN_ROWS")) min_rows = std::atoll(e);
+        if (s.P.br == 1 && s.P.bc == 1 && s.P.n_rows >= min_rows && s.P.rowptr[s.P.n_rows] < (int64_t)2147483647)
+          build_restrict(s.P, L.R);
+      }
       if (!s.dinv) throw Err("dinv missing");
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS) build_gs(s, L);

@@ -228,6 +228,61 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 6x6 block CSR, row-per-lane inside the block: lane (g, r) of a block row's lane group owns scalar row r and the
+// blocks k = g, g+W, ...; it reads its 48-B row of each block as three 16-B loads, so the six lanes of a group read
+// one contiguous 288-B block and a wave streams 10 / 5 / 2 block rows (W = 1 / 2 / 4) with full cache-line use.
+// (The generic bcsrvec kernel lets ONE lane read a whole block with 36 scalar loads at a 288-B lane stride and
+// reaches only 2.7 TB/s on the 6x6 elasticity levels.)
+template <int W, int EP>
+__global__ __launch_bounds__(BLOCK) void bcsr6_spmv_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ cols,
+                                                           const double* __restrict__ vals,
+                                                           const double* __restrict__ x, double* y, EpArgs ep) {
+  constexpr int LPR = 6 * W;                 // lanes per block row
+  constexpr int RPW = WAVE / LPR;            // block rows per wave
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int rloc = lane / LPR;
+  const int g = (lane % LPR) / 6;
+  const int r = lane % 6;
+  const int64_t row = wave * RPW + rloc;
+  const bool active = rloc < RPW && row < n_rows;
+  double acc = 0.0;
+  if (active) {
+    const int e = rowptr[row + 1];
+    for (int k = rowptr[row] + g; k < e; k += W) {
+      const double2* __restrict__ a = reinterpret_cast<const double2*>(vals + (int64_t)k * 36 + r * 6);
+      const double2* __restrict__ xv = reinterpret_cast<const double2*>(x + (int64_t)cols[k] * 6);
+      const double2 a0 = a[0], a1 = a[1], a2 = a[2];
+      const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
+      acc += a0.x * x0.x + a0.y * x0.y + a1.x * x1.x + a1.y * x1.y + a2.x * x2.x + a2.y * x2.y;
+    }
+  }
+  if (W == 4) acc += __shfl_down(acc, 12, WAVE);
+  if (W >= 2) acc += __shfl_down(acc, 6, WAVE);
+  // lanes with g == 0 now hold (A x)_r of their block row
+  const int64_t i = row * 6 + r;
+  double out = 0.0;
+  if (EP == EP_JAC) {
+    const double t = (active && g == 0) ? ep.b[i] - acc : 0.0;
+    // u_r = sum_c dinv[r][c] * t_c : fetch t_c from the six row-lanes of the group
+    const int base = lane - r;
+    double u = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double tc = __shfl(t, base + c, WAVE);
+      if (active && g == 0) u += ep.dinv[row * 36 + r * 6 + c] * tc;
+    }
+    if (active && g == 0) out = ep.yin[i] + ep.s * u;
+  } else if (active && g == 0) {
+    if (EP == EP_MULT) out = acc;
+    else if (EP == EP_RES) out = ep.b[i] - acc;
+    else out = ep.yin[i] + ep.s * acc;
+  }
+  if (active && g == 0) y[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // multicolour Gauss-Seidel, scalar: one colour per launch, colour-major SELL copy of A.
 //   x_k += dinv_k * (b_k - A_k: x)        (RHS form, reference gssmoother.cpp:209-212)
 // Rows of one colour have no mutual couplings, so the in-place update is race-free.
@@ -292,6 +347,51 @@ __global__ __launch_bounds__(BLOCK) void bgs_color_kernel(int list_begin, int li
       x[(int64_t)row * BS + r] += u;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column-blocked restriction  b_c = P^T r  for large scalar levels (reference ProlMap::TransferF2C,
+// dof_map.cpp:636-654).  The gather form over P^T touches ~40 different cache lines of r per coarse row and is
+// TA/L2-bound (2.9 TB/s); here a workgroup owns a chunk of RESTRICT_CHUNK consecutive FINE rows, stages that
+// piece of r in LDS with coalesced loads and reduces the chunk-local transpose of P from LDS:
+//   part[slot] = sum_e w[e] * r_lds[fi[e]]       (slot = (chunk, coarse column) pair, entries 10 B each)
+// A second tiny kernel adds the few partial sums of every coarse row in a fixed order (deterministic, no atomics).
+constexpr int RESTRICT_CHUNK = 1024;          // fine rows per workgroup
+constexpr int RESTRICT_MAX_ENTRIES = 4096;    // entries of P per chunk (P has <= sp_max_per_row entries per row)
+
+// phase A: every thread streams entries (coalesced, independent loads) and leaves the products in LDS;
+// phase B: one thread per (chunk, coarse column) slot adds its contiguous segment of products.
+__global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, const int32_t* __restrict__ chunk_slot,
+                                                               const int32_t* __restrict__ slot_ptr,
+                                                               const double* __restrict__ w, const uint16_t* __restrict__ fi,
+                                                               const double* __restrict__ r, double* __restrict__ part) {
+  __shared__ double rl[RESTRICT_CHUNK];
+  __shared__ double pr[RESTRICT_MAX_ENTRIES];
+  const int c = blockIdx.x;
+  const int64_t row0 = (int64_t)c * RESTRICT_CHUNK;
+  const int nrow = (int)((n_fine - row0) < RESTRICT_CHUNK ? (n_fine - row0) : RESTRICT_CHUNK);
+  const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
+  const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
+  for (int i = threadIdx.x; i < nrow; i += BLOCK) rl[i] = r[row0 + i];
+  __syncthreads();
+  for (int e = e0 + threadIdx.x; e < e1; e += BLOCK) pr[e - e0] = ld_nt(w + e) * rl[ld_nt(fi + e)];
+  __syncthreads();
+  for (int slot = s0 + threadIdx.x; slot < s1; slot += BLOCK) {
+    const int a = slot_ptr[slot] - e0, b = slot_ptr[slot + 1] - e0;
+    double acc = 0.0;
+    for (int k = a; k < b; ++k) acc += pr[k];
+    part[slot] = acc;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void restrict_sum_kernel(int64_t n_coarse, const int32_t* __restrict__ optr,
+                                                             const int32_t* __restrict__ oidx,
+                                                             const double* __restrict__ part, double* __restrict__ bc) {
+  const int64_t J = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (J >= n_coarse) return;
+  double acc = 0.0;
+  for (int k = optr[J]; k < optr[J + 1]; ++k) acc += part[oidx[k]];
+  bc[J] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------

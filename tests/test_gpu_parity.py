@@ -247,3 +247,23 @@ def test_pcg_elasticity_iteration_parity():
     cg.Solve(torch.from_numpy(p.load).cuda())
     assert abs(cg.iterations - it_ref) <= 1
     assert cg.errors[-1] < 1e-6 * cg.errors[0] * 10 and cg.iterations < 60
+
+
+def test_blocked_restriction_matches_oracle(monkeypatch):
+    """the column-blocked restriction (used for levels with >= 2^20 rows) forced on small levels"""
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_RESTRICT_MIN_ROWS", "1")
+    for shape, diri, mcs in (((70, 50), "left|top", 5), ((17, 17, 17), "right|top", 20)):
+        p, H = poisson_case(shape, diri, mcs)
+        orc = Oracle(H.levels, sm_type="jacobi")
+        dev = _dev(H, sm_type="jacobi")
+        rng = np.random.default_rng(1)
+        for l in range(H.n_levels - 1):
+            xf = rng.standard_normal(dev.sizes[l])
+            xc = np.full(dev.sizes[l + 1], np.nan)
+            dev.TransferF2C(l, xf, xc)
+            assert _rel(xc, orc.transfer_f2c(l, xf)) < 1e-13
+        b = rhs(p, 2)
+        x = np.empty(p.n)
+        dev.Mult(b, x)
+        assert _rel(x, orc.apply(b)) < 1e-12
