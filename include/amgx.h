@@ -100,7 +100,18 @@ int amgx_smooth(amgx_handle h, int level, int dir, double* x, const double* b, d
 /* AMGMatrix::SmoothVFromLevel (amg_matrix.cpp:310-374) */
 int amgx_smooth_v_from_level(amgx_handle h, int level, double* x, const double* b, double* res,
                              int res_updated, int update_res, int x_zero, int flags);
-/* y = A_level x  (GetMatrix(level).Mult) */
+/* Stage entry points for rank-partitioned levels: a level matrix may have n_cols > n_rows, the
+ * trailing columns being ghost entries owned by other ranks.  The caller fills the ghost part of the gathered vector
+ * (halo exchange, e.g. torch.distributed over RCCL) and drives the cycle stage by stage:
+ *   amgx_jacobi_pre : x = omega*Dinv*b, r = b - A x     b: n_cols entries (ghosts valid), x, r: n_rows
+ *                     (RichardsonSmoother::Smooth with res_updated = update_res = x_zero = 1, base_smoother.cpp:61-74)
+ *   amgx_prolong    : x_out = x_in + fac * P x_coarse   (ProlMap::AddC2F, dof_map.cpp:697-709, out of place)
+ *   amgx_jacobi_post: x_out = x_in + omega*Dinv*(b - A x_in)   x_in: n_cols entries (ghosts valid), x_out != x_in */
+int amgx_jacobi_pre(amgx_handle h, int level, const double* b, double* x, double* r, int flags);
+int amgx_jacobi_post(amgx_handle h, int level, const double* x_in, const double* b, double* x_out, int flags);
+int amgx_prolong(amgx_handle h, int level, double fac, const double* x_in, const double* x_coarse, double* x_out, int flags);
+
+/* y = A_level x  (GetMatrix(level).Mult); x has n_cols entries */
 int amgx_matvec(amgx_handle h, int level, const double* x, double* y, int flags);
 /* DOFMap::TransferF2C (x_coarse = P^T x_fine) and AddC2F (x_fine += fac * P x_coarse), dof_map.cpp:636-709 */
 int amgx_transfer_f2c(amgx_handle h, int level, const double* x_fine, double* x_coarse, int flags);

@@ -111,9 +111,11 @@ struct DevLevel {
   int sm_type = AMGX_SM_JACOBI;
   double omega = 0.9;
   int sm_steps = 1, sm_symm = 0;
-  int64_t n = 0;                        // block rows
+  int64_t n = 0;                        // block rows (= owned rows of a rank-partitioned level)
+  int64_t ncols = 0;                    // block columns of A (>= n: owned + ghost columns)
   int bs = 1;
   int64_t len() const { return n * bs; }
+  int64_t ext_len() const { return ncols * bs; }
   DevBuf<double> x, rhs, res, tmp;      // x_level / rhs_level / res_level (amg_matrix.cpp:19-26) + ping-pong buffer
 };
 
@@ -272,7 +274,7 @@ static void check_matrix(const amgx_matrix& A, const char* what) {
     if (A.col[k] < 0 || A.col[k] >= A.n_cols) throw Err(std::string(what) + ": column index out of range");
 }
 
-static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true) {
+static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true, bool rowrel_ok = false) {
   check_matrix(A, what);
   D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = A.br; D.bc = A.bc;
   D.nnz = A.rowptr[A.n_rows];
@@ -289,7 +291,7 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   }
   if (sellG) {
     HostSell S;
-    build_sell(A, nullptr, A.n_rows, A.n_rows == A.n_cols, sellG, S);
+    build_sell(A, nullptr, A.n_rows, rowrel_ok && A.n_cols >= A.n_rows, sellG, S);
     D.fmt = FMT_SELL;
     D.lanes = sellG;
     D.n_slices = (int)(S.slice_ptr.size() - 1);
@@ -776,16 +778,18 @@ static Handle* create(const amgx_hierarchy_desc* d) {
   for (int l = 0; l < d->n_levels; ++l) {
     const amgx_level_desc& s = d->levels[l];
     DevLevel& L = h->lev[l];
-    if (s.A.n_rows != s.A.n_cols || s.A.br != s.A.bc) throw Err("level matrix must be square with square blocks");
-    L.n = s.A.n_rows; L.bs = s.A.br;
+    // n_cols > n_rows: the trailing columns are ghost entries of a rank-partitioned level (filled by the caller's
+    // halo exchange before every operation that gathers from them)
+    if (s.A.n_cols < s.A.n_rows || s.A.br != s.A.bc) throw Err("level matrix must have n_cols >= n_rows and square blocks");
+    L.n = s.A.n_rows; L.ncols = s.A.n_cols; L.bs = s.A.br;
     L.sm_type = s.sm_type; L.omega = s.omega; L.sm_steps = s.sm_steps; L.sm_symm = s.sm_symm;
     if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
     // block GS walks the CSR arrays of A, so keep A in CSR there
-    upload_matrix(s.A, L.A, "A", !(s.sm_type == AMGX_SM_GS && s.A.br > 1));
+    upload_matrix(s.A, L.A, "A", !(s.sm_type == AMGX_SM_GS && s.A.br > 1), true);
     if (!last) {
       const amgx_level_desc& c = d->levels[l + 1];
-      if (s.P.n_rows != s.A.n_rows || s.P.n_cols != c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
+      if (s.P.n_rows != s.A.n_rows || s.P.n_cols > c.A.n_cols || s.P.n_cols < c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
         throw Err("P does not match the level matrices");
       if (s.PT.n_rows != s.P.n_cols || s.PT.n_cols != s.P.n_rows || s.PT.br != s.P.bc || s.PT.bc != s.P.br)
         throw Err("PT does not match P");
@@ -801,22 +805,23 @@ static Handle* create(const amgx_hierarchy_desc* d) {
           build_restrict(s.P, L.R);
       }
       if (!s.dinv) throw Err("dinv missing");
-      L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
+      L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
         // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
         std::vector<double> sv((size_t)nnz);
+        // (rank-partitioned levels: dinv must cover the ghost columns too, i.e. n_cols entries)
         for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
         amgx_matrix As = s.A;
         As.val = sv.data();
-        upload_matrix(As, L.Apre, "A (pre-smoothing image)");
+        upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true);
       }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
     }
-    const size_t len = (size_t)std::max<int64_t>(1, L.len());
+    const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
     HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));
     HIPCHK(hipMemset(L.rhs.p, 0, len * sizeof(double)));
@@ -975,13 +980,60 @@ int amgx_smooth_v_from_level(amgx_handle hh, int level, double* x, const double*
   });
 }
 
+int amgx_jacobi_pre(amgx_handle hh, int level, const double* b, double* x, double* r, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_jacobi_pre: level out of range");
+    amgx::DevLevel& L = h.lev[level];
+    if (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI) throw amgx::Err("amgx_jacobi_pre: level has no Jacobi smoother");
+    if (!b || !x || !r) throw amgx::Err("amgx_jacobi_pre: null vector");
+    Staged st(h, flags);
+    const double* db = st.in(0, b, L.ext_len());
+    double* dx = st.inout(1, x, L.len(), false);
+    double* dr = st.inout(2, r, L.len(), false);
+    h.pre_smooth(L, dx, db, dr);
+    st.out(1, x, L.len());
+    st.out(2, r, L.len());
+    st.finish();
+  });
+}
+
+int amgx_jacobi_post(amgx_handle hh, int level, const double* xin, const double* b, double* xout, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_jacobi_post: level out of range");
+    amgx::DevLevel& L = h.lev[level];
+    if (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI) throw amgx::Err("amgx_jacobi_post: level has no Jacobi smoother");
+    if (!xin || !b || !xout || xin == xout) throw amgx::Err("amgx_jacobi_post: bad vectors");
+    Staged st(h, flags);
+    const double* dxi = st.in(0, xin, L.ext_len());
+    const double* db = st.in(1, b, L.len());
+    double* dxo = st.inout(2, xout, L.len(), false);
+    h.jacobi_fused(L, dxi, db, dxo);
+    st.out(2, xout, L.len());
+    st.finish();
+  });
+}
+
+int amgx_prolong(amgx_handle hh, int level, double fac, const double* x_in, const double* x_coarse, double* x_out, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_prolong: level out of range");
+    if (!x_in || !x_coarse || !x_out) throw amgx::Err("amgx_prolong: null vector");
+    Staged st(h, flags);
+    const double* di = st.in(0, x_in, h.lev[level].len());
+    const double* dc = st.in(1, x_coarse, h.lev[level].P.n_cols * h.lev[level].P.bc);
+    double* dout = st.inout(2, x_out, h.lev[level].len(), false);
+    h.mult_add(h.lev[level].P, fac, dc, di, dout);
+    st.out(2, x_out, h.lev[level].len());
+    st.finish();
+  });
+}
+
 int amgx_matvec(amgx_handle hh, int level, const double* x, double* y, int flags) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matvec: level out of range");
     if (!x || !y || x == y) throw amgx::Err("amgx_matvec: bad vectors");
     const int64_t n = h.lev[level].len();
     Staged st(h, flags);
-    const double* dx = st.in(0, x, n);
+    const double* dx = st.in(0, x, h.lev[level].ext_len());
     double* dy = st.inout(1, y, n, false);
     h.mult(h.lev[level].A, dx, dy);
     st.out(1, y, n);

@@ -95,6 +95,7 @@ class DeviceAMGMatrix:
         if lib.amgx_create(C.byref(desc), C.byref(self._h)) != 0:
             raise NgsAMGError(lib.amgx_last_error(None).decode())
         self.sizes = [lv.A.n_rows * lv.A.br for lv in levels]
+        self.ext_sizes = [lv.A.n_cols * lv.A.bc for lv in levels]      # > sizes on rank-partitioned levels (ghost columns)
         self.n_levels = n
         self._stream = None
 
@@ -168,10 +169,24 @@ class DeviceAMGMatrix:
         self._ck(self._lib.amgx_smooth_v_from_level(self._h, level, vx.addr, vb.addr, vr.addr, int(res_updated),
                                                     int(update_res), int(x_zero), self._flags(vx, vb, vr)))
 
+    # stage entry points for rank-partitioned levels (ghost entries of the gathered vector filled by the caller) ----
+    def JacobiPre(self, level, b_ext, x, r):
+        vb, vx, vr = _Vec(b_ext, self.ext_sizes[level], "b"), _Vec(x, self._size(level), "x", True), _Vec(r, self._size(level), "r", True)
+        self._ck(self._lib.amgx_jacobi_pre(self._h, level, vb.addr, vx.addr, vr.addr, self._flags(vb, vx, vr)))
+
+    def JacobiPost(self, level, x_in_ext, b, x_out):
+        vi, vb, vo = _Vec(x_in_ext, self.ext_sizes[level], "x_in"), _Vec(b, self._size(level), "b"), _Vec(x_out, self._size(level), "x_out", True)
+        self._ck(self._lib.amgx_jacobi_post(self._h, level, vi.addr, vb.addr, vo.addr, self._flags(vi, vb, vo)))
+
+    def Prolong(self, level, fac, x_in, x_coarse, x_out):
+        nc = self.hierarchy.levels[level].P.n_cols * self.hierarchy.levels[level].P.bc
+        vi, vc, vo = _Vec(x_in, self._size(level), "x_in"), _Vec(x_coarse, nc, "x_coarse"), _Vec(x_out, self._size(level), "x_out", True)
+        self._ck(self._lib.amgx_prolong(self._h, level, float(fac), vi.addr, vc.addr, vo.addr, self._flags(vi, vc, vo)))
+
     # matrices / transfers ---------------------------------------------------------------------
     def MatVec(self, level, x, y):
         n = self._size(level)
-        vx, vy = _Vec(x, n, "x"), _Vec(y, n, "y", True)
+        vx, vy = _Vec(x, self.ext_sizes[level], "x"), _Vec(y, n, "y", True)
         self._ck(self._lib.amgx_matvec(self._h, level, vx.addr, vy.addr, self._flags(vx, vy)))
         return y
 

@@ -1,0 +1,53 @@
+"""scipy/numpy stage backend for ngsamg_amd.dist.DistributedAMG (TEST INFRASTRUCTURE: lets the rank-partitioned setup,
+halo tables and cycle logic run without a GPU, e.g. in world_size-2 gloo tests).  Vectors are CPU torch tensors."""
+import numpy as np
+import torch
+
+from oracle.pyoracle import Oracle
+
+
+def cpu_backend(omega=0.9):
+    tails = {}
+
+    class Ops:
+        def __init__(self, top, tail_hier, i):
+            self.top = top
+            self.A = [L.A.to_scipy() for L in top.levels]
+            self.P = [L.P.to_scipy() if L.P is not None else None for L in top.levels]
+            if id(tail_hier) not in tails:
+                tails[id(tail_hier)] = Oracle(tail_hier.levels, sm_type="jacobi", omega=omega)
+            self.tail = tails[id(tail_hier)]
+
+        def zeros(self, n):
+            return torch.zeros(int(n), dtype=torch.float64)
+
+        def index(self, idx):
+            return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64))
+
+        def gather(self, vec, idx, out):
+            torch.index_select(vec, 0, idx, out=out)
+
+        def jacobi_pre(self, l, bext, x, r):
+            L = self.top.levels[l]
+            n = L.A.n_rows
+            be = bext.numpy()
+            xe = omega * L.dinv * be                       # ghost entries of x from ghost dinv * ghost b
+            x.numpy()[:] = xe[:n]
+            r.numpy()[:] = be[:n] - self.A[l] @ xe
+
+        def restrict(self, l, r, bc):
+            bc.numpy()[:] = self.P[l].T @ r.numpy()
+
+        def prolong(self, l, x, xc, out):
+            out.numpy()[:] = x.numpy() + self.P[l] @ xc.numpy()[: self.P[l].shape[1]]
+
+        def jacobi_post(self, l, text, b, x):
+            L = self.top.levels[l]
+            n = L.A.n_rows
+            te = text.numpy()
+            x.numpy()[:] = te[:n] + omega * L.dinv[:n] * (b.numpy() - self.A[l] @ te)
+
+        def tail_apply(self, b, x):
+            x.numpy()[:] = self.tail.apply(b.numpy().copy())
+
+    return lambda top, tail_hier, i: Ops(top, tail_hier, i)

@@ -1,0 +1,93 @@
+"""Rank-partitioned V-cycle on CPU: loopback (virtual ranks in one process) and world_size-2 gloo processes.
+The distributed result must equal the serial oracle on the assembled global hierarchy."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from ngsamg_amd import dist as D
+from oracle.pyoracle import Oracle
+from tests.dist_cpu_backend import cpu_backend
+
+
+def _run_loopback(R, box, dim, dist_min_rows):
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, dim)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dist_min_rows, backend=cpu_backend(), max_coarse_size=10)
+    rng = np.random.default_rng(0)
+    bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
+    xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
+    amg.Mult(bs, xs)
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type="jacobi").apply(np.concatenate([b.numpy() for b in bs]))
+    got = np.concatenate([x.numpy() for x in xs])
+    return amg, got, ref
+
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (12, 12, 12), 3, 100), (4, (10, 10, 10), 3, 50), (8, (8, 8, 8), 3, 20),
+                                            (4, (24, 24), 2, 50), (2, (12, 12, 12), 3, 10 ** 9)])
+def test_loopback_matches_serial_oracle(R, box, dim, dmin):
+    amg, got, ref = _run_loopback(R, box, dim, dmin)
+    assert amg.k >= 1
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+def test_partitioned_matrix_is_the_global_one():
+    """owned rows of all ranks, renumbered globally, give a symmetric matrix with zero row sums"""
+    R, box = 4, (9, 9, 9)
+    pg = D.proc_grid(R, 3)
+    comm = D.LoopbackComm(R)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=50, backend=cpu_backend(), max_coarse_size=10)
+    A = amg.global_levels()[0].A.to_scipy()
+    assert abs(A - A.T).max() < 1e-13
+    assert np.abs(A.sum(axis=1)).max() < 1e-12
+    for l, lv in enumerate(amg.dist_levels):
+        assert sum(s.n for s in lv) > 0
+        for s in lv:
+            assert np.all(np.diff(s.ghost_owner) >= 0)          # ghosts sorted by owner
+            assert s.rank not in s.ghost_owner                  # no self ghosts
+
+
+def _worker(rank, world, port, box, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        comm = D.TorchComm()
+        pg = D.proc_grid(world, 3)
+        st = D.assemble_poisson_owned(rank, pg, box)
+        amg = D.DistributedAMG(comm, [st], dim=3, dist_min_rows=100, backend=cpu_backend(), max_coarse_size=10)
+        rng = np.random.default_rng(rank)
+        b = torch.from_numpy(rng.standard_normal(st.n) * st.free)
+        x = torch.zeros(st.n, dtype=torch.float64)
+        amg.Mult([b], [x])
+        glv = amg.global_levels()
+        allb = [None] * world
+        allx = [None] * world
+        dist.all_gather_object(allb, b.numpy())
+        dist.all_gather_object(allx, x.numpy())
+        if rank == 0:
+            ref = Oracle(glv, sm_type="jacobi").apply(np.concatenate(allb))
+            got = np.concatenate(allx)
+            q.put(float(np.linalg.norm(got - ref) / np.linalg.norm(ref)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_processes_match_serial_oracle():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, (12, 12, 12), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    for p in procs:
+        assert p.exitcode == 0
+    assert q.get(timeout=10) < 1e-12
