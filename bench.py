@@ -8,9 +8,9 @@ Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg 2"): 3D P1 Poisson on the 
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): round 1 runs one independent cfg-2 problem per
-rank (weak scaling, no halo exchange yet -- the rank-partitioned fine levels of SURVEY.md 8e are not built
-yet; this is stated in the JSON line's config).
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- the global grid is a box of
+N sub-cubes of 215^3 vertices, one per rank (ngsamg_amd/dist.py): rank-partitioned fine levels with halo exchange
+over torch.distributed (backend nccl = RCCL over xGMI), coarse hierarchy replicated after one all-gather.
 
 Prints ONE JSON line on rank 0 (contract of the driver) with the extra objects "roofline" (dominant kernel:
 level-0 residual SpMV r = b - A x, HIP-event timed) and "cpu_baseline" (the CPU oracle = restatement of the
@@ -36,6 +36,82 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def run_distributed(args, torch, dist, world, rank, device, nv):
+    """N > 1: rank-partitioned V-cycle, weak scaling (one nv^3 box per rank)."""
+    from ngsamg_amd import dist as D
+    from ngsamg_amd.device import matrix_bytes, vcycle_bytes
+    t0 = time.time()
+    comm = D.TorchComm()
+    pg = D.proc_grid(world, 3)
+    st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
+    t1 = time.time()
+    amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=20000, device=device, max_coarse_size=50, max_levels=10)
+    t2 = time.time()
+    if rank == 0:
+        log(f"[rank 0] owned-row assembly {t1 - t0:.1f}s, distributed setup + upload {t2 - t1:.1f}s; "
+            f"distributed levels {amg.k}, sizes {[lv[0].n for lv in amg.dist_levels]}, ghosts {[lv[0].ghost_owner.size for lv in amg.dist_levels]}, "
+            f"replicated tail: {amg.tail_hier.n_levels} levels from n = {amg.tail_hier.levels[0].n}")
+    # algorithmic bytes per rank and cycle: distributed levels (same per-level formula as the serial model) + replicated tail
+    per_rank = 0
+    for l in range(amg.k):
+        L = amg.tops[0].levels[l]
+        n = L.A.n_rows
+        nc = amg.tops[0].levels[l + 1].A.n_rows
+        per_rank += 2 * matrix_bytes(L.A) + matrix_bytes(L.P) + matrix_bytes(L.PT) + 16 * n + 15 * 8 * n + 2 * 8 * nc
+    per_rank += vcycle_bytes(amg.tail_hier)[0]
+    rng = np.random.default_rng(rank)
+    b = torch.from_numpy(rng.standard_normal(st.n) * st.free).to(f"cuda:{device}")
+    x = torch.empty_like(b)
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            amg.Mult([b], [x])
+        stream.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            amg.Mult([b], [x])
+        torch.cuda.synchronize()
+        dist.barrier()
+        te = time.perf_counter()
+    rdev = f"cuda:{device}" if dist.get_backend() == "nccl" else "cpu"
+    tt = torch.tensor([te - ts], dtype=torch.float64, device=rdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    xn = torch.tensor([float(torch.dot(x, x).item())], dtype=torch.float64, device=rdev)
+    dist.all_reduce(xn)
+    ms_per_step = 1e3 * elapsed / args.steps
+    # one "apply" = one V-cycle on ONE rank's 10M-DOF share; the job does `world` of them per step
+    applies_per_s = world * args.steps / elapsed
+    lv0 = amg.tops[0].levels[0]
+    spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.A.n_rows
+    k_ms = amg.ops[0].top.time_op(0, 0, reps=50)
+    achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
+    if rank == 0:
+        out = {
+            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF per GPU, Jacobi V(1,1))",
+            "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg4-style weak scaling of cfg2: global grid {tuple(pg[d] * nv for d in range(3))} = "
+                                   f"{world} x {nv}^3 vertices, hashed jitter (seed 1), Dirichlet right|top, jacobi omega=0.9, V(1,1)",
+                       "parallelism": f"{world} ranks, box partition {pg}, {amg.k} rank-partitioned levels with halo exchange "
+                                      f"(torch.distributed {dist.get_backend()}), coarse hierarchy replicated from n = {amg.tail_hier.levels[0].n}; "
+                                      f"one apply = one V-cycle over one rank's share, value = ranks x steps / time",
+                       "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(world * st.n)},
+            "x_norm": float(xn.item()) ** 0.5,
+            "roofline": {"bound": "hbm", "kernel": "sell_spmv_kernel<EP_RES> (level 0 owned rows, rank 0)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes": int(spmv_bytes), "cycle_algorithmic_bytes_per_rank": int(per_rank),
+                         "cycle_achieved_GBs_per_gpu": round(per_rank / (ms_per_step * 1e-3) / 1e9, 1),
+                         "cycle_frac": round(per_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,24 +125,34 @@ def main():
     ap.add_argument("--ops", action="store_true", help="print HIP-event timings of the individual kernels per level")
     args = ap.parse_args()
 
-    import torch
-    import __graft_entry__ as ge
-    ge.build_host()
-    ge.build_hip()
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # the host setup is OpenMP-parallel: share the box's cores between the ranks
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
+    import torch
+    import __graft_entry__ as ge
+    if local_rank == 0:
+        ge.build_host()
+        ge.build_hip()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # NGSAMG_DIST_BACKEND=gloo is a rehearsal mode (several ranks may share one GPU, halos staged through the host)
+        backend = os.environ.get("NGSAMG_DIST_BACKEND", "nccl")
+        ndev = max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend=backend)
+        dist.barrier()           # the libraries are (re)built by local rank 0 only
     if args.gpus != world and rank == 0:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the apply path has no CPU fallback")
-    device = local_rank if world > 1 else 0
+    device = (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0
     torch.cuda.set_device(device)
 
     from ngsamg_amd import fem
@@ -74,9 +160,13 @@ def main():
     from ngsamg_amd.hierarchy import Hierarchy
     from ngsamg_amd.device import DeviceAMGMatrix, vcycle_bytes, matrix_bytes
 
+    nv = args.nv
+    if world > 1:
+        run_distributed(args, torch, dist, world, rank, device, nv)
+        return
+
     # ---- host setup (cold path, not timed) -------------------------------------------------------------
     t0 = time.time()
-    nv = args.nv
     prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
     A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
     t1 = time.time()

@@ -126,6 +126,19 @@ class TorchComm:
 
     def halo(self, bufs_send, bufs_recv):
         dist = self.dist
+        some = next(iter(bufs_send[0].values()), None)
+        if some is not None and some.is_cuda and dist.get_backend(self.device_group) == "gloo":
+            # debug transport (several ranks sharing one GPU, no RCCL): stage through pinned host copies
+            import torch
+            hs = {q: t.cpu() for q, t in bufs_send[0].items()}
+            hr = {q: torch.empty(t.shape, dtype=t.dtype) for q, t in bufs_recv[0].items()}
+            reqs = [dist.isend(t, q, group=self.device_group) for q, t in hs.items()]
+            reqs += [dist.irecv(t, q, group=self.device_group) for q, t in hr.items()]
+            for r in reqs:
+                r.wait()
+            for q, t in bufs_recv[0].items():
+                t.copy_(hr[q])
+            return
         ops = []
         for q, t in bufs_send[0].items():
             ops.append(dist.P2POp(dist.isend, t, q, group=self.device_group))
@@ -140,6 +153,11 @@ class TorchComm:
         dist = self.dist
         m = max(counts)
         p = parts[0]
+        if p.is_cuda and dist.get_backend(self.device_group) == "gloo":
+            lst = [None] * self.size
+            dist.all_gather_object(lst, p[:counts[self.rank]].cpu().numpy(), group=self.device_group)
+            outs[0].copy_(torch.from_numpy(np.concatenate(lst)))
+            return
         if p.numel() != m:
             pad = torch.zeros(m, dtype=p.dtype, device=p.device)
             pad[:p.numel()].copy_(p)
