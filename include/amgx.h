@@ -108,6 +108,11 @@ int amgx_smooth_v_from_level(amgx_handle h, int level, double* x, const double* 
  *   amgx_prolong    : x_out = x_in + fac * P x_coarse   (ProlMap::AddC2F, dof_map.cpp:697-709, out of place)
  *   amgx_jacobi_post: x_out = x_in + omega*Dinv*(b - A x_in)   x_in: n_cols entries (ghosts valid), x_out != x_in */
 int amgx_jacobi_pre(amgx_handle h, int level, const double* b, double* x, double* r, int flags);
+/* r = b - A_level x   (BaseSmoother::CalcResiduum, base_smoother.hpp:132-142); x: n_cols entries, b, r: n_rows.
+ * With amgx_smooth (whose x may carry ghost entries too: they are read, never written) this gives the stages of the
+ * hybrid Gauss-Seidel smoother of rank-partitioned levels: local sweep on the owned rows with the off-rank values
+ * frozen (reference HybridGSSmoother, gssmoother.cpp:709-861, with dinv = inverse of the modified diagonal). */
+int amgx_residual(amgx_handle h, int level, const double* x, const double* b, double* r, int flags);
 int amgx_jacobi_post(amgx_handle h, int level, const double* x_in, const double* b, double* x_out, int flags);
 int amgx_prolong(amgx_handle h, int level, double fac, const double* x_in, const double* x_coarse, double* x_out, int flags);
 

@@ -196,7 +196,7 @@ AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
 
 AMGX_SYMBOLS = [
     "amgx_last_error", "amgx_create", "amgx_destroy", "amgx_set_stream", "amgx_synchronize", "amgx_apply",
-    "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_jacobi_pre", "amgx_jacobi_post",
+    "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_jacobi_pre", "amgx_jacobi_post", "amgx_residual",
     "amgx_prolong", "amgx_matvec", "amgx_transfer_f2c",
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op",
@@ -228,6 +228,7 @@ def hip():
     lib.amgx_smooth.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.amgx_smooth_v_from_level.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.amgx_jacobi_pre.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    lib.amgx_residual.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.amgx_jacobi_post.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.amgx_prolong.argtypes = [vp, C.c_int, C.c_double, dp, dp, dp, C.c_int]
     lib.amgx_matvec.argtypes = [vp, C.c_int, dp, dp, C.c_int]

@@ -729,6 +729,7 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     if (ci < 0) continue;
     for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
       const int64_t j = d.A.col[k];
+      if (j >= n) continue;          // ghost column of a rank-partitioned level: frozen during the sweep (hybrid GS)
       if (j != i && d.color[j] == ci) throw Err("invalid colouring: two coupled rows share a colour");
     }
   }
@@ -954,7 +955,7 @@ int amgx_smooth(amgx_handle hh, int level, int dir, double* x, const double* b, 
     if (!x || !b || !res) throw amgx::Err("amgx_smooth: null vector");
     const int64_t n = L.len();
     Staged st(h, flags);
-    double* dx = st.inout(0, x, n, true);
+    double* dx = st.inout(0, x, L.ext_len(), true);        // ghost entries (if any) are read, never written
     const double* db = st.in(1, b, n);
     double* dr = st.inout(2, res, n, true);
     h.level_smooth(L, dir, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
@@ -976,6 +977,21 @@ int amgx_smooth_v_from_level(amgx_handle hh, int level, double* x, const double*
     h.smooth_v_from_level(level, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
     st.out(0, x, n);
     st.out(2, res, n);
+    st.finish();
+  });
+}
+
+int amgx_residual(amgx_handle hh, int level, const double* x, const double* b, double* r, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_residual: level out of range");
+    if (!x || !b || !r || x == r) throw amgx::Err("amgx_residual: bad vectors");
+    amgx::DevLevel& L = h.lev[level];
+    Staged st(h, flags);
+    const double* dx = st.in(0, x, L.ext_len());
+    const double* db = st.in(1, b, L.len());
+    double* dr = st.inout(2, r, L.len(), false);
+    h.residual(L.A, dx, db, dr);
+    st.out(2, r, L.len());
     st.finish();
   });
 }

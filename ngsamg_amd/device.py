@@ -159,7 +159,7 @@ class DeviceAMGMatrix:
     # smoothers ---------------------------------------------------------------------------------
     def Smooth(self, level, x, b, res, res_updated=False, update_res=False, x_zero=False, back=False):
         n = self._size(level)
-        vx, vb, vr = _Vec(x, n, "x", True), _Vec(b, n, "b"), _Vec(res, n, "res", True)
+        vx, vb, vr = _Vec(x, self.ext_sizes[level], "x", True), _Vec(b, n, "b"), _Vec(res, n, "res", True)
         self._ck(self._lib.amgx_smooth(self._h, level, 1 if back else 0, vx.addr, vb.addr, vr.addr,
                                        int(res_updated), int(update_res), int(x_zero), self._flags(vx, vb, vr)))
 
@@ -177,6 +177,10 @@ class DeviceAMGMatrix:
     def JacobiPost(self, level, x_in_ext, b, x_out):
         vi, vb, vo = _Vec(x_in_ext, self.ext_sizes[level], "x_in"), _Vec(b, self._size(level), "b"), _Vec(x_out, self._size(level), "x_out", True)
         self._ck(self._lib.amgx_jacobi_post(self._h, level, vi.addr, vb.addr, vo.addr, self._flags(vi, vb, vo)))
+
+    def Residual(self, level, x_ext, b, r):
+        vx, vb, vr = _Vec(x_ext, self.ext_sizes[level], "x"), _Vec(b, self._size(level), "b"), _Vec(r, self._size(level), "r", True)
+        self._ck(self._lib.amgx_residual(self._h, level, vx.addr, vb.addr, vr.addr, self._flags(vx, vb, vr)))
 
     def Prolong(self, level, fac, x_in, x_coarse, x_out):
         nc = self.hierarchy.levels[level].P.n_cols * self.hierarchy.levels[level].P.bc

@@ -456,17 +456,44 @@ def _dinv_ext(comm, states, omega_unused=None):
         s.dinv_ext = np.concatenate([di, g])
 
 
+def _hybrid_gs_data(comm, states):
+    """per level: inverse of the modified diagonal md = max(1, 0.51 (1 + ad)) d with ad_k = sum over the off-rank
+    couplings |g_kj| / sqrt(d_k d_j)  (reference hybrid_smoother_utils.hpp:35-142), and a colouring of the
+    rank-local (owned x owned) graph for the multicolour sweep"""
+    lib = _lib.host()
+    diags = [np.asarray(s.A[:, :s.n].diagonal()) for s in states]
+    gdiag = _exchange_ghost_values(comm, states, diags)
+    for s, d, gd in zip(states, diags, gdiag):
+        G = sp.csr_matrix(s.A[:, s.n:])
+        free = s.free.astype(bool)
+        sd = np.sqrt(np.where(d > 0, d, 1.0))
+        sg = np.sqrt(np.where(gd > 0, gd, 1.0))
+        ad = np.asarray(abs(G).multiply(1.0 / sd[:, None]).multiply(1.0 / sg[None, :]).sum(axis=1)).ravel() if G.shape[1] else np.zeros(s.n)
+        md = np.maximum(1.0, 0.51 * (1.0 + ad)) * d
+        dinv = np.where(free & (md != 0), 1.0 / np.where(md != 0, md, 1.0), 0.0)
+        s.dinv_gs_ext = np.concatenate([dinv, np.zeros(s.ghost_owner.size)])
+        Aoo = _mat(sp.csr_matrix(s.A[:, :s.n]))
+        color = np.zeros(s.n, dtype=np.int32)
+        nc = C.c_int32()
+        dsc = Aoo.desc()
+        fr = np.ascontiguousarray(s.free, dtype=np.uint8)
+        _lib.hcheck(lib.amgh_coloring(C.byref(dsc), _lib.ptr(fr, C.c_uint8), _lib.ptr(color, C.c_int32), C.byref(nc)))
+        s.color, s.n_colors = color, int(nc.value)
+
+
 class _TopHierarchy:
     """duck-typed Hierarchy holding the rank-partitioned levels of one rank (for DeviceAMGMatrix)"""
 
-    def __init__(self, states):
+    def __init__(self, states, gs=False):
         self.levels = []
         for i, s in enumerate(states):
             last = i + 1 == len(states)
-            color = np.full(s.n, -1, dtype=np.int32)
+            use_gs = gs and not last
+            color = s.color if use_gs else np.full(s.n, -1, dtype=np.int32)
+            dinv = s.dinv_gs_ext if use_gs else s.dinv_ext
             self.levels.append(Level(A=_mat(s.A), P=None if last else _mat(s.P), PT=None if last else _mat(s.PT),
-                                     free=s.free, dinv=np.ascontiguousarray(s.dinv_ext), coords=None, color=color,
-                                     n_colors=0, agg=None))
+                                     free=s.free, dinv=np.ascontiguousarray(dinv), coords=None, color=color,
+                                     n_colors=s.n_colors if use_gs else 0, agg=None))
         self.coarse_n = 0
         self.coarse_inv = np.empty(0)
         self.n_levels = len(self.levels)
@@ -481,8 +508,10 @@ class DistributedAMG:
     """
 
     def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=20000, max_dist_levels=3, device=0,
-                 backend=None, **opts):
-        self.comm, self.dim, self.omega = comm, dim, omega
+                 backend=None, sm_type="jacobi", **opts):
+        if sm_type not in ("jacobi", "gs"):
+            raise NgsAMGError("DistributedAMG: sm_type must be jacobi or gs")
+        self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
         _send_lists(comm, states0)
         levels = [states0]
         while len(levels) <= max_dist_levels:
@@ -495,6 +524,9 @@ class DistributedAMG:
             levels.append(coarsen_distributed_level(comm, levels[0], dim, True, opts))
         for lv in levels:
             _dinv_ext(comm, lv)
+        if sm_type == "gs":
+            for lv in levels[:-1]:
+                _hybrid_gs_data(comm, lv)
         self.dist_levels = levels
         self.k = len(levels) - 1                      # levels 0..k-1 are smoothed in distributed form, level k is gathered
         # ---- gather level k and build the replicated tail ---------------------------------------------
@@ -519,9 +551,9 @@ class DistributedAMG:
         topts["first_aaf"] = opts.get("aaf", 2.0 ** -dim)
         self.tail_hier = Hierarchy(_mat(Ag), None, None, dim=dim, energy=0, **topts)
         # ---- per-rank execution objects --------------------------------------------------------------------
-        self.tops = [_TopHierarchy([lv[i] for lv in levels]) for i in range(len(states0))]
+        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type == "gs")) for i in range(len(states0))]
         if backend is None:
-            backend = _device_backend(device, omega)
+            backend = _device_backend(device, omega, sm_type)
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
         self._alloc()
 
@@ -537,6 +569,8 @@ class DistributedAMG:
                 b["text"].append(ops.zeros(next_))
                 b["x"].append(ops.zeros(s.n))
                 b["r"].append(ops.zeros(s.n))
+                b.setdefault("xext", []).append(ops.zeros(next_) if self.sm_type == "gs" else None)
+                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type == "gs" else None)
                 b["send"].append({q: ops.zeros(idx.size) for q, idx in s.send.items()})
                 b["sidx"].append({q: ops.index(idx) for q, idx in s.send.items()})
             sk = self.dist_levels[self.k][i]
@@ -559,6 +593,8 @@ class DistributedAMG:
 
     def Mult(self, bs, xs):
         """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind)"""
+        if self.sm_type == "gs":
+            return self._mult_gs(bs, xs)
         k = self.k
         for l in range(k):
             for i, ops in enumerate(self.ops):
@@ -589,6 +625,44 @@ class DistributedAMG:
                 s, b = self.dist_levels[l][i], self.buf[i]
                 xl = xs[i] if l == 0 else b["x"][l]
                 ops.jacobi_post(l, b["text"][l], b["bext"][l][:s.n], xl)
+        return xs
+
+    def _mult_gs(self, bs, xs):
+        """V(1,1) with the hybrid Gauss-Seidel smoother on the rank-partitioned levels:
+        pre  : x = 0; forward sweep on the owned rows (all off-rank values are 0); halo(x); r = b - A x; restrict
+        post : x += P x_c; halo(x); backward sweep with the off-rank values frozen (reference stages: gssmoother.cpp:709-861)"""
+        k = self.k
+        for l in range(k):
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                bl = bs[i] if l == 0 else b["b"][l]
+                b["xext"][l].zero_()
+                ops.gs_sweep(l, 0, b["xext"][l], bl, b["r"][l])
+            self._halo(l, "xext")
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                bl = bs[i] if l == 0 else b["b"][l]
+                ops.residual(l, b["xext"][l], bl, b["r"][l])
+                nxt = b["b"][l + 1] if l + 1 < k else b["bk"][:b["nk"]]
+                ops.restrict(l, b["r"][l], nxt)
+        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], self.counts)
+        for i, ops in enumerate(self.ops):
+            b = self.buf[i]
+            ops.tail_apply(b["bglob"], b["xglob"])
+        for l in range(k - 1, -1, -1):
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                r = s.rank
+                xc = b["xext"][l + 1][:self.dist_levels[l + 1][i].n] if l + 1 < k else b["xglob"][int(self.offs[r]):int(self.offs[r]) + b["nk"]]
+                xo = b["xext"][l][:s.n]
+                ops.prolong(l, xo, xc, xo)
+            self._halo(l, "xext")
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                bl = bs[i] if l == 0 else b["b"][l]
+                ops.gs_sweep(l, 1, b["xext"][l], bl, b["r"][l])
+                if l == 0:
+                    xs[i].copy_(b["xext"][0][:s.n])
         return xs
 
     # ---- the same hierarchy as ONE global serial hierarchy (for the oracle / tests) -----------------------------
@@ -626,12 +700,31 @@ class DistributedAMG:
             PT = sp.csr_matrix(P.T)
             PT.sort_indices()
             free = np.concatenate([t[1] for t in gf]).astype(np.uint8)
-            out.append(Level(A=_mat(A), P=_mat(P), PT=_mat(PT), free=free, dinv=np.concatenate([t[1] for t in gd]),
-                             coords=None, color=np.full(n, -1, dtype=np.int32), n_colors=0, agg=None))
+            L = Level(A=_mat(A), P=_mat(P), PT=_mat(PT), free=free, dinv=np.concatenate([t[1] for t in gd]),
+                      coords=None, color=np.full(n, -1, dtype=np.int32), n_colors=0, agg=None)
+            if self.sm_type == "gs":
+                # hybrid GS as ONE serial smoother: every rank is a block, its rows are visited in its colour-major order
+                pg = [(s.rank, s.dinv_gs_ext[:s.n], s.color) for s in lv]
+                gg = sorted(comm.allgather(pg)[0], key=lambda t: t[0])
+                L.dinv = np.concatenate([t[1] for t in gg])
+                order, block = [], []
+                for t in gg:
+                    rows = np.nonzero(t[2] >= 0)[0]
+                    order.append(off[t[0]] + rows[np.argsort(t[2][rows], kind="stable")])
+                    block.append(np.full(t[2].size, t[0], dtype=np.int32))
+                L.gs_order = np.concatenate(order).astype(np.int32)
+                L.gs_block = np.concatenate(block)
+            out.append(L)
         return out + list(self.tail_hier.levels)
 
+    def oracle_sm_types(self):
+        """per-level smoother names for oracle.pyoracle.Oracle over global_levels()"""
+        if self.sm_type == "jacobi":
+            return ["jacobi"] * (self.k + self.tail_hier.n_levels)
+        return ["gs_order"] * self.k + ["gs_mc"] * self.tail_hier.n_levels
 
-def _device_backend(device, omega):
+
+def _device_backend(device, omega, sm_type="jacobi"):
     """execution on the GPU through the C ABI (include/amgx.h); vectors are torch CUDA tensors"""
     import torch
     from .device import DeviceAMGMatrix
@@ -640,9 +733,10 @@ def _device_backend(device, omega):
 
     class Ops:
         def __init__(self, top, tail_hier, i):
-            self.top = DeviceAMGMatrix(top, sm_type="jacobi", omega=omega, clev="none", device=device, use_graph=False)
+            types = [sm_type] * (top.n_levels - 1) + ["jacobi"]
+            self.top = DeviceAMGMatrix(top, sm_type=types, omega=omega, clev="none", device=device, use_graph=False)
             if id(tail_hier) not in tails:
-                tails[id(tail_hier)] = DeviceAMGMatrix(tail_hier, sm_type="jacobi", omega=omega, device=device)
+                tails[id(tail_hier)] = DeviceAMGMatrix(tail_hier, sm_type=sm_type, omega=omega, device=device)
             self.tail = tails[id(tail_hier)]
             self.dev = torch.device("cuda", device)
 
@@ -669,5 +763,11 @@ def _device_backend(device, omega):
 
         def tail_apply(self, b, x):
             self.tail.Mult(b, x)
+
+        def gs_sweep(self, l, back, xext, b, scratch):
+            self.top.Smooth(l, xext, b, scratch, False, False, False, back=bool(back))
+
+        def residual(self, l, xext, b, r):
+            self.top.Residual(l, xext, b, r)
 
     return lambda top, tail_hier, i: Ops(top, tail_hier, i)

@@ -22,7 +22,10 @@ struct orc_handle {
   int64_t* crs_idx;          /* free scalar dof indices */
   double* crs_L;             /* nf x nf lower factor */
   double* crs_tmp;
+  double** x_old;            /* per level: snapshot of x for hybrid GS */
 };
+
+static struct orc_handle* g_cur = NULL;   /* set by the public entry points (the oracle is single-threaded at this level) */
 
 static char g_err[512];
 static int g_threads = 1;
@@ -89,14 +92,16 @@ static void jacobi_smooth(const orc_level* L, double* x, const double* b, double
 
 static inline int is_free(const orc_level* L, int64_t k) { return !L->free || L->free[k]; }
 
-/* RHS form, gssmoother.cpp:209-212:  x_k += dinv_k (b_k - A_k: x) */
-static inline void gs_row_rhs(const orc_level* L, int64_t k, double* x, const double* b) {
+/* RHS form, gssmoother.cpp:209-212:  x_k += dinv_k (b_k - A_k: x)
+ * xo != NULL: hybrid form -- entries whose column belongs to another block read the sweep-start values xo */
+static inline void gs_row_rhs(const orc_level* L, int64_t k, double* x, const double* b, const double* xo) {
   const orc_matrix* A = &L->A;
   const int bs = A->br;
   double r[MAXBS] = {0, 0, 0, 0, 0, 0};
   for (int64_t p = A->rowptr[k]; p < A->rowptr[k + 1]; p++) {
     const double* a = A->val + p * bs * bs;
-    const double* xv = x + (int64_t)A->col[p] * bs;
+    const int64_t j = A->col[p];
+    const double* xv = ((xo && L->gs_block[j] != L->gs_block[k]) ? xo : x) + j * bs;
     for (int i = 0; i < bs; i++)
       for (int j = 0; j < bs; j++) r[i] += a[i * bs + j] * xv[j];
   }
@@ -137,26 +142,40 @@ static inline void gs_row_res(const orc_level* L, int64_t k, double* x, double* 
  * the GPU multicolour kernel does); backwards = reversed */
 static void gs_sweep(const orc_level* L, double* x, const double* b, double* res, int res_form, int backwards) {
   const int64_t n = L->A.n_rows;
+  const double* xo = NULL;
+  if (L->gs_block) {
+    /* hybrid: freeze the off-block values; only the gather (RHS) form is restated, the reference's RES variant gives
+     * the same x and the same final residual (hybrid_base_smoother.cpp:296-405) */
+    double* snap = g_cur->x_old[(int)(L - g_cur->lev)];
+    memcpy(snap, x, sizeof(double) * L->A.n_cols * L->A.bc);
+    xo = snap;
+    res_form = 0;
+  }
   if (L->gs_order) {
     const int64_t m = L->gs_order_len;
     for (int64_t q = 0; q < m; q++) {
       int64_t k = L->gs_order[backwards ? m - 1 - q : q];
       if (!is_free(L, k)) continue;
-      if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b);
+      if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b, xo);
     }
     return;
   }
   /* free range [first_free, next_free), gssmoother.cpp:111-139 -- equivalent to testing every row */
   if (!backwards) {
-    for (int64_t k = 0; k < n; k++) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b); }
+    for (int64_t k = 0; k < n; k++) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b, xo); }
   } else {
-    for (int64_t k = n - 1; k >= 0; k--) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b); }
+    for (int64_t k = n - 1; k >= 0; k--) if (is_free(L, k)) { if (res_form) gs_row_res(L, k, x, res); else gs_row_rhs(L, k, x, b, xo); }
   }
 }
 
 static void gs_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
                       int res_updated, int update_res, int x_zero) {
   /* GSS3::Smooth / SmoothBack, gssmoother.cpp:350-398 */
+  if (L->gs_block) {
+    gs_sweep(L, x, b, res, 0, dir);
+    if (update_res) spmv(&L->A, x, res, 1, 0.0, b);
+    return;
+  }
   if (res_updated) {
     if (update_res) gs_sweep(L, x, b, res, 1, dir);
     else gs_sweep(L, x, b, res, 0, dir);
@@ -355,16 +374,19 @@ int orc_create(const orc_desc* d, orc_handle** out) {
   h->x_level = (double**)calloc(d->n_levels, sizeof(double*));
   h->rhs_level = (double**)calloc(d->n_levels, sizeof(double*));
   h->res_level = (double**)calloc(d->n_levels, sizeof(double*));
+  h->x_old = (double**)calloc(d->n_levels, sizeof(double*));
   for (int l = 0; l < d->n_levels; l++) {
     const orc_level* L = &h->lev[l];
-    if (L->A.br != L->A.bc || L->A.br > MAXBS || L->A.n_rows != L->A.n_cols) { orc_destroy(h); return fail("orc_create: bad level matrix"); }
+    /* n_cols > n_rows: trailing ghost columns of a rank-local matrix (stage-wise use only) */
+    if (L->A.br != L->A.bc || L->A.br > MAXBS || L->A.n_rows > L->A.n_cols) { orc_destroy(h); return fail("orc_create: bad level matrix"); }
     if (l + 1 < d->n_levels) {
       const orc_level* Lc = &h->lev[l + 1];
       if (L->P.n_rows != L->A.n_rows || L->P.n_cols != Lc->A.n_rows || L->P.br != L->A.br || L->P.bc != Lc->A.br ||
           L->PT.n_rows != L->P.n_cols || L->PT.n_cols != L->P.n_rows || L->PT.br != L->P.bc || L->PT.bc != L->P.br)
         { orc_destroy(h); return fail("orc_create: P / PT shapes do not match the level matrices"); }
     }
-    const int64_t n = vlen(L);
+    const int64_t n = L->A.n_cols * L->A.bc;
+    h->x_old[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
     h->x_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
     h->rhs_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
     h->res_level[l] = (double*)calloc(n > 0 ? n : 1, sizeof(double));
@@ -422,7 +444,9 @@ void orc_destroy(orc_handle* h) {
     if (h->x_level) free(h->x_level[l]);
     if (h->rhs_level) free(h->rhs_level[l]);
     if (h->res_level) free(h->res_level[l]);
+    if (h->x_old) free(h->x_old[l]);
   }
+  free(h->x_old);
   free(h->x_level); free(h->rhs_level); free(h->res_level);
   free(h->lev); free(h->crs_idx); free(h->crs_L); free(h->crs_tmp);
   free(h);
@@ -430,6 +454,7 @@ void orc_destroy(orc_handle* h) {
 
 int orc_apply(orc_handle* h, const double* b, double* x) {
   if (!h) return fail("orc_apply: null handle");
+  g_cur = h;
   do_cycle(h, x, b);
   return 0;
 }
@@ -437,6 +462,7 @@ int orc_apply(orc_handle* h, const double* b, double* x) {
 int orc_apply_add(orc_handle* h, double s, const double* b, double* x) {
   /* AMGMatrix::MultAdd, amg_matrix.cpp:385-389 */
   if (!h) return fail("orc_apply_add: null handle");
+  g_cur = h;
   do_cycle(h, h->x_level[0], b);
   const int64_t n = vlen(&h->lev[0]);
   for (int64_t i = 0; i < n; i++) x[i] += s * h->x_level[0][i];
@@ -446,6 +472,7 @@ int orc_apply_add(orc_handle* h, double s, const double* b, double* x) {
 int orc_smooth_v_from_level(orc_handle* h, int level, double* x, const double* b, double* res,
                             int res_updated, int update_res, int x_zero) {
   if (!h || level < 0 || level + 1 >= h->n_levels) return fail("orc_smooth_v_from_level: bad level");
+  g_cur = h;
   smooth_v_from_level(h, level, x, b, res, res_updated, update_res, x_zero);
   return 0;
 }
@@ -453,6 +480,7 @@ int orc_smooth_v_from_level(orc_handle* h, int level, double* x, const double* b
 int orc_smooth(orc_handle* h, int level, int dir, double* x, const double* b, double* res,
                int res_updated, int update_res, int x_zero) {
   if (!h || level < 0 || level >= h->n_levels) return fail("orc_smooth: bad level");
+  g_cur = h;
   level_smooth(&h->lev[level], dir, x, b, res, res_updated, update_res, x_zero);
   return 0;
 }
@@ -494,6 +522,7 @@ int orc_pcg(orc_handle* h, const orc_matrix* Ain, const double* b, double* x, do
    * (tests/h1/amg_utils.py:337-363): err = sqrt(|<C r, r>|), stop at err <= tol * err_0 */
   const orc_matrix* A = Ain ? Ain : (h ? &h->lev[0].A : NULL);
   if (!A) return fail("orc_pcg: no matrix");
+  g_cur = h;
   const int64_t n = A->n_rows * A->br;
   double* d = (double*)malloc(sizeof(double) * n);
   double* w = (double*)malloc(sizeof(double) * n);

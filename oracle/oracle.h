@@ -48,6 +48,11 @@ typedef struct orc_level {
   int32_t sm_symm;            /* ProxySmoother symm                                                */
   const int32_t* gs_order;    /* NULL = natural row order (reference-exact); else forward visiting */
   int64_t gs_order_len;       /*   order of the rows (e.g. colour-major), backward = reversed      */
+  const int32_t* gs_block;    /* NULL, or the owner ("rank") of every row: HYBRID Gauss-Seidel -- couplings to rows of  */
+                              /*   another block use the values from the start of the sweep (reference              */
+                              /*   HybridGSSmoother: local GS on M, G x_old moved to the right-hand side,           */
+                              /*   hybrid_base_smoother.cpp:296-495, gssmoother.cpp:709-861); dinv then holds the   */
+                              /*   inverse of the modified diagonal (hybrid_smoother_utils.hpp:111-142)             */
 } orc_level;
 
 typedef struct orc_desc {

@@ -30,7 +30,7 @@ class orc_matrix(C.Structure):
 class orc_level(C.Structure):
     _fields_ = [("A", orc_matrix), ("P", orc_matrix), ("PT", orc_matrix), ("free", c_u8p), ("dinv", c_f64p),
                 ("sm_type", C.c_int32), ("omega", C.c_double), ("sm_steps", C.c_int32), ("sm_symm", C.c_int32),
-                ("gs_order", c_i32p), ("gs_order_len", C.c_int64)]
+                ("gs_order", c_i32p), ("gs_order_len", C.c_int64), ("gs_block", c_i32p)]
 
 
 class orc_desc(C.Structure):
@@ -123,6 +123,15 @@ class Oracle:
                 order = color_order(lv.color)
                 self._keep.append(order)
                 o.gs_order, o.gs_order_len = _p(order, C.c_int32), order.shape[0]
+            if t == "gs_order":          # explicit visiting order (+ optional hybrid blocks) attached to the level
+                order = np.ascontiguousarray(lv.gs_order, dtype=np.int32)
+                self._keep.append(order)
+                o.gs_order, o.gs_order_len = _p(order, C.c_int32), order.shape[0]
+                blk = getattr(lv, "gs_block", None)
+                if blk is not None:
+                    blk = np.ascontiguousarray(blk, dtype=np.int32)
+                    self._keep.append(blk)
+                    o.gs_block = _p(blk, C.c_int32)
         d = orc_desc()
         d.n_levels = n
         d.levels = arr
@@ -132,6 +141,7 @@ class Oracle:
         self._h = C.c_void_p()
         self.levels = levels
         self.sizes = [lv.A.n_rows * lv.A.br for lv in levels]
+        self.ext_sizes = [lv.A.n_cols * lv.A.bc for lv in levels]
         L.orc_set_threads(int(threads))
         if L.orc_create(C.byref(d), C.byref(self._h)) != 0:
             raise RuntimeError(L.orc_last_error().decode())

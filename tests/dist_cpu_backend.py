@@ -6,7 +6,7 @@ import torch
 from oracle.pyoracle import Oracle
 
 
-def cpu_backend(omega=0.9):
+def cpu_backend(omega=0.9, sm_type="jacobi"):
     tails = {}
 
     class Ops:
@@ -15,7 +15,10 @@ def cpu_backend(omega=0.9):
             self.A = [L.A.to_scipy() for L in top.levels]
             self.P = [L.P.to_scipy() if L.P is not None else None for L in top.levels]
             if id(tail_hier) not in tails:
-                tails[id(tail_hier)] = Oracle(tail_hier.levels, sm_type="jacobi", omega=omega)
+                tails[id(tail_hier)] = Oracle(tail_hier.levels, sm_type="jacobi" if sm_type == "jacobi" else "gs_mc", omega=omega)
+            # rank-local smoother objects: one single-level oracle per distributed level (rectangular A, no coarse solve)
+            self.loc = [Oracle([L], sm_type="gs_mc", clev="none") if sm_type == "gs" and L.P is not None else None
+                        for L in top.levels]
             self.tail = tails[id(tail_hier)]
 
         def zeros(self, n):
@@ -49,5 +52,11 @@ def cpu_backend(omega=0.9):
 
         def tail_apply(self, b, x):
             x.numpy()[:] = self.tail.apply(b.numpy().copy())
+
+        def gs_sweep(self, l, back, xext, b, scratch):
+            self.loc[l].smooth(0, xext.numpy(), b.numpy(), scratch.numpy(), False, False, False, bool(back))
+
+        def residual(self, l, xext, b, r):
+            r.numpy()[:] = b.numpy() - self.A[l] @ xext.numpy()
 
     return lambda top, tail_hier, i: Ops(top, tail_hier, i)

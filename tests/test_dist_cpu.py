@@ -12,17 +12,18 @@ from oracle.pyoracle import Oracle
 from tests.dist_cpu_backend import cpu_backend
 
 
-def _run_loopback(R, box, dim, dist_min_rows):
+def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi"):
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
-    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dist_min_rows, backend=cpu_backend(), max_coarse_size=10)
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dist_min_rows, backend=cpu_backend(sm_type=sm),
+                           max_coarse_size=10, sm_type=sm)
     rng = np.random.default_rng(0)
     bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
     xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
     amg.Mult(bs, xs)
     glv = amg.global_levels()
-    ref = Oracle(glv, sm_type="jacobi").apply(np.concatenate([b.numpy() for b in bs]))
+    ref = Oracle(glv, sm_type=amg.oracle_sm_types()).apply(np.concatenate([b.numpy() for b in bs]))
     got = np.concatenate([x.numpy() for x in xs])
     return amg, got, ref
 
@@ -33,6 +34,20 @@ def test_loopback_matches_serial_oracle(R, box, dim, dmin):
     amg, got, ref = _run_loopback(R, box, dim, dmin)
     assert amg.k >= 1
     assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (12, 12, 12), 3, 100), (4, (10, 10, 10), 3, 50), (8, (8, 8, 8), 3, 20), (4, (24, 24), 2, 50)])
+def test_loopback_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin):
+    """rank-partitioned hybrid Gauss-Seidel == the oracle's serial hybrid GS (blocks = ranks, modified diagonal)"""
+    amg, got, ref = _run_loopback(R, box, dim, dmin, "gs")
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    # and the hybrid smoother still gives a convergent preconditioner: PCG on the global system
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=amg.oracle_sm_types())
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
+    _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)
+    assert errs[-1] < 1e-8 * errs[0] and it < 60
 
 
 def test_partitioned_matrix_is_the_global_one():
