@@ -104,6 +104,7 @@ struct DevRestrict {                    // column-blocked P^T (see restrict_chun
 
 struct DevLevel {
   DevRestrict R;
+  DevRestrict RF;                       // chunk-local P^T for sell_pre_restrict_kernel (fused pre-smoothing + restriction)
   DevMatrix A, P, PT;
   DevMatrix Apre;                       // scalar Jacobi levels: A * diag(omega * dinv), see EP_PRE in kernels.hpp
   DevBuf<double> dinv;
@@ -286,6 +287,7 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   if (allow_sell && A.br == 1 && A.bc == 1 && D.n_rows > 0 && D.nnz > 0) {
     int G = 1;
     while (G < 16 && D.n_rows * G < ((int64_t)1 << 20) && avg > 3.0 * G) G <<= 1;
+    if (const char* e = std::getenv("AMGX_SELL_MAX_LANES")) G = std::max(1, std::min(G, std::atoi(e)));   // test hook
     for (int g = G; g >= 1; g >>= 1)
       if ((double)sell_stored(A, g) <= 1.35 * (double)D.nnz) { sellG = g; break; }
   }
@@ -310,9 +312,8 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   }
 }
 
-static void build_restrict(const amgx_matrix& P, DevRestrict& R) {
+static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES) {
   const int64_t nf = P.n_rows, nc = P.n_cols;
-  const int CH = RESTRICT_CHUNK;
   const int64_t nch = (nf + CH - 1) / CH;
   std::vector<int32_t> chunk_slot(nch + 1, 0), slot_ptr(1, 0), slot_col;
   std::vector<double> w;
@@ -331,7 +332,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R) {
       w.push_back(t[q].w); fi.push_back(t[q].i);
     }
     if (!t.empty()) slot_ptr.push_back((int32_t)w.size());
-    if ((int64_t)t.size() > RESTRICT_MAX_ENTRIES) return;      // rows too long for the LDS product buffer: keep the P^T form
+    if ((int64_t)t.size() > max_entries) return;      // rows too long for the LDS product buffer: keep the P^T form
     chunk_slot[c + 1] = (int32_t)slot_col.size();
   }
   const int64_t ns = (int64_t)slot_col.size();
@@ -524,7 +525,7 @@ struct Handle {
     if (R.empty()) { mult(lev[l].PT, xf, xc); return; }
     hipLaunchKernelGGL(restrict_chunk_kernel, dim3(R.n_chunks), dim3(BLOCK), 0, stream, lev[l].n, R.chunk_slot.p, R.slot_ptr.p,
                        R.w.p, R.fi.p, xf, R.part.p);
-    hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+    hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                        R.oidx.p, R.part.p, xc);
     HIPCHK(hipGetLastError());
   }
@@ -588,6 +589,24 @@ struct Handle {
     }
   }
 
+  // pre-smoothing followed by the restriction of the residual (amg_matrix.cpp:193-212), fused where possible
+  void pre_smooth_restrict(int l, double* x, const double* b, double* r, double* b_coarse) {
+    DevLevel& L = lev[l];
+    if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty()) {
+      const DevRestrict& R = L.RF;
+      const int grid = (L.Apre.n_slices + (FUSED_BLOCK / WAVE) - 1) / (FUSED_BLOCK / WAVE);
+      if (grid != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
+      hipLaunchKernelGGL(sell_pre_restrict_kernel, dim3(grid), dim3(FUSED_BLOCK), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
+                         L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                         R.oidx.p, R.part.p, b_coarse);
+      HIPCHK(hipGetLastError());
+      return;
+    }
+    pre_smooth(L, x, b, r);
+    transfer_f2c(l, r, b_coarse);
+  }
+
   // coarse-grid correction + post-smoothing: x += P x_c; SmoothBack(x, b, r, 0, 0, 0)   (amg_matrix.cpp:263-302)
   void post_smooth(int l, double* x, const double* b, double* r, const double* xc) {
     DevLevel& L = lev[l];
@@ -607,8 +626,7 @@ struct Handle {
     for (int l = 0; l + 1 < L; ++l) {
       double* xl = l == 0 ? x : lev[l].x.p;
       const double* bl = l == 0 ? b : lev[l].rhs.p;
-      pre_smooth(lev[l], xl, bl, lev[l].res.p);
-      transfer_f2c(l, lev[l].res.p, lev[l + 1].rhs.p);
+      pre_smooth_restrict(l, xl, bl, lev[l].res.p, lev[l + 1].rhs.p);
     }
     coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
     for (int l = L - 2; l >= 0; --l) {
@@ -626,8 +644,7 @@ struct Handle {
       double* xl = l == 0 ? x0 : V.x.p;
       const double* bl = l == 0 ? b0 : V.rhs.p;
       double* rl = V.res.p;
-      pre_smooth(V, xl, bl, rl);
-      transfer_f2c(l, rl, lev[l + 1].rhs.p);
+      pre_smooth_restrict(l, xl, bl, rl, lev[l + 1].rhs.p);
       w_rec(l + 1, x0, b0);
       add_c2f(l, 1.0, xl, lev[l + 1].x.p);
       level_smooth(V, 1, xl, bl, rl, false, true, false);
@@ -648,8 +665,7 @@ struct Handle {
     transfer_f2c(start, res, lev[start + 1].rhs.p);
     if (start + 2 < L)
       for (int l = start + 1; l + 1 < L; ++l) {
-        pre_smooth(lev[l], lev[l].x.p, lev[l].rhs.p, lev[l].res.p);
-        transfer_f2c(l, lev[l].res.p, lev[l + 1].rhs.p);
+        pre_smooth_restrict(l, lev[l].x.p, lev[l].rhs.p, lev[l].res.p, lev[l + 1].rhs.p);
       }
     coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
     if (start + 2 < L)
@@ -817,6 +833,12 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         amgx_matrix As = s.A;
         As.val = sv.data();
         upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true);
+        // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
+        // Measured tie (profiles/r01/restrict_fused.txt: 444 + 18 us fused vs 328 + 135 us separate, same process), so it
+        // is opt-in (AMGX_FUSED_RESTRICT=1); kept because it is the only variant that never writes r to HBM.
+        if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 && s.A.n_rows == s.A.n_cols &&
+            s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && std::getenv("AMGX_FUSED_RESTRICT"))
+          build_restrict(s.P, L.RF, FUSED_CHUNK, FUSED_MAX_ENTRIES);
       }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);

@@ -384,14 +384,94 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused Jacobi pre-smoothing + restriction for big scalar levels (the level-0 hot spot):
+//   x = omega*Dinv*b,  r = b - A'b  (EP_PRE, one pass over the column-scaled image),  part = chunk-local P^T r
+// One 1024-thread workgroup owns 16 consecutive SELL slices = FUSED_CHUNK rows; r never goes to HBM: it is left in
+// LDS, multiplied with the chunk-local transpose of P (entries: fp64 weight + 16-bit local row) and reduced per
+// (chunk, coarse column) slot; restrict_sum_kernel then adds the ~10 partial sums of every coarse row in a fixed
+// order.  Replaces: 80 MB write of r + the P^T gather kernel (134 us at cfg 2, TA/L2-bound).
+constexpr int FUSED_BLOCK = 1024;
+constexpr int FUSED_CHUNK = 1024;
+constexpr int FUSED_MAX_ENTRIES = 4096;
+
+__global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int n_slices, SellMat M,
+                                                                        const double* __restrict__ b, const double* __restrict__ dinv,
+                                                                        double omega, double* __restrict__ x, double* r_out,
+                                                                        const int32_t* __restrict__ chunk_slot,
+                                                                        const int32_t* __restrict__ slot_ptr,
+                                                                        const double* __restrict__ w, const uint16_t* __restrict__ fi,
+                                                                        double* __restrict__ part) {
+  __shared__ double rl[FUSED_CHUNK];
+  __shared__ double pr[FUSED_MAX_ENTRIES];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));
+  const int row = s * WAVE + lane;
+  // the chunk-local restriction data of this thread is requested FIRST, so that it arrives while the row product
+  // streams A'; the epilogue after the barriers then touches LDS only
+  const int c = blockIdx.x;
+  const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
+  const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
+  double wq[FUSED_MAX_ENTRIES / FUSED_BLOCK];
+  int fq[FUSED_MAX_ENTRIES / FUSED_BLOCK];
+#pragma unroll
+  for (int q = 0; q < FUSED_MAX_ENTRIES / FUSED_BLOCK; ++q) {
+    const int e = e0 + threadIdx.x + q * FUSED_BLOCK;
+    wq[q] = e < e1 ? ld_nt(w + e) : 0.0;
+    fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
+  }
+  const int myslot = s0 + threadIdx.x;
+  const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
+  const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
+  double r = 0.0;
+  if (s < n_slices) {
+    const double acc = sell_row_dot(M, s, lane, row, b);
+    if (row < n_rows) {
+      const double bi = b[row];
+      r = bi - acc;
+      x[row] = omega * (dinv[row] * bi);
+      if (r_out) r_out[row] = r;
+    }
+  }
+  rl[threadIdx.x] = r;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < FUSED_MAX_ENTRIES / FUSED_BLOCK; ++q) {
+    const int e = threadIdx.x + q * FUSED_BLOCK;
+    if (e0 + e < e1) pr[e] = wq[q] * rl[fq[q]];
+  }
+  __syncthreads();
+  if (myslot < s1) {
+    double acc = 0.0;
+    for (int k = pa; k < pb; ++k) acc += pr[k];
+    part[myslot] = acc;
+  }
+  for (int slot = myslot + FUSED_BLOCK; slot < s1; slot += FUSED_BLOCK) {     // chunks with more than 1024 slots
+    const int a = slot_ptr[slot] - e0, bnd = slot_ptr[slot + 1] - e0;
+    double acc = 0.0;
+    for (int k = a; k < bnd; ++k) acc += pr[k];
+    part[slot] = acc;
+  }
+}
+
+// adds the partial sums of every coarse row: RSUM_G lanes per row (the partials of a row sit in different chunks,
+// i.e. in unrelated cache lines: lanes in parallel instead of one thread walking them)
+constexpr int RSUM_G = 8;
 __global__ __launch_bounds__(BLOCK) void restrict_sum_kernel(int64_t n_coarse, const int32_t* __restrict__ optr,
                                                              const int32_t* __restrict__ oidx,
                                                              const double* __restrict__ part, double* __restrict__ bc) {
-  const int64_t J = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (J >= n_coarse) return;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t J = t / RSUM_G;
+  const int sub = (int)(t % RSUM_G);
   double acc = 0.0;
-  for (int k = optr[J]; k < optr[J + 1]; ++k) acc += part[oidx[k]];
-  bc[J] = acc;
+  if (J < n_coarse) {
+    const int e = optr[J + 1];
+    for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[oidx[k]];
+  }
+  // fixed combination order: deterministic
+#pragma unroll
+  for (int o = RSUM_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, RSUM_G);
+  if (J < n_coarse && sub == 0) bc[J] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -267,3 +267,25 @@ def test_blocked_restriction_matches_oracle(monkeypatch):
         x = np.empty(p.n)
         dev.Mult(b, x)
         assert _rel(x, orc.apply(b)) < 1e-12
+
+
+@pytest.mark.parametrize("cycle", ["V", "W", "BS"])
+def test_fused_presmooth_restriction_matches_oracle(monkeypatch, cycle):
+    """sell_pre_restrict_kernel (fused Jacobi pre-smoothing + chunked restriction, used on levels in the
+    one-thread-per-row SELL form, i.e. >= 2^20 rows) forced onto small levels"""
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_SELL_MAX_LANES", "1")
+    monkeypatch.setenv("AMGX_FUSED_RESTRICT", "1")
+    for shape, diri, mcs in (((70, 50), "left|top", 5), ((23, 22, 21), "right|top", 20)):
+        p, H = poisson_case(shape, diri, mcs)
+        assert p.n > 3 * 1024                   # several chunks, last one partial
+        b = rhs(p, 2)
+        dev = _dev(H, sm_type="jacobi", mg_cycle=cycle)
+        x = np.full(p.n, np.nan)
+        dev.Mult(b, x)
+        assert _rel(x, Oracle(H.levels, sm_type="jacobi", cycle=cycle).apply(b)) < 1e-12
+    monkeypatch.delenv("AMGX_FUSED_RESTRICT")
+    dev2 = _dev(H, sm_type="jacobi", mg_cycle=cycle)
+    y = np.empty(p.n)
+    dev2.Mult(b, y)
+    assert _rel(y, x) < 1e-13
