@@ -102,7 +102,21 @@ struct DevRestrict {                    // column-blocked P^T (see restrict_chun
   bool empty() const { return n_chunks == 0; }
 };
 
+struct DevCsr {                         // plain CSR copy for the single-workgroup coarse tail
+  DevBuf<int32_t> rowptr, col;
+  DevBuf<double> val;
+  void upload(const amgx_matrix& A, const double* scaled_vals = nullptr) {
+    const int64_t nnz = A.rowptr[A.n_rows];
+    std::vector<int32_t> rp(A.n_rows + 1);
+    for (int64_t i = 0; i <= A.n_rows; ++i) rp[i] = (int32_t)A.rowptr[i];
+    rowptr.upload(rp);
+    col.upload(A.col, nnz);
+    val.upload(scaled_vals ? scaled_vals : A.val, nnz);
+  }
+};
+
 struct DevLevel {
+  DevCsr tA, tApre, tP, tPT;            // only on tail levels
   DevRestrict R;
   DevRestrict RF;                       // chunk-local P^T for sell_pre_restrict_kernel (fused pre-smoothing + restriction)
   DevMatrix A, P, PT;
@@ -360,6 +374,9 @@ struct Handle {
   DevBuf<double> coarse_inv;
   hipStream_t own_stream = nullptr, stream = nullptr;
   bool use_graph = true;
+  int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
+  int tail_ops = 0;
+  DevBuf<TailOp> tail_prog;
   std::string err;
   struct GraphKey { const double* b; double* x; int kind; bool operator<(const GraphKey& o) const { return std::tie(b, x, kind) < std::tie(o.b, o.x, o.kind); } };
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -623,13 +640,17 @@ struct Handle {
   void cycle_v(double* x, const double* b) {
     const int L = n_levels();
     if (L == 1) { coarse_solve(b, x); return; }
-    for (int l = 0; l + 1 < L; ++l) {
+    const int T = tail_level > 0 ? tail_level : L - 1;     // levels >= T run inside tail_kernel
+    for (int l = 0; l < T; ++l) {
       double* xl = l == 0 ? x : lev[l].x.p;
       const double* bl = l == 0 ? b : lev[l].rhs.p;
       pre_smooth_restrict(l, xl, bl, lev[l].res.p, lev[l + 1].rhs.p);
     }
-    coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
-    for (int l = L - 2; l >= 0; --l) {
+    if (tail_level > 0) {
+      hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(TAIL_BLOCK), 0, stream, tail_ops, tail_prog.p);
+      HIPCHK(hipGetLastError());
+    } else coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
+    for (int l = T - 1; l >= 0; --l) {
       double* xl = l == 0 ? x : lev[l].x.p;
       const double* bl = l == 0 ? b : lev[l].rhs.p;
       post_smooth(l, xl, bl, lev[l].res.p, lev[l + 1].x.p);
@@ -856,6 +877,51 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     if (d->coarse_n != L.len() || !d->coarse_inv) throw Err("clev = inv needs the dense coarse inverse of matching size");
     h->coarse_n = d->coarse_n;
     h->coarse_inv.upload(d->coarse_inv, (size_t)d->coarse_n * d->coarse_n);
+  }
+  // ---- single-workgroup coarse tail (V-cycle, plain scalar Jacobi, exact coarse solve, square levels) -----------
+  {
+    const int L = d->n_levels;
+    int T = -1;
+    if (d->cycle == AMGX_CYCLE_V && d->clev == AMGX_CLEV_INV && L >= 2 && !std::getenv("AMGX_NO_TAIL_KERNEL")) {
+      T = L - 1;
+      while (T - 1 >= 1) {
+        const amgx_level_desc& s = d->levels[T - 1];
+        const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= TAIL_MAX_ROWS && s.sm_type == AMGX_SM_JACOBI &&
+                        s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= TAIL_MAX_ROWS;
+        if (!ok) break;
+        --T;
+      }
+      if (T > L - 2) T = -1;                  // no smoothed level qualifies
+    }
+    if (T > 0) {
+      std::vector<TailOp> prog;
+      auto spmv = [&](int ep, const DevCsr& M, int n, const double* x, double* y, EpArgs a) {
+        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a});
+      };
+      for (int l = T; l + 1 < L; ++l) {
+        const amgx_level_desc& s = d->levels[l];
+        DevLevel& V = h->lev[l];
+        const int64_t nnz = s.A.rowptr[s.A.n_rows];
+        std::vector<double> sv((size_t)nnz);
+        for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
+        V.tA.upload(s.A); V.tApre.upload(s.A, sv.data()); V.tP.upload(s.P); V.tPT.upload(s.PT);
+      }
+      for (int l = T; l + 1 < L; ++l) {       // down: r = b - A'b, x = omega*Dinv*b ; b_{l+1} = P^T r
+        DevLevel& V = h->lev[l];
+        spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p});
+        spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr});
+      }
+      prog.push_back(TailOp{T_DENSE, 0, (int)h->coarse_n, nullptr, nullptr, h->coarse_inv.p, h->lev[L - 1].rhs.p, h->lev[L - 1].x.p,
+                            EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr}});
+      for (int l = L - 2; l >= T; --l) {      // up: tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)
+        DevLevel& V = h->lev[l];
+        spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.tmp.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
+        spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr});
+      }
+      h->tail_prog.upload(prog);
+      h->tail_ops = (int)prog.size();
+      h->tail_level = T;
+    }
   }
   HIPCHK(hipDeviceSynchronize());
   return h.release();

@@ -517,6 +517,66 @@ __global__ __launch_bounds__(BLOCK) void fill_kernel(int64_t n, uint64_t seed, d
   v[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Coarse tail of the Jacobi V-cycle in ONE workgroup: the levels with <= TAIL_MAX_ROWS rows are launch-latency bound
+// (~4.7 us per dependent graph node, 11+ nodes), so their whole down-sweep, the dense coarse solve and the up-sweep run
+// as a list of row-parallel operations separated by workgroup barriers.  Matrices are plain CSR here.
+constexpr int TAIL_BLOCK = 1024;
+constexpr int TAIL_G = 8;
+constexpr int TAIL_MAX_ROWS = 256;     // one workgroup is latency-bound beyond this (1261-row level: 4x slower than separate kernels)
+enum TailType : int { T_SPMV = 0, T_DENSE = 1 };
+
+struct TailOp {
+  int type;          // TailType
+  int ep;            // Epilogue for T_SPMV
+  int n;             // rows
+  const int32_t* rowptr;
+  const int32_t* col;
+  const double* val; // CSR values, or the dense n x n matrix
+  const double* x;
+  double* y;
+  EpArgs args;
+};
+
+__device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, double* y, const EpArgs& a) {
+  switch (ep) {
+    case EP_MULT: store_scalar<EP_MULT>(row, acc, y, a); break;
+    case EP_RES: store_scalar<EP_RES>(row, acc, y, a); break;
+    case EP_AXPY: store_scalar<EP_AXPY>(row, acc, y, a); break;
+    case EP_JAC: store_scalar<EP_JAC>(row, acc, y, a); break;
+    default: store_scalar<EP_PRE>(row, acc, y, a); break;
+  }
+}
+
+__global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailOp* __restrict__ ops) {
+  const int tid = threadIdx.x;
+  for (int i = 0; i < n_ops; ++i) {
+    const TailOp op = ops[i];
+    if (op.type == T_DENSE) {
+      const int lane = tid & (WAVE - 1);
+      for (int row = tid >> 6; row < op.n; row += TAIL_BLOCK / WAVE) {
+        double acc = 0.0;
+        for (int c = lane; c < op.n; c += WAVE) acc += op.val[(int64_t)row * op.n + c] * op.x[c];
+#pragma unroll
+        for (int o = WAVE >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+        if (lane == 0) op.y[row] = acc;
+      }
+    } else {
+      const int sub = tid % TAIL_G;
+      // all lanes of a group run the same trip count (row is group-uniform), so the shuffles are safe
+      for (int row = tid / TAIL_G; row < op.n; row += TAIL_BLOCK / TAIL_G) {
+        double acc = 0.0;
+        const int e = op.rowptr[row + 1];
+        for (int k = op.rowptr[row] + sub; k < e; k += TAIL_G) acc += op.val[k] * op.x[op.col[k]];
+#pragma unroll
+        for (int o = TAIL_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, TAIL_G);
+        if (sub == 0) tail_store(op.ep, row, acc, op.y, op.args);
+      }
+    }
+    __syncthreads();     // workgroup-scope release/acquire: the next operation reads what this one wrote
+  }
+}
+
 // dense y = M x, one wave per row (coarsest-level inverse, n <= a few hundred)
 __global__ __launch_bounds__(BLOCK) void dense_gemv_kernel(int n, const double* __restrict__ M,
                                                            const double* __restrict__ x, double* y) {
