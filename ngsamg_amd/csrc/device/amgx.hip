@@ -86,7 +86,13 @@ struct DevGS {                          // colour-major data for multicolour Gau
   int n_colors = 0;
   // scalar: SELL copy of A in colour-major row order
   std::vector<int> color_slice_ptr;     // [n_colors+1] slice ranges
+  int lanes = 1;                        // G of the colour-major SELL-G copy
   DevMatrix::Sell sell;
+  // split copies for pre-smoothing from x = 0 (forward sweep needs only lower-colour couplings, the residual after it
+  // only higher-colour couplings): one pass over A instead of two
+  DevMatrix::Sell lower, upper;
+  int n_slices_total = 0;
+  bool has_split = false;
   DevBuf<int32_t> rowid;
   // block: colour-major row list over the CSR of A
   std::vector<int> color_row_ptr;       // [n_colors+1]
@@ -499,8 +505,9 @@ struct Handle {
   }
 
   // one multicolour GS sweep (RHS form), forward: colours ascending, backward: descending
-  void gs_sweep(const DevLevel& L, int dir, double* x, const double* b) {
+  void gs_sweep(const DevLevel& L, int dir, double* x, const double* b, bool lower_only = false) {
     const DevGS& g = L.gs;
+    const DevMatrix::Sell& copy = (lower_only && g.has_split) ? g.lower : g.sell;
     if (g.n_colors == 0 && L.n > 0) throw Err("Gauss-Seidel requested but the level has no colouring");
     for (int q = 0; q < g.n_colors; ++q) {
       const int c = dir == 0 ? q : g.n_colors - 1 - q;
@@ -508,7 +515,15 @@ struct Handle {
         const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
         if (s1 == s0) continue;
         const int grid = (s1 - s0 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        hipLaunchKernelGGL(gs_color_kernel, dim3(grid), dim3(BLOCK), 0, stream, s0, s1, g.sell.view(), g.rowid.p, L.dinv.p, b, x);
+#define LAUNCH_GSC(GG) hipLaunchKernelGGL((gs_color_kernel<GG>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, copy.view(), g.rowid.p, L.dinv.p, b, x)
+        switch (g.lanes) {
+          case 1: LAUNCH_GSC(1); break;
+          case 2: LAUNCH_GSC(2); break;
+          case 4: LAUNCH_GSC(4); break;
+          case 8: LAUNCH_GSC(8); break;
+          default: LAUNCH_GSC(16); break;
+        }
+#undef LAUNCH_GSC
       } else {
         const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
         if (r1 == r0) continue;
@@ -595,6 +610,24 @@ struct Handle {
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
       residual(L.A, x, b, r);              // r = b - A x
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gs.has_split && L.bs == 1) {
+      // forward sweep from x = 0: only couplings to lower colours contribute; afterwards b - L x - D x = 0 on every
+      // swept row, hence r = -U x (r on non-free rows is not needed: their prolongation rows are empty)
+      zero(x, L.len());
+      zero(r, L.len());
+      gs_sweep(L, 0, x, b, true);
+      const DevGS& g = L.gs;
+      const int grid = (g.n_slices_total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+#define LAUNCH_UR(GG) hipLaunchKernelGGL((gs_upper_residual_kernel<GG>), dim3(grid), dim3(BLOCK), 0, stream, g.n_slices_total, g.upper.view(), g.rowid.p, x, r)
+      switch (g.lanes) {
+        case 1: LAUNCH_UR(1); break;
+        case 2: LAUNCH_UR(2); break;
+        case 4: LAUNCH_UR(4); break;
+        case 8: LAUNCH_UR(8); break;
+        default: LAUNCH_UR(16); break;
+      }
+#undef LAUNCH_UR
+      HIPCHK(hipGetLastError());
     } else if (plain(L) && L.sm_type == AMGX_SM_GS) {
       zero(x, L.len());
       gs_sweep(L, 0, x, b);
@@ -775,18 +808,61 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
   DevGS& g = L.gs;
   g.n_colors = nc;
   if (d.A.br == 1) {
-    // colour-major row list, each colour padded to a multiple of 64 rows
+    // lanes per row: one thread per row only while a colour still has >= 2^17 rows; below that G grows with the row
+    // length so that a row is consumed in ~2-4 steps
+    const int64_t nnz = d.A.rowptr[n];
+    const double avg = n ? (double)nnz / (double)n : 0.0;
+    int G = 1;
+    if (n / std::max(1, nc) < ((int64_t)1 << 17)) while (G < 16 && avg > 4.0 * G) G <<= 1;
+    g.lanes = G;
+    const int R = WAVE / G;
+    // colour-major row list, each colour padded to a multiple of R rows (= whole slices)
     std::vector<int64_t> cstart(nc + 1, 0);
-    for (int c = 0; c < nc; ++c) cstart[c + 1] = cstart[c] + ((cnt[c + 1] + WAVE - 1) / WAVE) * WAVE;
+    for (int c = 0; c < nc; ++c) cstart[c + 1] = cstart[c] + ((cnt[c + 1] + R - 1) / R) * R;
     std::vector<int32_t> rows(cstart[nc], -1);
     std::vector<int64_t> pos(cstart.begin(), cstart.end() - 1);
     for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
     g.color_slice_ptr.resize(nc + 1);
-    for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / WAVE);
+    for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / R);
     HostSell S;
-    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, 1, S);
+    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, G, S);
     upload_sell(S, g.sell);
     g.rowid.upload(rows);
+    g.n_slices_total = (int)(S.slice_ptr.size() - 1);
+    // the split form relies on x_k = (b - L x)_k / a_kk, i.e. on dinv being the plain inverse diagonal
+    bool plain_diag = d.dinv != nullptr && d.A.n_rows == d.A.n_cols;
+    for (int64_t i = 0; i < n && plain_diag; ++i) {
+      if (d.color[i] < 0) continue;
+      double aii = 0.0;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) if (d.A.col[k] == i) aii = d.A.val[k];
+      if (!(std::fabs(d.dinv[i] * aii - 1.0) < 1e-12)) plain_diag = false;
+    }
+    if (plain_diag) {
+      // lower / upper parts w.r.t. the colour order; couplings to non-free columns are dropped (x is 0 there)
+      for (int part = 0; part < 2; ++part) {
+        std::vector<int64_t> rp(n + 1, 0);
+        std::vector<int32_t> cc;
+        std::vector<double> vv;
+        cc.reserve(nnz / 2 + 16); vv.reserve(nnz / 2 + 16);
+        for (int64_t i = 0; i < n; ++i) {
+          const int ci = d.color[i];
+          if (ci >= 0)
+            for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+              const int cj = d.color[d.A.col[k]];
+              if (cj < 0) continue;
+              if ((part == 0 && cj < ci) || (part == 1 && cj > ci)) { cc.push_back(d.A.col[k]); vv.push_back(d.A.val[k]); }
+            }
+          rp[i + 1] = (int64_t)cc.size();
+        }
+        amgx_matrix F = d.A;
+        F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+        HostSell SP;
+        build_sell(F, rows.data(), (int64_t)rows.size(), true, G, SP);
+        if ((int)(SP.slice_ptr.size() - 1) != g.n_slices_total) throw Err("build_gs: split copy has a different slice count");
+        upload_sell(SP, part == 0 ? g.lower : g.upper);
+      }
+      g.has_split = true;
+    }
   } else {
     g.color_row_ptr.assign(nc + 1, 0);
     for (int c = 0; c < nc; ++c) g.color_row_ptr[c + 1] = g.color_row_ptr[c] + (int)cnt[c + 1];

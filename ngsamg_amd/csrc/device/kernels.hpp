@@ -286,6 +286,7 @@ __global__ __launch_bounds__(BLOCK) void bcsr6_spmv_kernel(int64_t n_rows, const
 // multicolour Gauss-Seidel, scalar: one colour per launch, colour-major SELL copy of A.
 //   x_k += dinv_k * (b_k - A_k: x)        (RHS form, reference gssmoother.cpp:209-212)
 // Rows of one colour have no mutual couplings, so the in-place update is race-free.
+template <int G>
 __global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int slice_end, SellMat M,
                                                          const int32_t* __restrict__ rowid,
                                                          const double* __restrict__ dinv,
@@ -293,10 +294,29 @@ __global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int sl
   const int lane = threadIdx.x & (WAVE - 1);
   const int s = __builtin_amdgcn_readfirstlane(slice_begin + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= slice_end) return;
-  const int row = rowid[(int64_t)s * WAVE + lane];
-  if (row < 0) return;
-  const double acc = sell_row_dot(M, s, lane, row, x);
-  x[row] += dinv[row] * (b[row] - acc);
+  // G lanes per row (SELL-G slices of 64/G rows): short dependent chains on the coarse levels, where a colour has
+  // only a few hundred rows of ~50 entries and one thread per row would be pure latency
+  const int row = rowid[(int64_t)s * (WAVE / G) + lane / G];
+  double acc = row >= 0 ? sell_row_dot(M, s, lane, row, x) : 0.0;
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  if (row >= 0 && (lane % G) == 0) x[row] += dinv[row] * (b[row] - acc);
+}
+
+// r = -(U x) on the colour-major rows: the residual right after a forward sweep from x = 0, where
+// (b - L x - D x)_k = 0 holds for every swept row (see Handle::pre_smooth), so only the entries coupling to HIGHER
+// colours are needed.  One launch over all colours (no ordering required).
+template <int G>
+__global__ __launch_bounds__(BLOCK) void gs_upper_residual_kernel(int n_slices, SellMat M, const int32_t* __restrict__ rowid,
+                                                                  const double* __restrict__ x, double* __restrict__ r) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (s >= n_slices) return;
+  const int row = rowid[(int64_t)s * (WAVE / G) + lane / G];
+  double acc = row >= 0 ? sell_row_dot(M, s, lane, row, x) : 0.0;
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+  if (row >= 0 && (lane % G) == 0) r[row] = -acc;
 }
 
 // multicolour Gauss-Seidel, block BS x BS: CSR rows through a colour-major row list, G lanes per row
