@@ -507,7 +507,7 @@ class DistributedAMG:
     backend:  callable(top_hierarchy, tail_hierarchy, rank) -> (top_ops, tail_ops); default = the HIP library
     """
 
-    def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=20000, max_dist_levels=3, device=0,
+    def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=50000, max_dist_levels=3, device=0,
                  backend=None, sm_type="jacobi", **opts):
         if sm_type not in ("jacobi", "gs"):
             raise NgsAMGError("DistributedAMG: sm_type must be jacobi or gs")
@@ -591,6 +591,11 @@ class DistributedAMG:
             recvs.append({q: vec[s.n + a:s.n + e] for q, (a, e) in s.recv_seg.items()})
         self.comm.halo(sends, recvs)
 
+    def rhs_buffer(self, i=0):
+        """owned part of the level-0 right-hand-side buffer of local rank i: fill THIS tensor and pass it to Mult to
+        save the copy of b into the [owned | ghost] layout (Jacobi path)"""
+        return self.buf[i]["bext"][0][:self.dist_levels[0][i].n]
+
     def Mult(self, bs, xs):
         """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind)"""
         if self.sm_type == "gs":
@@ -599,7 +604,7 @@ class DistributedAMG:
         for l in range(k):
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
-                if l == 0:
+                if l == 0 and bs[i].data_ptr() != b["bext"][0].data_ptr():
                     b["bext"][0][:s.n].copy_(bs[i])
             self._halo(l, "bext")
             for i, ops in enumerate(self.ops):
