@@ -129,9 +129,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
-        # the host setup is OpenMP-parallel: share the box's cores between the ranks
-        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
+    if world > 1:
+        # the host setup is OpenMP-parallel: share the box's cores between the ranks.  torch.distributed.run exports
+        # OMP_NUM_THREADS=1 to its children, which would make the (untimed) setup of a 10M-DOF box take minutes.
+        os.environ["OMP_NUM_THREADS"] = os.environ.get("NGSAMG_OMP_THREADS", str(max(1, min(32, (os.cpu_count() or 8) // world))))
     import torch
     import __graft_entry__ as ge
     if local_rank == 0:
