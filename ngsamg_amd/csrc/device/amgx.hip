@@ -123,6 +123,7 @@ struct DevCsr {                         // plain CSR copy for the single-workgro
 
 struct DevLevel {
   DevCsr tA, tApre, tP, tPT;            // only on tail levels
+  DevBuf<int32_t> t_rowlist, t_cptr;    // colour-major row list of a Gauss-Seidel tail level
   DevRestrict R;
   DevRestrict RF;                       // chunk-local P^T for sell_pre_restrict_kernel (fused pre-smoothing + restriction)
   DevMatrix A, P, PT;
@@ -954,7 +955,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     h->coarse_n = d->coarse_n;
     h->coarse_inv.upload(d->coarse_inv, (size_t)d->coarse_n * d->coarse_n);
   }
-  // ---- single-workgroup coarse tail (V-cycle, plain scalar Jacobi, exact coarse solve, square levels) -----------
+  // ---- single-workgroup coarse tail (V-cycle, plain scalar smoothers, exact coarse solve, square levels) ----------
   {
     const int L = d->n_levels;
     int T = -1;
@@ -962,8 +963,10 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       T = L - 1;
       while (T - 1 >= 1) {
         const amgx_level_desc& s = d->levels[T - 1];
-        const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= TAIL_MAX_ROWS && s.sm_type == AMGX_SM_JACOBI &&
-                        s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= TAIL_MAX_ROWS;
+        const int64_t cap = s.sm_type == AMGX_SM_GS ? TAIL_MAX_ROWS_GS : TAIL_MAX_ROWS;
+        const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= cap &&
+                        (s.sm_type == AMGX_SM_JACOBI || (s.sm_type == AMGX_SM_GS && s.color && s.n_colors > 0)) &&
+                        s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= 512;
         if (!ok) break;
         --T;
       }
@@ -971,28 +974,55 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     }
     if (T > 0) {
       std::vector<TailOp> prog;
+      const EpArgs none{nullptr, nullptr, nullptr, 0.0, nullptr};
       auto spmv = [&](int ep, const DevCsr& M, int n, const double* x, double* y, EpArgs a) {
-        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a});
+        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0});
+      };
+      auto gs = [&](DevLevel& V, int nc, int backward) {
+        prog.push_back(TailOp{T_GS, 0, (int)V.n, V.tA.rowptr.p, V.tA.col.p, V.tA.val.p, nullptr, V.x.p,
+                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr}, V.t_rowlist.p, V.t_cptr.p, nc, backward});
       };
       for (int l = T; l + 1 < L; ++l) {
         const amgx_level_desc& s = d->levels[l];
         DevLevel& V = h->lev[l];
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
-        std::vector<double> sv((size_t)nnz);
-        for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
-        V.tA.upload(s.A); V.tApre.upload(s.A, sv.data()); V.tP.upload(s.P); V.tPT.upload(s.PT);
+        V.tA.upload(s.A); V.tP.upload(s.P); V.tPT.upload(s.PT);
+        if (s.sm_type == AMGX_SM_JACOBI) {
+          std::vector<double> sv((size_t)nnz);
+          for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
+          V.tApre.upload(s.A, sv.data());
+        } else {
+          std::vector<int32_t> cptr(s.n_colors + 1, 0), rl;
+          for (int64_t i = 0; i < s.A.n_rows; ++i) if (s.color[i] >= 0) cptr[s.color[i] + 1]++;
+          for (int c = 0; c < s.n_colors; ++c) cptr[c + 1] += cptr[c];
+          rl.resize(cptr[s.n_colors]);
+          std::vector<int32_t> pos(cptr.begin(), cptr.end() - 1);
+          for (int64_t i = 0; i < s.A.n_rows; ++i) if (s.color[i] >= 0) rl[pos[s.color[i]]++] = (int32_t)i;
+          V.t_rowlist.upload(rl); V.t_cptr.upload(cptr);
+        }
       }
-      for (int l = T; l + 1 < L; ++l) {       // down: r = b - A'b, x = omega*Dinv*b ; b_{l+1} = P^T r
+      for (int l = T; l + 1 < L; ++l) {       // down
         DevLevel& V = h->lev[l];
-        spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p});
-        spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr});
+        if (V.sm_type == AMGX_SM_JACOBI) {     // r = b - A'b, x = omega*Dinv*b
+          spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p});
+        } else {                               // x = 0; forward sweep; r = b - A x
+          prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0});
+          gs(V, d->levels[l].n_colors, 0);
+          spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr});
+        }
+        spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, none);   // b_{l+1} = P^T r
       }
       prog.push_back(TailOp{T_DENSE, 0, (int)h->coarse_n, nullptr, nullptr, h->coarse_inv.p, h->lev[L - 1].rhs.p, h->lev[L - 1].x.p,
-                            EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr}});
-      for (int l = L - 2; l >= T; --l) {      // up: tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)
+                            none, nullptr, nullptr, 0, 0});
+      for (int l = L - 2; l >= T; --l) {      // up
         DevLevel& V = h->lev[l];
-        spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.tmp.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
-        spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr});
+        if (V.sm_type == AMGX_SM_JACOBI) {     // tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)
+          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.tmp.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
+          spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr});
+        } else {                               // x += P x_{l+1} ; backward sweep
+          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.x.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
+          gs(V, d->levels[l].n_colors, 1);
+        }
       }
       h->tail_prog.upload(prog);
       h->tail_ops = (int)prog.size();

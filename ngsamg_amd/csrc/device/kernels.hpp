@@ -543,8 +543,9 @@ __global__ __launch_bounds__(BLOCK) void fill_kernel(int64_t n, uint64_t seed, d
 // as a list of row-parallel operations separated by workgroup barriers.  Matrices are plain CSR here.
 constexpr int TAIL_BLOCK = 1024;
 constexpr int TAIL_G = 8;
-constexpr int TAIL_MAX_ROWS = 256;     // one workgroup is latency-bound beyond this (1261-row level: 4x slower than separate kernels)
-enum TailType : int { T_SPMV = 0, T_DENSE = 1 };
+constexpr int TAIL_MAX_ROWS = 256;     // Jacobi: one workgroup is latency-bound beyond this (1261-row level: 4x slower than separate kernels)
+constexpr int TAIL_MAX_ROWS_GS = 256;  // Gauss-Seidel: measured no gain for larger levels either (54 colour phases in one workgroup ~ 118 launches)
+enum TailType : int { T_SPMV = 0, T_DENSE = 1, T_GS = 2, T_ZERO = 3 };
 
 struct TailOp {
   int type;          // TailType
@@ -556,6 +557,11 @@ struct TailOp {
   const double* x;
   double* y;
   EpArgs args;
+  // T_GS: multicolour sweep  y[row] += dinv[row] * (b[row] - A[row,:] y)  over the colour-major row list
+  const int32_t* rowlist;
+  const int32_t* cptr;   // [n_colors+1] ranges of rowlist
+  int n_colors;
+  int backward;
 };
 
 __device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, double* y, const EpArgs& a) {
@@ -572,7 +578,25 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
   const int tid = threadIdx.x;
   for (int i = 0; i < n_ops; ++i) {
     const TailOp op = ops[i];
-    if (op.type == T_DENSE) {
+    if (op.type == T_ZERO) {
+      for (int k = tid; k < op.n; k += TAIL_BLOCK) op.y[k] = 0.0;
+    } else if (op.type == T_GS) {
+      const int sub = tid % TAIL_G;
+      for (int q = 0; q < op.n_colors; ++q) {
+        const int c = op.backward ? op.n_colors - 1 - q : q;
+        const int r1 = op.cptr[c + 1];
+        for (int p = op.cptr[c] + tid / TAIL_G; p < r1; p += TAIL_BLOCK / TAIL_G) {
+          const int row = op.rowlist[p];
+          double acc = 0.0;
+          const int e = op.rowptr[row + 1];
+          for (int k = op.rowptr[row] + sub; k < e; k += TAIL_G) acc += op.val[k] * op.y[op.col[k]];
+#pragma unroll
+          for (int o = TAIL_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, TAIL_G);
+          if (sub == 0) op.y[row] += op.args.dinv[row] * (op.args.b[row] - acc);
+        }
+        __syncthreads();   // the next colour reads what this one wrote
+      }
+    } else if (op.type == T_DENSE) {
       const int lane = tid & (WAVE - 1);
       for (int row = tid >> 6; row < op.n; row += TAIL_BLOCK / WAVE) {
         double acc = 0.0;

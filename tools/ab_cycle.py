@@ -23,6 +23,7 @@ def main():
     from ngsamg_amd.hierarchy import Hierarchy
     from ngsamg_amd.device import DeviceAMGMatrix
     nv = int(sys.argv[1]) if len(sys.argv) > 1 else 215
+    sm = sys.argv[2] if len(sys.argv) > 2 else "jacobi"
     p = fem.poisson_fast((nv, nv, nv))
     H = Hierarchy(Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val), p.free, p.coords, dim=3, energy=0, max_coarse_size=50)
     hs = {}
@@ -30,7 +31,9 @@ def main():
         for name, env in VARIANTS.items():
             for k, v in env.items():
                 os.environ[k] = v
-            hs[f"{name}#{inst}"] = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
+            if sm == "gs" and name == "fused_restrict":
+                continue
+            hs[f"{name}#{inst}"] = DeviceAMGMatrix(H, sm_type=sm, device=0)
             for k in env:
                 del os.environ[k]
     res = {k: [] for k in hs}
