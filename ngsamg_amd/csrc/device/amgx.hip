@@ -76,8 +76,8 @@ struct DevMatrix {
     DevBuf<int32_t> col32, cbase;
     DevBuf<uint16_t> col16;
     DevBuf<double> val;
-    int rowrel = 0;
-    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel}; }
+    int rowrel = 0, diag_first = 0;
+    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first}; }
   } sell;
   bool empty() const { return n_rows == 0; }
 };
@@ -171,7 +171,7 @@ struct HostSell {
   std::vector<uint16_t> col16;
   std::vector<double> val;
   int64_t n_comp_slices = 0, stream_bytes = 0;
-  int rowrel = 0;
+  int rowrel = 0, diag_first = 0;
 };
 
 // G = lanes per row (1, 2, 4, 8, 16).  G == 1: one thread per row, slices of 64 rows, odd widths allowed.
@@ -190,10 +190,24 @@ static int64_t sell_stored(const amgx_matrix& A, int G) {
   return stored;
 }
 
-static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, int G, HostSell& S) {
+static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, int G, HostSell& S, bool want_diag_first = false) {
   const int R = WAVE / G;
   const int64_t ns = (m + R - 1) / R;
   S.rowrel = rowrel ? 1 : 0;
+  // diagonal-first entry order (one thread per row, square matrix, every row has its diagonal stored): the Jacobi
+  // epilogues then get the own-row value of the gathered vector from entry 0 instead of a second streaming read
+  std::vector<int32_t> dpos;
+  bool diag_first = want_diag_first && G == 1 && !rows && A.n_rows <= A.n_cols && !std::getenv("AMGX_NO_DIAG_FIRST");
+  if (diag_first) {
+    dpos.assign(A.n_rows, -1);
+    for (int64_t i = 0; i < A.n_rows && diag_first; ++i) {
+      for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) if (A.col[k] == i) { dpos[i] = (int32_t)(k - A.rowptr[i]); break; }
+      if (dpos[i] < 0) diag_first = false;
+    }
+  }
+  S.diag_first = diag_first ? 1 : 0;
+  // CSR position (relative to the row start) of entry e in the device order
+  auto src = [&](int64_t r, int e) -> int { if (!diag_first) return e; const int dp = dpos[r]; return e == 0 ? dp : (e <= dp ? e - 1 : e); };
   S.slice_ptr.assign(ns + 1, 0);
   auto row_of = [&](int64_t q) -> int64_t { return (q < m) ? (rows ? rows[q] : q) : -1; };
   for (int64_t s = 0; s < ns; ++s) {
@@ -232,9 +246,10 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
         const int e = entry(l, j);
         if (e < len) {
           const int64_t o = off(l, j);
-          S.col32[o] = A.col[rb + e];
-          S.val[o] = A.val[rb + e];
-          cb = std::min<int64_t>(cb, (int64_t)A.col[rb + e] - (rowrel ? r : 0));
+          const int64_t ks = rb + src(r, e);
+          S.col32[o] = A.col[ks];
+          S.val[o] = A.val[ks];
+          cb = std::min<int64_t>(cb, (int64_t)A.col[ks] - (rowrel ? r : 0));
         }
       }
       if (cb == INT64_MAX) cb = 0;
@@ -252,7 +267,7 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
         const int64_t rk = rows ? r : q;
         const int64_t rr = rowrel ? rk : 0;
         if (e < len) {
-          const int64_t d = (int64_t)A.col[rb + e] - rr - cb;
+          const int64_t d = (int64_t)A.col[rb + src(r, e)] - rr - cb;
           if (d < 0 || d > 65535) comp = false; else S.col16[o] = (uint16_t)d;
         } else {
           // padding (value 0): any valid column; prefer one reachable in both encodings
@@ -277,6 +292,7 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
 static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
   const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
   D.rowrel = S.rowrel;
+  D.diag_first = S.diag_first;
   D.slice_ptr.upload(S.slice_ptr);
   D.val.upload(S.val);
   if (S.n_comp_slices < ns) D.col32.upload(S.col32);               // only read by 32-bit slices
@@ -314,7 +330,7 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   }
   if (sellG) {
     HostSell S;
-    build_sell(A, nullptr, A.n_rows, rowrel_ok && A.n_cols >= A.n_rows, sellG, S);
+    build_sell(A, nullptr, A.n_rows, rowrel_ok && A.n_cols >= A.n_rows, sellG, S, rowrel_ok);
     D.fmt = FMT_SELL;
     D.lanes = sellG;
     D.n_slices = (int)(S.slice_ptr.size() - 1);

@@ -56,14 +56,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 // ---------------------------------------------------------------------------------------------------
 // scalar epilogue
+// have_xd: xd is the value of the gathered vector at the own row (EP_JAC: yin[row], EP_PRE: b[row]) and need not be loaded
 template <int EP>
-__device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y, const EpArgs& ep) {
+__device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y, const EpArgs& ep, bool have_xd = false, double xd = 0.0) {
   if (EP == EP_MULT) y[row] = acc;
   else if (EP == EP_RES) y[row] = ep.b[row] - acc;
   else if (EP == EP_AXPY) y[row] = ep.yin[row] + ep.s * acc;
-  else if (EP == EP_JAC) y[row] = ep.yin[row] + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
+  else if (EP == EP_JAC) y[row] = (have_xd ? xd : ep.yin[row]) + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
   else {
-    const double bi = ep.b[row];
+    const double bi = have_xd ? xd : ep.b[row];
     y[row] = bi - acc;
     ep.y2[row] = ep.s * (ep.dinv[row] * bi);
   }
@@ -83,13 +84,15 @@ struct SellMat {
   const int32_t* cbase;
   const double* val;
   int rowrel;
+  int diag_first;             // G == 1 only: entry 0 of every row is its diagonal, so the gathered x[row] comes for free
 };
 
 template <class T>
 __device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 
 // dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
-__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x) {
+// xd (optional): receives the x value gathered for entry 0 of this lane's row (meaningful when M.diag_first)
+__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd = nullptr) {
   const int64_t sp0 = M.slice_ptr[s];
   const int64_t base = sp0 & ~(int64_t)63;
   const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
@@ -106,13 +109,17 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
       const uint32_t c = ld_nt(cp + p * WAVE + lane);
       const int c0 = r0 + cb[2 * p] + (int)(c & 0xffffu);
       const int c1 = r0 + cb[2 * p + 1] + (int)(c >> 16);
-      acc0 += v0 * x[c0];
+      const double x0 = x[c0];
+      if (xd && p == 0) *xd = x0;
+      acc0 += v0 * x0;
       acc1 += v1 * x[c1];
     }
     if (w & 1) {
       const int64_t o = (int64_t)(w - 1) * WAVE + lane;
       const int c0 = r0 + cb[w - 1] + (int)ld_nt(M.col16 + base + o);
-      acc0 += ld_nt(vb + o) * x[c0];
+      const double x0 = x[c0];
+      if (xd && np == 0) *xd = x0;
+      acc0 += ld_nt(vb + o) * x0;
     }
   } else {
     const int32_t* __restrict__ cp = M.col32 + base;
@@ -120,12 +127,16 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
     for (int p = 0; p < np; ++p) {
       const double v0 = ld_nt(vb + (p * WAVE + lane) * 2), v1 = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
       const int c0 = ld_nt(cp + (p * WAVE + lane) * 2), c1 = ld_nt(cp + (p * WAVE + lane) * 2 + 1);
-      acc0 += v0 * x[c0];
+      const double x0 = x[c0];
+      if (xd && p == 0) *xd = x0;
+      acc0 += v0 * x0;
       acc1 += v1 * x[c1];
     }
     if (w & 1) {
       const int64_t o = (int64_t)(w - 1) * WAVE + lane;
-      acc0 += ld_nt(vb + o) * x[ld_nt(cp + o)];
+      const double x0 = x[ld_nt(cp + o)];
+      if (xd && np == 0) *xd = x0;
+      acc0 += ld_nt(vb + o) * x0;
     }
   }
   return acc0 + acc1;
@@ -140,10 +151,12 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
   const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
   const int row = s * (WAVE / G) + lane / G;
-  double acc = sell_row_dot(M, s, lane, row, x);
+  double xd = 0.0;
+  const bool use_xd = G == 1 && (EP == EP_JAC || EP == EP_PRE) && M.diag_first;
+  double acc = sell_row_dot(M, s, lane, row, x, use_xd ? &xd : nullptr);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-  if ((lane % G) == 0 && row < n_rows) store_scalar<EP>(row, acc, y, ep);
+  if ((lane % G) == 0 && row < n_rows) store_scalar<EP>(row, acc, y, ep, use_xd, xd);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ VARIANTS = {
     "default": {},
     "fused_restrict": {"AMGX_FUSED_RESTRICT": "1"},
     "no_tail_kernel": {"AMGX_NO_TAIL_KERNEL": "1"},
+    "no_diag_first": {"AMGX_NO_DIAG_FIRST": "1"},
 }
 
 
