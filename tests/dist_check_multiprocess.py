@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Multi-PROCESS check of the rank-partitioned V-cycle on ONE GPU: W processes share cuda:0, transport = gloo with
 host-staged halos (debug transport; RCCL refuses several ranks per device).  Exercises everything of the N > 1 path
-except the RCCL calls themselves.   python tools/dist_check.py [W] [box]"""
+except the RCCL calls themselves.   python tests/dist_check_multiprocess.py [W] [box]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path.insert(0, ROOT)
 
 
