@@ -289,3 +289,35 @@ def test_fused_presmooth_restriction_matches_oracle(monkeypatch, cycle):
     y = np.empty(p.n)
     dev2.Mult(b, y)
     assert _rel(y, x) < 1e-13
+
+
+@pytest.mark.parametrize("sm", ["jacobi", "gs"])
+def test_size_independent_properties_at_large_size(sm):
+    """1.1 M DOF (the one-thread-per-row SELL path, 16-bit column deltas, graph replay): properties that need no oracle --
+    linearity of the cycle, symmetry of the preconditioner (the reference dumps the same asymmetry, amg_pc.cpp:162-173),
+    positive definiteness on the free dofs -- plus the oracle comparison itself."""
+    import torch
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((103, 103, 103), "right|top", 50)
+    dev = _dev(H, sm_type=sm)
+    assert dev.matrix_info(0, "A")["fmt"] == "sell" and dev.matrix_info(0, "A")["lanes"] == 1
+    rng = np.random.default_rng(0)
+    free = torch.from_numpy(p.free.astype(np.float64)).cuda()
+    u = torch.from_numpy(rng.standard_normal(p.n)).cuda() * free
+    v = torch.from_numpy(rng.standard_normal(p.n)).cuda() * free
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        Cu, Cv, Cw = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+        dev.Mult(u, Cu)
+        dev.Mult(v, Cv)
+        w = 0.3 * u - 1.7 * v
+        dev.Mult(w, Cw)
+        s.synchronize()
+        lin = (Cw - (0.3 * Cu - 1.7 * Cv)).norm() / Cw.norm()
+        a, b = torch.dot(Cu, v).item(), torch.dot(u, Cv).item()
+        pd = torch.dot(Cu, u).item()
+    assert lin.item() < 1e-12
+    assert abs(a - b) <= 1e-11 * max(abs(a), abs(b))
+    assert pd > 0
+    ref = Oracle(H.levels, sm_type="jacobi" if sm == "jacobi" else "gs_mc", threads=8).apply(u.cpu().numpy())
+    assert _rel(Cu.cpu().numpy(), ref) < (1e-12 if sm == "jacobi" else 1e-10)
