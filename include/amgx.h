@@ -127,7 +127,7 @@ int amgx_coarse_solve(amgx_handle h, const double* rhs, double* x, int flags);
 /* GetNLevels / GetNDof / GetBlockSize (python_amg.hpp:15-103) */
 int amgx_n_levels(amgx_handle h);
 int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* nnz);
-/* device-format report per level matrix: which = 0 A, 1 P, 2 PT; fmt: 0 CSR-vector, 1 sliced-ELL;
+/* device-format report per level matrix: which = 0 A, 1 P, 2 PT; fmt: 0 CSR-vector, 1 sliced-ELL, 2 block sliced-ELL;
  * stored_entries counts padding (for the traffic model in DESIGN.md) */
 int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);
 

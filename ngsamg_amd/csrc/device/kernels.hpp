@@ -241,6 +241,67 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// BSELL: sliced ELL for square BS x BS block matrices, ONE LANE PER SCALAR ROW.  A slice holds RB = 64/BS block rows
+// (63 / 60 / 64 active lanes for BS = 3 / 6 / 2); per block step k the values are stored structure-of-arrays,
+//   [k][column pair cp][lane 0..63][2]   (+ [k][last column][lane] when BS is odd),
+// so every wave instruction streams one aligned 1 KiB (or 512 B) chunk, exactly like the scalar SELL kernel; the block
+// column index is stored once per (k, block row).  Used when the slice padding stays small (FEM fine levels); irregular
+// coarse levels keep the CSR row-per-lane kernels.
+struct BSellMat {
+  const int64_t* slice_ptr;   // [n_slices+1] cumulative block steps
+  const int32_t* col;         // [steps * RB]
+  const double* val;          // [steps * BS * 64]
+};
+
+template <int BS, int EP>
+__global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n_slices, BSellMat M,
+                                                           const double* __restrict__ x, double* y, EpArgs ep) {
+  constexpr int RB = WAVE / BS;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (s >= n_slices) return;
+  const int rbl = lane / BS < RB ? lane / BS : RB - 1;      // idle lanes (lane >= RB*BS) shadow the last block row
+  const int r = lane % BS;
+  const int64_t brow = (int64_t)s * RB + rbl;
+  const bool active = lane < RB * BS && brow < n_rows;
+  const int64_t k0 = M.slice_ptr[s];
+  const int w = (int)(M.slice_ptr[s + 1] - k0);
+  const double* __restrict__ vb = M.val + k0 * (BS * WAVE);
+  const int32_t* __restrict__ cb = M.col + k0 * RB;
+  double acc = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < w; ++k) {
+    const int c = cb[k * RB + rbl];        // cached load: the RB*4-byte column chunks of consecutive steps share cache lines
+    const double* __restrict__ xv = x + (int64_t)c * BS;
+    const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) {
+      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+      acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+    }
+    if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+  }
+  const int64_t i = brow * BS + r;
+  double out = 0.0;
+  if (EP == EP_JAC) {
+    const double t = active ? ep.b[i] - acc : 0.0;
+    const int base = lane - r;
+    double u = 0.0;
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      const double tc = __shfl(t, base + c, WAVE);
+      if (active) u += ep.dinv[brow * (BS * BS) + r * BS + c] * tc;
+    }
+    if (active) out = ep.yin[i] + ep.s * u;
+  } else if (active) {
+    if (EP == EP_MULT) out = acc;
+    else if (EP == EP_RES) out = ep.b[i] - acc;
+    else out = ep.yin[i] + ep.s * acc;
+  }
+  if (active) y[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 6x6 block CSR, row-per-lane inside the block: lane (g, r) of a block row's lane group owns scalar row r and the
 // blocks k = g, g+W, ...; it reads its 48-B row of each block as three 16-B loads, so the six lanes of a group read
 // one contiguous 288-B block and a wave streams 10 / 5 / 2 block rows (W = 1 / 2 / 4) with full cache-line use.

@@ -225,7 +225,7 @@ class DeviceAMGMatrix:
                                             C.byref(stored), C.byref(lanes)))
         nb = C.c_int64()
         self._ck(self._lib.amgx_matrix_stream_bytes(self._h, level, {"A": 0, "P": 1, "PT": 2}[which], C.byref(nb)))
-        return {"fmt": "sell" if fmt.value == 1 else "csrvec", "stored": stored.value, "lanes": lanes.value,
+        return {"fmt": {0: "csrvec", 1: "sell", 2: "bsell"}.get(fmt.value, "?"), "stored": stored.value, "lanes": lanes.value,
                 "stream_bytes": nb.value}
 
     def time_op(self, level, op, reps=20):

@@ -85,15 +85,19 @@ def test_scalar_formats(n, avg, spread, expect_fmt):
     assert _rel(xo, x + 0.9 * (b - S @ x)) < 1e-12
 
 
-@pytest.mark.parametrize("bs,avg", [(2, 9), (3, 15), (3, 40), (6, 8), (6, 30), (6, 70)])
-def test_block_matvec_and_jacobi(bs, avg):
+@pytest.mark.parametrize("bs,avg,uniform", [(2, 9, False), (3, 15, False), (3, 40, False), (6, 8, False), (6, 30, False), (6, 70, False),
+                                            (2, 9, True), (3, 15, True), (6, 15, True), (6, 44, True)])
+def test_block_matvec_and_jacobi(bs, avg, uniform):
+    """uniform row lengths -> block SELL (one lane per scalar row); varying lengths -> CSR block kernels"""
     rng = np.random.default_rng(bs * 100 + avg)
     n = 700
-    A = _rand_bcsr(rng, n, n, bs, bs, lambda i: avg + (i % 5) - 2, 150)
+    A = _rand_bcsr(rng, n, n, bs, bs, (lambda i: avg) if uniform else (lambda i: max(1, avg + (i % 5) * (avg // 3) - (2 * avg) // 3)), 150)
     lev = _level(A)
     dinv = rng.standard_normal((n, bs, bs))
     lev.dinv = np.ascontiguousarray(dinv.reshape(-1))
     dev = _dev([lev])
+    if uniform:
+        assert dev.matrix_info(0, "A")["fmt"] == "bsell"
     S = A.to_scipy()
     x = rng.standard_normal(n * bs)
     y = np.empty(n * bs)
