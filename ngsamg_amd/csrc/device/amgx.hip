@@ -1012,10 +1012,10 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         As.val = sv.data();
         upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true);
         // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
-        // Measured tie (profiles/r01/restrict_fused.txt: 444 + 18 us fused vs 328 + 135 us separate, same process), so it
-        // is opt-in (AMGX_FUSED_RESTRICT=1); kept because it is the only variant that never writes r to HBM.
+        // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
+        // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
         if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 && s.A.n_rows == s.A.n_cols &&
-            s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && std::getenv("AMGX_FUSED_RESTRICT"))
+            s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
           build_restrict(s.P, L.RF, FUSED_CHUNK, FUSED_MAX_ENTRIES);
       }
     } else if (s.dinv) {

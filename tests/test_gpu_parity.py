@@ -275,7 +275,6 @@ def test_fused_presmooth_restriction_matches_oracle(monkeypatch, cycle):
     one-thread-per-row SELL form, i.e. >= 2^20 rows) forced onto small levels"""
     from oracle.pyoracle import Oracle
     monkeypatch.setenv("AMGX_SELL_MAX_LANES", "1")
-    monkeypatch.setenv("AMGX_FUSED_RESTRICT", "1")
     for shape, diri, mcs in (((70, 50), "left|top", 5), ((23, 22, 21), "right|top", 20)):
         p, H = poisson_case(shape, diri, mcs)
         assert p.n > 3 * 1024                   # several chunks, last one partial
@@ -284,7 +283,7 @@ def test_fused_presmooth_restriction_matches_oracle(monkeypatch, cycle):
         x = np.full(p.n, np.nan)
         dev.Mult(b, x)
         assert _rel(x, Oracle(H.levels, sm_type="jacobi", cycle=cycle).apply(b)) < 1e-12
-    monkeypatch.delenv("AMGX_FUSED_RESTRICT")
+    monkeypatch.setenv("AMGX_NO_FUSED_RESTRICT", "1")
     dev2 = _dev(H, sm_type="jacobi", mg_cycle=cycle)
     y = np.empty(p.n)
     dev2.Mult(b, y)

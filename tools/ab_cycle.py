@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "fused_restrict": {"AMGX_FUSED_RESTRICT": "1"},
+    "no_fused_restrict": {"AMGX_NO_FUSED_RESTRICT": "1"},
     "no_tail_kernel": {"AMGX_NO_TAIL_KERNEL": "1"},
     "no_diag_first": {"AMGX_NO_DIAG_FIRST": "1"},
 }
@@ -28,11 +28,11 @@ def main():
     p = fem.poisson_fast((nv, nv, nv))
     H = Hierarchy(Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val), p.free, p.coords, dim=3, energy=0, max_coarse_size=50)
     hs = {}
-    for inst in range(2):                      # two instances per variant: allocation placement alone moves the time by ~2 %
+    for inst in range(int(os.environ.get("AB_INSTANCES", "2"))):                      # two instances per variant: allocation placement alone moves the time by ~2 %
         for name, env in VARIANTS.items():
             for k, v in env.items():
                 os.environ[k] = v
-            if sm == "gs" and name == "fused_restrict":
+            if sm == "gs" and name == "no_fused_restrict":
                 continue
             hs[f"{name}#{inst}"] = DeviceAMGMatrix(H, sm_type=sm, device=0)
             for k in env:
