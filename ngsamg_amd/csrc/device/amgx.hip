@@ -508,16 +508,38 @@ struct Handle {
       if (M.br == 6) hipLaunchKernelGGL((bsell_spmv_kernel<6, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
       else if (M.br == 3) hipLaunchKernelGGL((bsell_spmv_kernel<3, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
       else hipLaunchKernelGGL((bsell_spmv_kernel<2, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
-    } else if (M.br == 6 && M.bc == 6) {
-      // 6x6: row-per-lane kernel; W lane groups per block row chosen from the average row length
+    } else if (M.br >= 2 && M.bc >= 2 && (EP != EP_JAC || M.br == M.bc) && (M.br == M.bc || M.nnz >= 6 * M.n_rows)) {
+      // (short rectangular rows, i.e. prolongations with <= 4 blocks per row, stay with the lane-per-block kernel: measured)
+      // row-per-lane block CSR kernel; W lane groups per block row chosen from the average row length
       const double avg = M.n_rows ? (double)M.nnz / (double)M.n_rows : 0.0;
       const int W = avg >= 48.0 ? 4 : (avg >= 20.0 ? 2 : 1);
-      const int rpw = WAVE / (6 * W);
+      const int rpw = WAVE / (M.br * W);
       const int64_t waves = (M.n_rows + rpw - 1) / rpw;
       const int grid = (int)std::max<int64_t>(1, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-      if (W == 4) hipLaunchKernelGGL((bcsr6_spmv_kernel<4, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
-      else if (W == 2) hipLaunchKernelGGL((bcsr6_spmv_kernel<2, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
-      else hipLaunchKernelGGL((bcsr6_spmv_kernel<1, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep);
+#define LAUNCH_RL(BR, BC, WW) hipLaunchKernelGGL((bcsr_rowlane_kernel<BR, BC, WW, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
+#define LAUNCH_RLW(BR, BC) { if (W == 4) LAUNCH_RL(BR, BC, 4); else if (W == 2) LAUNCH_RL(BR, BC, 2); else LAUNCH_RL(BR, BC, 1); }
+      const int key = M.br * 10 + M.bc;
+      if constexpr (EP == EP_JAC) {
+        switch (key) {
+          case 22: LAUNCH_RLW(2, 2); break;
+          case 33: LAUNCH_RLW(3, 3); break;
+          case 66: LAUNCH_RLW(6, 6); break;
+          default: throw Err("unsupported block shape");
+        }
+      } else {
+        switch (key) {
+          case 22: LAUNCH_RLW(2, 2); break;
+          case 33: LAUNCH_RLW(3, 3); break;
+          case 66: LAUNCH_RLW(6, 6); break;
+          case 36: LAUNCH_RLW(3, 6); break;
+          case 63: LAUNCH_RLW(6, 3); break;
+          case 23: LAUNCH_RLW(2, 3); break;
+          case 32: LAUNCH_RLW(3, 2); break;
+          default: throw Err("unsupported block shape " + std::to_string(M.br) + "x" + std::to_string(M.bc));
+        }
+      }
+#undef LAUNCH_RLW
+#undef LAUNCH_RL
     } else {
       const int G = std::min(M.lanes, 16) < 2 ? 2 : std::min(M.lanes, 16);
       const int grid = grid_for(M.n_rows * G);

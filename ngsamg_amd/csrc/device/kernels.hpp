@@ -302,50 +302,55 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 6x6 block CSR, row-per-lane inside the block: lane (g, r) of a block row's lane group owns scalar row r and the
-// blocks k = g, g+W, ...; it reads its 48-B row of each block as three 16-B loads, so the six lanes of a group read
-// one contiguous 288-B block and a wave streams 10 / 5 / 2 block rows (W = 1 / 2 / 4) with full cache-line use.
-// (The generic bcsrvec kernel lets ONE lane read a whole block with 36 scalar loads at a 288-B lane stride and
-// reaches only 2.7 TB/s on the 6x6 elasticity levels.)
-template <int W, int EP>
-__global__ __launch_bounds__(BLOCK) void bcsr6_spmv_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr,
-                                                           const int32_t* __restrict__ cols,
-                                                           const double* __restrict__ vals,
-                                                           const double* __restrict__ x, double* y, EpArgs ep) {
-  constexpr int LPR = 6 * W;                 // lanes per block row
+// Block CSR, ROW-PER-LANE inside the block (BR x BC blocks, BR >= 2): lane (g, r) of a block row's lane group owns
+// scalar row r and the blocks k = g, g+W, ...; it reads its BC contiguous values of each block, so the BR lanes of a
+// group read one contiguous block and a wave streams 64/(BR*W) block rows with full cache-line use.  (The generic
+// bcsrvec kernel lets ONE lane read a whole block with BR*BC scalar loads at a block-sized lane stride: 2.7 TB/s on 6x6.)
+template <int BR, int BC, int W, int EP>
+__global__ __launch_bounds__(BLOCK) void bcsr_rowlane_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ cols,
+                                                             const double* __restrict__ vals,
+                                                             const double* __restrict__ x, double* y, EpArgs ep) {
+  constexpr int LPR = BR * W;                // lanes per block row
   constexpr int RPW = WAVE / LPR;            // block rows per wave
   const int lane = threadIdx.x & (WAVE - 1);
   const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   const int rloc = lane / LPR;
-  const int g = (lane % LPR) / 6;
-  const int r = lane % 6;
+  const int g = (lane % LPR) / BR;
+  const int r = lane % BR;
   const int64_t row = wave * RPW + rloc;
   const bool active = rloc < RPW && row < n_rows;
   double acc = 0.0;
   if (active) {
     const int e = rowptr[row + 1];
     for (int k = rowptr[row] + g; k < e; k += W) {
-      const double2* __restrict__ a = reinterpret_cast<const double2*>(vals + (int64_t)k * 36 + r * 6);
-      const double2* __restrict__ xv = reinterpret_cast<const double2*>(x + (int64_t)cols[k] * 6);
-      const double2 a0 = a[0], a1 = a[1], a2 = a[2];
-      const double2 x0 = xv[0], x1 = xv[1], x2 = xv[2];
-      acc += a0.x * x0.x + a0.y * x0.y + a1.x * x1.x + a1.y * x1.y + a2.x * x2.x + a2.y * x2.y;
+      const double* __restrict__ a = vals + (int64_t)k * (BR * BC) + r * BC;
+      const double* __restrict__ xv = x + (int64_t)cols[k] * BC;
+      if ((BC & 1) == 0) {
+        // 16-byte loads: k*BR*BC*8 and r*BC*8 are multiples of 16 for even BC
+        const double2* __restrict__ a2 = reinterpret_cast<const double2*>(a);
+        const double2* __restrict__ x2 = reinterpret_cast<const double2*>(xv);
+#pragma unroll
+        for (int c = 0; c < BC / 2; ++c) { const double2 av = a2[c], xx = x2[c]; acc += av.x * xx.x + av.y * xx.y; }
+      } else {
+#pragma unroll
+        for (int c = 0; c < BC; ++c) acc += a[c] * xv[c];
+      }
     }
   }
-  if (W == 4) acc += __shfl_down(acc, 12, WAVE);
-  if (W >= 2) acc += __shfl_down(acc, 6, WAVE);
+#pragma unroll
+  for (int o = W >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o * BR, WAVE);
   // lanes with g == 0 now hold (A x)_r of their block row
-  const int64_t i = row * 6 + r;
+  const int64_t i = row * BR + r;
   double out = 0.0;
-  if (EP == EP_JAC) {
+  if (EP == EP_JAC) {           // square blocks only
     const double t = (active && g == 0) ? ep.b[i] - acc : 0.0;
-    // u_r = sum_c dinv[r][c] * t_c : fetch t_c from the six row-lanes of the group
     const int base = lane - r;
     double u = 0.0;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < BR; ++c) {
       const double tc = __shfl(t, base + c, WAVE);
-      if (active && g == 0) u += ep.dinv[row * 36 + r * 6 + c] * tc;
+      if (active && g == 0) u += ep.dinv[row * (BR * BR) + r * BR + c] * tc;
     }
     if (active && g == 0) out = ep.yin[i] + ep.s * u;
   } else if (active && g == 0) {
