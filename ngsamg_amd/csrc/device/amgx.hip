@@ -630,17 +630,20 @@ struct Handle {
       } else {
         const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
         if (r1 == r0) continue;
-        const int G = std::max(2, std::min(L.A.lanes, 16));
-        const int grid = grid_for((int64_t)(r1 - r0) * G);
-#define LAUNCH_GS(BS, GG) hipLaunchKernelGGL((bgs_color_kernel<BS, GG>), dim3(grid), dim3(BLOCK), 0, stream, r0, r1, g.rowlist.p, L.A.rowptr.p, L.A.col.p, L.A.val.p, L.dinv.p, b, x)
-#define LAUNCH_GSG(BS) switch (G) { case 2: LAUNCH_GS(BS, 2); break; case 4: LAUNCH_GS(BS, 4); break; case 8: LAUNCH_GS(BS, 8); break; default: LAUNCH_GS(BS, 16); break; }
+        const double avg = L.A.n_rows ? (double)L.A.nnz / (double)L.A.n_rows : 0.0;
+        const int W = avg >= 48.0 ? 4 : (avg >= 20.0 ? 2 : 1);
+        const int rpw = WAVE / (L.bs * W);
+        const int64_t waves = ((int64_t)(r1 - r0) + rpw - 1) / rpw;
+        const int grid = (int)std::max<int64_t>(1, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+#define LAUNCH_GS(BS, WW) hipLaunchKernelGGL((bgs_color_kernel<BS, WW>), dim3(grid), dim3(BLOCK), 0, stream, r0, r1, g.rowlist.p, L.A.rowptr.p, L.A.col.p, L.A.val.p, L.dinv.p, b, x)
+#define LAUNCH_GSW(BS) { if (W == 4) LAUNCH_GS(BS, 4); else if (W == 2) LAUNCH_GS(BS, 2); else LAUNCH_GS(BS, 1); }
         switch (L.bs) {
-          case 2: LAUNCH_GSG(2); break;
-          case 3: LAUNCH_GSG(3); break;
-          case 6: LAUNCH_GSG(6); break;
+          case 2: LAUNCH_GSW(2); break;
+          case 3: LAUNCH_GSW(3); break;
+          case 6: LAUNCH_GSW(6); break;
           default: throw Err("unsupported block size for GS");
         }
-#undef LAUNCH_GSG
+#undef LAUNCH_GSW
 #undef LAUNCH_GS
       }
       HIPCHK(hipGetLastError());

@@ -398,8 +398,9 @@ __global__ __launch_bounds__(BLOCK) void gs_upper_residual_kernel(int n_slices, 
   if (row >= 0 && (lane % G) == 0) r[row] = -acc;
 }
 
-// multicolour Gauss-Seidel, block BS x BS: CSR rows through a colour-major row list, G lanes per row
-template <int BS, int G>
+// multicolour Gauss-Seidel, block BS x BS: CSR rows through a colour-major row list, row-per-lane inside the block
+// (lane (g, r) owns scalar row r and the blocks k = g, g+W, ... of its block row, like bcsr_rowlane_kernel)
+template <int BS, int W>
 __global__ __launch_bounds__(BLOCK) void bgs_color_kernel(int list_begin, int list_end,
                                                           const int32_t* __restrict__ rowlist,
                                                           const int32_t* __restrict__ rowptr,
@@ -407,45 +408,38 @@ __global__ __launch_bounds__(BLOCK) void bgs_color_kernel(int list_begin, int li
                                                           const double* __restrict__ vals,
                                                           const double* __restrict__ dinv,
                                                           const double* __restrict__ b, double* x) {
-  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t q = list_begin + t / G;
-  const int sub = (int)(t % G);
-  const bool active = q < list_end;
+  constexpr int LPR = BS * W;
+  constexpr int RPW = WAVE / LPR;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int rloc = lane / LPR;
+  const int g = (lane % LPR) / BS;
+  const int r = lane % BS;
+  const int64_t q = list_begin + wave * RPW + rloc;
+  const bool active = rloc < RPW && q < list_end;
   const int row = active ? rowlist[q] : 0;
-  double acc[BS];
-#pragma unroll
-  for (int r = 0; r < BS; ++r) acc[r] = 0.0;
+  double acc = 0.0;
   if (active) {
     const int e = rowptr[row + 1];
-    for (int k = rowptr[row] + sub; k < e; k += G) {
-      const double* __restrict__ a = vals + (int64_t)k * (BS * BS);
+    for (int k = rowptr[row] + g; k < e; k += W) {
+      const double* __restrict__ a = vals + (int64_t)k * (BS * BS) + r * BS;
       const double* xv = x + (int64_t)cols[k] * BS;
-      double xr[BS];
 #pragma unroll
-      for (int c = 0; c < BS; ++c) xr[c] = xv[c];
-#pragma unroll
-      for (int r = 0; r < BS; ++r)
-#pragma unroll
-        for (int c = 0; c < BS; ++c) acc[r] += a[r * BS + c] * xr[c];
+      for (int c = 0; c < BS; ++c) acc += a[c] * xv[c];
     }
   }
 #pragma unroll
-  for (int r = 0; r < BS; ++r)
+  for (int o = W >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o * BS, WAVE);
+  const int64_t i = (int64_t)row * BS + r;
+  const double t = (active && g == 0) ? b[i] - acc : 0.0;
+  const int base = lane - r;
+  double u = 0.0;
 #pragma unroll
-    for (int o = G >> 1; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, G);
-  if (active && sub == 0) {
-    double tt[BS];
-#pragma unroll
-    for (int r = 0; r < BS; ++r) tt[r] = b[(int64_t)row * BS + r] - acc[r];
-    const double* __restrict__ d = dinv + (int64_t)row * (BS * BS);
-#pragma unroll
-    for (int r = 0; r < BS; ++r) {
-      double u = 0.0;
-#pragma unroll
-      for (int c = 0; c < BS; ++c) u += d[r * BS + c] * tt[c];
-      x[(int64_t)row * BS + r] += u;
-    }
+  for (int c = 0; c < BS; ++c) {
+    const double tc = __shfl(t, base + c, WAVE);
+    if (active && g == 0) u += dinv[(int64_t)row * (BS * BS) + r * BS + c] * tc;
   }
+  if (active && g == 0) x[i] += u;
 }
 
 // ---------------------------------------------------------------------------------------------------
