@@ -571,8 +571,16 @@ class DistributedAMG:
                 b["r"].append(ops.zeros(s.n))
                 b.setdefault("xext", []).append(ops.zeros(next_) if self.sm_type == "gs" else None)
                 b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type == "gs" else None)
-                b["send"].append({q: ops.zeros(idx.size) for q, idx in s.send.items()})
-                b["sidx"].append({q: ops.index(idx) for q, idx in s.send.items()})
+                # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
+                peers = sorted(s.send)
+                allidx = np.concatenate([s.send[q] for q in peers]) if peers else np.empty(0, dtype=np.int64)
+                sbuf = ops.zeros(allidx.size)
+                off, views = 0, {}
+                for q in peers:
+                    views[q] = sbuf[off:off + s.send[q].size]
+                    off += s.send[q].size
+                b["send"].append(views)
+                b["sidx"].append((ops.index(allidx), sbuf))
             sk = self.dist_levels[self.k][i]
             b["bk"] = ops.zeros(max(self.counts))
             b["bglob"] = ops.zeros(int(self.offs[-1]))
@@ -585,8 +593,9 @@ class DistributedAMG:
         for i, ops in enumerate(self.ops):
             s, b = self.dist_levels[l][i], self.buf[i]
             vec = b[key][l]
-            for q, idx in b["sidx"][l].items():
-                ops.gather(vec, idx, b["send"][l][q])
+            idx, sbuf = b["sidx"][l]
+            if sbuf.numel():
+                ops.gather(vec, idx, sbuf)
             sends.append(b["send"][l])
             recvs.append({q: vec[s.n + a:s.n + e] for q, (a, e) in s.recv_seg.items()})
         self.comm.halo(sends, recvs)
