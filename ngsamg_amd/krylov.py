@@ -6,10 +6,13 @@ from __future__ import annotations
 
 
 class CGSolver:
-    def __init__(self, mat, pre=None, tol=1e-12, maxsteps=100, callback=None):
+    def __init__(self, mat, pre=None, tol=1e-12, maxsteps=100, callback=None, check_every=1):
         """mat: DeviceAMGMatrix (its level-0 matrix is the operator) or any object with MatVec(0, x, y);
-        pre: object with Mult(b, x) or None."""
+        pre: object with Mult(b, x) or None.
+        check_every: the scalars (alpha, beta, error) live on the device; the host looks at the error only every
+        `check_every` iterations (1 = the reference's behaviour: test after every iteration)."""
         self.mat, self.pre, self.tol, self.maxsteps, self.callback = mat, pre, tol, maxsteps, callback
+        self.check_every = max(1, int(check_every))
         self.errors = []
         self.iterations = 0
 
@@ -26,31 +29,44 @@ class CGSolver:
         else:
             w.copy_(d)
         s = w.clone()
-        wdn = torch.dot(w, d).item()
-        err0 = abs(wdn) ** 0.5
+        wdn = torch.dot(w, d)                        # 0-dim device tensors from here on: no host round trips
+        errs = torch.zeros(self.maxsteps + 1, dtype=b.dtype, device=b.device)
+        errs[0] = wdn.abs().sqrt()
+        err0 = float(errs[0].item())
         self.errors = [err0]
         self.iterations = 0
         if err0 == 0.0:
             return x
+        done = 0
         for it in range(1, self.maxsteps + 1):
             self.mat.MatVec(0, s, w)
             wd = wdn
-            as_s = torch.dot(s, w).item()
-            alpha = wd / as_s
-            x.add_(s, alpha=alpha)
-            d.add_(w, alpha=-alpha)
+            alpha = wd / torch.dot(s, w)
+            x.addcmul_(s, alpha)                     # x += alpha s
+            d.addcmul_(w, -alpha)                    # d -= alpha A s
             if self.pre is not None:
                 self.pre.Mult(d, w)
             else:
                 w.copy_(d)
-            wdn = torch.dot(w, d).item()
+            wdn = torch.dot(w, d)
             beta = wdn / wd
             s.mul_(beta).add_(w)
-            err = abs(wdn) ** 0.5
-            self.errors.append(err)
+            errs[it] = wdn.abs().sqrt()
             self.iterations = it
-            if self.callback:
-                self.callback(it, err)
-            if err <= self.tol * err0:
-                break
+            if it % self.check_every == 0 or it == self.maxsteps:
+                host = errs[done + 1:it + 1].cpu().tolist()
+                stop = None
+                for k, e in enumerate(host):
+                    self.errors.append(e)
+                    if self.callback:
+                        self.callback(done + 1 + k, e)
+                    if e <= self.tol * err0 and stop is None:
+                        stop = done + 1 + k
+                done = it
+                if stop is not None:
+                    # iterations beyond the first converged one (only possible with check_every > 1) are harmless extra
+                    # work; report the count at which the tolerance was met
+                    self.errors = self.errors[:stop + 1]
+                    self.iterations = stop
+                    break
         return x
