@@ -30,7 +30,7 @@ import ctypes as C
 import numpy as np
 import scipy.sparse as sp
 
-from . import _lib, fem
+from . import _lib
 from ._lib import Matrix, NgsAMGError
 from .hierarchy import Hierarchy, Level
 
@@ -445,7 +445,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
     return nxt
 
 
-def _dinv_ext(comm, states, omega_unused=None):
+def _dinv_ext(comm, states):
     dins = []
     for s in states:
         d = s.A[:, :s.n].diagonal()

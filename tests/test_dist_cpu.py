@@ -1,7 +1,6 @@
 """Rank-partitioned V-cycle on CPU: loopback (virtual ranks in one process) and world_size-2 gloo processes.
 The distributed result must equal the serial oracle on the assembled global hierarchy."""
 import os
-import sys
 
 import numpy as np
 import pytest

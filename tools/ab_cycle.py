@@ -3,9 +3,7 @@
 gpurun land on different physical GPUs and differ by several per cent).  python tools/ab_cycle.py [nv]"""
 import os
 import sys
-import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +17,6 @@ VARIANTS = {
 
 
 def main():
-    import torch
     from ngsamg_amd import fem, Matrix
     from ngsamg_amd.hierarchy import Hierarchy
     from ngsamg_amd.device import DeviceAMGMatrix
