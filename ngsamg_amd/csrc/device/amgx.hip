@@ -132,6 +132,7 @@ struct DevLevel {
   DevBuf<int32_t> t_rowlist, t_cptr;    // colour-major row list of a Gauss-Seidel tail level
   DevRestrict R;
   DevRestrict RF;                       // chunk-local P^T for sell_pre_restrict_kernel (fused pre-smoothing + restriction)
+  int fused_block = 1024;               // workgroup size = rows per chunk of the fused kernel
   DevMatrix A, P, PT;
   DevMatrix Apre;                       // scalar Jacobi levels: A * diag(omega * dinv), see EP_PRE in kernels.hpp
   DevBuf<double> dinv;
@@ -750,10 +751,18 @@ struct Handle {
     DevLevel& L = lev[l];
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty()) {
       const DevRestrict& R = L.RF;
-      const int grid = (L.Apre.n_slices + (FUSED_BLOCK / WAVE) - 1) / (FUSED_BLOCK / WAVE);
+      const int FB = L.fused_block;
+      const int grid = (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
       if (grid != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
-      hipLaunchKernelGGL(sell_pre_restrict_kernel, dim3(grid), dim3(FUSED_BLOCK), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                         L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+      if (FB == 256)
+        hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+      else if (FB == 512)
+        hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+      else
+        hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
       hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
@@ -1041,7 +1050,11 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
         if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 && s.A.n_rows == s.A.n_cols &&
             s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
-          build_restrict(s.P, L.RF, FUSED_CHUNK, FUSED_MAX_ENTRIES);
+        {
+          L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
+          if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
+          build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
+        }
       }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);

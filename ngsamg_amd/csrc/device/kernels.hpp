@@ -484,10 +484,8 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 // LDS, multiplied with the chunk-local transpose of P (entries: fp64 weight + 16-bit local row) and reduced per
 // (chunk, coarse column) slot; restrict_sum_kernel then adds the ~10 partial sums of every coarse row in a fixed
 // order.  Replaces: 80 MB write of r + the P^T gather kernel (134 us at cfg 2, TA/L2-bound).
-constexpr int FUSED_BLOCK = 1024;
-constexpr int FUSED_CHUNK = 1024;
-constexpr int FUSED_MAX_ENTRIES = 4096;
-
+// FB = workgroup size = rows per chunk (1024 or 512); 4 entries of P per row at most
+template <int FUSED_BLOCK>
 __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
                                                                         double omega, double* __restrict__ x, double* r_out,
@@ -495,7 +493,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
                                                                         const int32_t* __restrict__ slot_ptr,
                                                                         const double* __restrict__ w, const uint16_t* __restrict__ fi,
                                                                         double* __restrict__ part) {
-  __shared__ double rl[FUSED_CHUNK];
+  constexpr int FUSED_MAX_ENTRIES = 4 * FUSED_BLOCK;
+  __shared__ double rl[FUSED_BLOCK];
   __shared__ double pr[FUSED_MAX_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
   const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));

@@ -10,9 +10,9 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "no_fused_restrict": {"AMGX_NO_FUSED_RESTRICT": "1"},
-    "no_tail_kernel": {"AMGX_NO_TAIL_KERNEL": "1"},
-    "no_diag_first": {"AMGX_NO_DIAG_FIRST": "1"},
+
+    "fused_block_256": {"AMGX_FUSED_BLOCK": "256"},
+    "fused_block_1024": {"AMGX_FUSED_BLOCK": "1024"},
 }
 
 
