@@ -457,6 +457,7 @@ struct Handle {
   DevBuf<double> coarse_inv;
   hipStream_t own_stream = nullptr, stream = nullptr;
   bool use_graph = true;
+  int ep_nt = 1;                        // non-temporal epilogue operands (AMGX_NO_EP_NT=1 disables)
   int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
   int tail_ops = 0;
   DevBuf<TailOp> tail_prog;
@@ -571,14 +572,14 @@ struct Handle {
     HIPCHK(hipGetLastError());
   }
 
-  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr}); }
-  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr}); }
+  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr, 0}); }
+  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr, 0}); }
   // y = yin + s * M x
-  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr}); }
+  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr, 0}); }
   // xout = xin + omega * dinv * (b - A xin)
   void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout) {
     if (xin == xout) throw Err("jacobi_fused: in-place update is not allowed");
-    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr});
+    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr, ep_nt});
   }
 
   void zero(double* v, int64_t n) { if (n) HIPCHK(hipMemsetAsync(v, 0, n * sizeof(double), stream)); }
@@ -713,7 +714,7 @@ struct Handle {
   void pre_smooth(DevLevel& L, double* x, const double* b, double* r) {
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Apre.empty()) {
       // one pass: r = b - A' b, x = omega * Dinv * b   (A' = A * omega*Dinv built at create time)
-      spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x});
+      spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x, ep_nt});
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
       residual(L.A, x, b, r);              // r = b - A x
@@ -756,13 +757,13 @@ struct Handle {
       if (grid != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
       if (FB == 256)
         hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, ep_nt, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
       else if (FB == 512)
         hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, ep_nt, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
       else
         hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, ep_nt, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
       hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
@@ -1000,6 +1001,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
   h->cycle = d->cycle;
   h->clev = d->clev;
   h->use_graph = d->use_graph != 0;
+  h->ep_nt = std::getenv("AMGX_NO_EP_NT") ? 0 : 1;   // A/B: -0.4 % cycle time (profiles/r01/restrict_fused.txt)
   if (d->cycle < 0 || d->cycle > 2) throw Err("amgx_create: unknown cycle");
   HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
@@ -1092,13 +1094,13 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     }
     if (T > 0) {
       std::vector<TailOp> prog;
-      const EpArgs none{nullptr, nullptr, nullptr, 0.0, nullptr};
+      const EpArgs none{nullptr, nullptr, nullptr, 0.0, nullptr, 0};
       auto spmv = [&](int ep, const DevCsr& M, int n, const double* x, double* y, EpArgs a) {
         prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0});
       };
       auto gs = [&](DevLevel& V, int nc, int backward) {
         prog.push_back(TailOp{T_GS, 0, (int)V.n, V.tA.rowptr.p, V.tA.col.p, V.tA.val.p, nullptr, V.x.p,
-                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr}, V.t_rowlist.p, V.t_cptr.p, nc, backward});
+                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward});
       };
       for (int l = T; l + 1 < L; ++l) {
         const amgx_level_desc& s = d->levels[l];
@@ -1122,11 +1124,11 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       for (int l = T; l + 1 < L; ++l) {       // down
         DevLevel& V = h->lev[l];
         if (V.sm_type == AMGX_SM_JACOBI) {     // r = b - A'b, x = omega*Dinv*b
-          spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p});
+          spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p, 0});
         } else {                               // x = 0; forward sweep; r = b - A x
           prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0});
           gs(V, d->levels[l].n_colors, 0);
-          spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr});
+          spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr, 0});
         }
         spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, none);   // b_{l+1} = P^T r
       }
@@ -1135,10 +1137,10 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       for (int l = L - 2; l >= T; --l) {      // up
         DevLevel& V = h->lev[l];
         if (V.sm_type == AMGX_SM_JACOBI) {     // tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)
-          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.tmp.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
-          spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr});
+          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.tmp.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr, 0});
+          spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr, 0});
         } else {                               // x += P x_{l+1} ; backward sweep
-          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.x.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr});
+          spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.x.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr, 0});
           gs(V, d->levels[l].n_colors, 1);
         }
       }

@@ -46,6 +46,7 @@ struct EpArgs {
   const double* dinv;
   double s;      // AXPY factor or Jacobi omega
   double* y2;    // second output of EP_PRE
+  int nt;        // 1: stream the epilogue's own-row operands / results non-temporally (read / written once per cycle)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
@@ -53,6 +54,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int xcd = bid & 7, idx = bid >> 3;
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
+
+template <class T>
+__device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 
 // ---------------------------------------------------------------------------------------------------
 // scalar epilogue
@@ -62,11 +66,14 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
   if (EP == EP_MULT) y[row] = acc;
   else if (EP == EP_RES) y[row] = ep.b[row] - acc;
   else if (EP == EP_AXPY) y[row] = ep.yin[row] + ep.s * acc;
-  else if (EP == EP_JAC) y[row] = (have_xd ? xd : ep.yin[row]) + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
-  else {
+  else if (EP == EP_JAC) {
+    if (ep.nt) __builtin_nontemporal_store((have_xd ? xd : ep.yin[row]) + ep.s * (ld_nt(ep.dinv + row) * (ld_nt(ep.b + row) - acc)), y + row);
+    else y[row] = (have_xd ? xd : ep.yin[row]) + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
+  } else {
     const double bi = have_xd ? xd : ep.b[row];
     y[row] = bi - acc;
-    ep.y2[row] = ep.s * (ep.dinv[row] * bi);
+    if (ep.nt) __builtin_nontemporal_store(ep.s * (ld_nt(ep.dinv + row) * bi), ep.y2 + row);
+    else ep.y2[row] = ep.s * (ep.dinv[row] * bi);
   }
 }
 
@@ -86,9 +93,6 @@ struct SellMat {
   int rowrel;
   int diag_first;             // G == 1 only: entry 0 of every row is its diagonal, so the gathered x[row] comes for free
 };
-
-template <class T>
-__device__ __forceinline__ T ld_nt(const T* p) { return __builtin_nontemporal_load(p); }
 
 // dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
 // xd (optional): receives the x value gathered for entry 0 of this lane's row (meaningful when M.diag_first)
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 template <int FUSED_BLOCK>
 __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
-                                                                        double omega, double* __restrict__ x, double* r_out,
+                                                                        double omega, int nt, double* __restrict__ x, double* r_out,
                                                                         const int32_t* __restrict__ chunk_slot,
                                                                         const int32_t* __restrict__ slot_ptr,
                                                                         const double* __restrict__ w, const uint16_t* __restrict__ fi,
@@ -521,7 +525,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     if (row < n_rows) {
       const double bi = b[row];
       r = bi - acc;
-      x[row] = omega * (dinv[row] * bi);
+      if (nt) __builtin_nontemporal_store(omega * (ld_nt(dinv + row) * bi), x + row);
+      else x[row] = omega * (dinv[row] * bi);
       if (r_out) r_out[row] = r;
     }
   }

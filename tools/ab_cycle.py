@@ -11,8 +11,7 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     "default": {},
 
-    "fused_block_256": {"AMGX_FUSED_BLOCK": "256"},
-    "fused_block_1024": {"AMGX_FUSED_BLOCK": "1024"},
+    "no_ep_nt": {"AMGX_NO_EP_NT": "1"},
 }
 
 
