@@ -139,8 +139,13 @@ def main():
         ge.build_host()
         ge.build_hip()
     dist = None
-    if world > 1:
+    force_dist = bool(int(os.environ.get("NGSAMG_FORCE_DIST", "0")))     # world_size 1 through the distributed code path
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # NGSAMG_DIST_BACKEND=gloo is a rehearsal mode (several ranks may share one GPU, halos staged through the host)
         backend = os.environ.get("NGSAMG_DIST_BACKEND", "nccl")
         ndev = max(1, torch.cuda.device_count())
@@ -163,7 +168,7 @@ def main():
     from ngsamg_amd.device import DeviceAMGMatrix, vcycle_bytes, matrix_bytes
 
     nv = args.nv
-    if world > 1:
+    if world > 1 or force_dist:
         run_distributed(args, torch, dist, world, rank, device, nv)
         return
 
