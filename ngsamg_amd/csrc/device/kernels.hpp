@@ -46,8 +46,11 @@ struct EpArgs {
   const double* dinv;
   double s;      // AXPY factor or Jacobi omega
   double* y2;    // second output of EP_PRE
-  int nt;        // 1: stream the epilogue's own-row operands / results non-temporally (read / written once per cycle)
+  int nt;        // bit 0: stream the epilogue's own-row operands / results non-temporally (read / written once per cycle)
+                 // bit 1 (EP_PRE): second output is z = x + omega*Dinv*r, the pre-smoothed iterate smoothed once more
+                 //        without a coarse correction (cycle with the post-smoothing folded into the prolongation)
 };
+constexpr int EPF_NT = 1, EPF_FOLD = 2;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7;
@@ -67,13 +70,17 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
   else if (EP == EP_RES) y[row] = ep.b[row] - acc;
   else if (EP == EP_AXPY) y[row] = ep.yin[row] + ep.s * acc;
   else if (EP == EP_JAC) {
-    if (ep.nt) __builtin_nontemporal_store((have_xd ? xd : ep.yin[row]) + ep.s * (ld_nt(ep.dinv + row) * (ld_nt(ep.b + row) - acc)), y + row);
+    if (ep.nt & EPF_NT) __builtin_nontemporal_store((have_xd ? xd : ep.yin[row]) + ep.s * (ld_nt(ep.dinv + row) * (ld_nt(ep.b + row) - acc)), y + row);
     else y[row] = (have_xd ? xd : ep.yin[row]) + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
   } else {
     const double bi = have_xd ? xd : ep.b[row];
-    y[row] = bi - acc;
-    if (ep.nt) __builtin_nontemporal_store(ep.s * (ld_nt(ep.dinv + row) * bi), ep.y2 + row);
-    else ep.y2[row] = ep.s * (ep.dinv[row] * bi);
+    const double r = bi - acc;
+    y[row] = r;
+    const double di = (ep.nt & EPF_NT) ? ld_nt(ep.dinv + row) : ep.dinv[row];
+    double xi = ep.s * (di * bi);
+    if (ep.nt & EPF_FOLD) xi += ep.s * (di * r);
+    if (ep.nt & EPF_NT) __builtin_nontemporal_store(xi, ep.y2 + row);
+    else ep.y2[row] = xi;
   }
 }
 
@@ -525,8 +532,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     if (row < n_rows) {
       const double bi = b[row];
       r = bi - acc;
-      if (nt) __builtin_nontemporal_store(omega * (ld_nt(dinv + row) * bi), x + row);
-      else x[row] = omega * (dinv[row] * bi);
+      const double di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row];
+      double xi = omega * (di * bi);
+      if (nt & EPF_FOLD) xi += omega * (di * r);
+      if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);
+      else x[row] = xi;
       if (r_out) r_out[row] = r;
     }
   }

@@ -10,8 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-
-    "no_ep_nt": {"AMGX_NO_EP_NT": "1"},
+    "q_csr": {"AMGX_Q_MAX_PAD": "1.0"},
 }
 
 
