@@ -127,8 +127,10 @@ int amgx_coarse_solve(amgx_handle h, const double* rhs, double* x, int flags);
 /* GetNLevels / GetNDof / GetBlockSize (python_amg.hpp:15-103) */
 int amgx_n_levels(amgx_handle h);
 int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* nnz);
-/* device-format report per level matrix: which = 0 A, 1 P, 2 PT; fmt: 0 CSR-vector, 1 sliced-ELL, 2 block sliced-ELL;
- * stored_entries counts padding (for the traffic model in DESIGN.md) */
+/* device-format report per level matrix: which = 0 A, 1 P, 2 PT, 3 A' = A*omega*Dinv (pre-smoothing image),
+ * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation); fmt: -1 not built, 0 CSR-vector,
+ * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows; stored_entries counts padding
+ * (for the traffic model in DESIGN.md) */
 int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);
 
 /* bytes of matrix data (values, indices, pointers, in the device encoding) that one SpMV with this matrix
@@ -140,7 +142,9 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *   op = 0: residual SpMV  r = b - A_level x      (the dominant kernel of the Jacobi V-cycle)
  *   op = 1: fused Jacobi post-smooth  x' = x + omega*dinv*(b - A_level x)
  *   op = 2: restriction  b_c = P^T r      op = 3: prolongation  x += P x_c
- *   op = 4: one whole cycle (amgx_apply on internal vectors) */
+ *   op = 4: one whole cycle (amgx_apply on internal vectors)
+ *   op = 5: pre-smoothing + restriction as the V-cycle runs it on this level (fused / folded where built)
+ *   op = 6: coarse-grid correction + post-smoothing as the V-cycle runs it on this level */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
 
 #ifdef __cplusplus

@@ -78,6 +78,10 @@ struct DevMatrix {
     DevBuf<uint16_t> col16;
     DevBuf<double> val;
     int rowrel = 0, diag_first = 0;
+    // windowed form (sell_win_spmv_kernel): inside every window of `win` consecutive rows the rows are stored in order
+    // of decreasing length (slice padding 1.42 -> 1.08 on Q at cfg 2); rowloc[slot] = row of the slot inside its window
+    int win = 0;
+    DevBuf<uint16_t> rowloc;
     SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first}; }
   } sell;
   struct BSell {                       // block SELL (kernels.hpp, BSellMat)
@@ -369,7 +373,7 @@ static void check_matrix(const amgx_matrix& A, const char* what) {
 }
 
 static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true, bool rowrel_ok = false, bool keep_csr = false,
-                          double max_pad = 1.35) {
+                          double max_pad = 1.35, int win = 0) {
   check_matrix(A, what);
   D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = A.br; D.bc = A.bc;
   D.nnz = A.rowptr[A.n_rows];
@@ -385,7 +389,29 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
     for (int g = G; g >= 1; g >>= 1)
       if ((double)sell_stored(A, g) <= max_pad * (double)D.nnz) { sellG = g; break; }
   }
-  if (sellG) {
+  // one thread per row with ragged rows: length-sorted windows instead of padding every slice to its longest row
+  const bool windowed = win > 0 && sellG == 1 && (double)sell_stored(A, 1) > 1.10 * (double)D.nnz && !std::getenv("AMGX_NO_SELL_WINDOW");
+  if (windowed) {
+    std::vector<int32_t> rows((size_t)A.n_rows);
+    std::vector<uint16_t> rowloc((size_t)A.n_rows);
+    for (int64_t w0 = 0; w0 < A.n_rows; w0 += win) {
+      const int64_t w1 = std::min<int64_t>(A.n_rows, w0 + win);
+      for (int64_t i = w0; i < w1; ++i) rows[i] = (int32_t)i;
+      std::stable_sort(rows.begin() + w0, rows.begin() + w1, [&](int32_t a, int32_t b) {
+        return A.rowptr[a + 1] - A.rowptr[a] > A.rowptr[b + 1] - A.rowptr[b]; });
+      for (int64_t i = w0; i < w1; ++i) rowloc[i] = (uint16_t)(rows[i] - w0);
+    }
+    HostSell S;
+    build_sell(A, rows.data(), A.n_rows, false, 1, S, false);
+    D.fmt = FMT_SELL;
+    D.lanes = 1;
+    D.n_slices = (int)(S.slice_ptr.size() - 1);
+    D.stored = S.slice_ptr.back() & ~(int64_t)63;
+    D.stream_bytes = S.stream_bytes + 2 * A.n_rows;
+    upload_sell(S, D.sell);
+    D.sell.win = win;
+    D.sell.rowloc.upload(rowloc);
+  } else if (sellG) {
     HostSell S;
     build_sell(A, nullptr, A.n_rows, rowrel_ok && A.n_cols >= A.n_rows, sellG, S, rowrel_ok);
     D.fmt = FMT_SELL;
@@ -483,7 +509,11 @@ struct Handle {
   template <int EP>
   void spmv_ep(const DevMatrix& M, const double* x, double* y, const EpArgs& ep) {
     if (M.n_rows == 0) return;
-    if (M.fmt == FMT_SELL) {
+    if (M.fmt == FMT_SELL && M.sell.win) {
+      if (M.sell.win != SELL_WIN) throw Err("windowed SELL: unexpected window size");
+      const int grid = (int)((M.n_rows + SELL_WIN - 1) / SELL_WIN);
+      hipLaunchKernelGGL((sell_win_spmv_kernel<SELL_WIN, EP>), dim3(grid), dim3(SELL_WIN), 0, stream, M.n_rows, M.sell.view(), M.sell.rowloc.p, x, y, ep);
+    } else if (M.fmt == FMT_SELL) {
       const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
 #define LAUNCH_SELL(G) hipLaunchKernelGGL((sell_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.sell.view(), x, y, ep)
       switch (M.lanes) {
@@ -1147,7 +1177,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
             Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
             double qpad = 1.6;
             if (const char* e = std::getenv("AMGX_Q_MAX_PAD")) qpad = std::atof(e);
-            upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad);
+            upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
           }
         }
       }
@@ -1514,8 +1544,10 @@ int amgx_level_info(amgx_handle hh, int level, int64_t* n, int32_t* bs, int64_t*
 int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t* stored, int32_t* lanes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matrix_info: level out of range");
-    const amgx::DevMatrix& M = which == 0 ? h.lev[level].A : (which == 1 ? h.lev[level].P : h.lev[level].PT);
-    if (fmt) *fmt = M.fmt;
+    if (which < 0 || which > 4) throw amgx::Err("matrix query: which must be 0..4");
+    const amgx::DevLevel& LV = h.lev[level];
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : LV.Q;
+    if (fmt) *fmt = M.empty() ? -1 : ((M.fmt == amgx::FMT_SELL && M.sell.win) ? 3 : M.fmt);
     if (stored) *stored = M.stored;
     if (lanes) *lanes = M.lanes;
   });
@@ -1524,7 +1556,9 @@ int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t
 int amgx_matrix_stream_bytes(amgx_handle hh, int level, int which, int64_t* bytes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels() || !bytes) throw amgx::Err("amgx_matrix_stream_bytes: bad arguments");
-    const amgx::DevMatrix& M = which == 0 ? h.lev[level].A : (which == 1 ? h.lev[level].P : h.lev[level].PT);
+    if (which < 0 || which > 4) throw amgx::Err("matrix query: which must be 0..4");
+    const amgx::DevLevel& LV = h.lev[level];
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : LV.Q;
     *bytes = M.stream_bytes;
   });
 }
@@ -1535,7 +1569,7 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
     if (reps < 1 || !avg_ms) throw amgx::Err("amgx_time_op: bad arguments");
     amgx::DevLevel& L = h.lev[level];
     const bool has_c = level + 1 < h.n_levels();
-    if ((op == 2 || op == 3) && !has_c) throw amgx::Err("amgx_time_op: no transfer on the coarsest level");
+    if ((op == 2 || op == 3 || op == 5 || op == 6) && !has_c) throw amgx::Err("amgx_time_op: no transfer on the coarsest level");
     if (op == 1 && (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI)) throw amgx::Err("amgx_time_op: level has no Jacobi smoother");
     auto launch = [&]() {
       switch (op) {
@@ -1544,6 +1578,8 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
         case 2: h.transfer_f2c(level, L.res.p, h.lev[level + 1].rhs.p); break;
         case 3: h.mult_add(L.P, 1.0, h.lev[level + 1].x.p, L.x.p, L.tmp.p); break;
         case 4: h.run_cycle(h.lev[0].x.p, h.lev[0].rhs.p, true); break;
+        case 5: h.pre_smooth_restrict(level, L.x.p, L.rhs.p, L.res.p, h.lev[level + 1].rhs.p, h.folded(L)); break;
+        case 6: h.post_smooth(level, L.x.p, L.rhs.p, L.res.p, h.lev[level + 1].x.p, h.folded(L)); break;
         default: throw amgx::Err("amgx_time_op: unknown op");
       }
     };

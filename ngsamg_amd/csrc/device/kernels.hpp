@@ -170,6 +170,23 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
   if ((lane % G) == 0 && row < n_rows) store_scalar<EP>(row, acc, y, ep, use_xd, xd);
 }
 
+// Windowed SELL, one thread per row: a workgroup owns WB consecutive rows, stored in order of decreasing length
+// (host: upload_matrix), so that the 64 rows of a slice have (nearly) the same length.  The row sums go through LDS
+// back to natural order, so the epilogue's own-row reads and the store stay coalesced.
+constexpr int SELL_WIN = 512;
+template <int WB, int EP>
+__global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, SellMat M, const uint16_t* __restrict__ rowloc,
+                                                           const double* __restrict__ x, double* y, EpArgs ep) {
+  __shared__ double buf[WB];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (WB / WAVE) + (threadIdx.x >> 6));
+  const int64_t slot = (int64_t)s * WAVE + lane;
+  if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, x);
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * WB + threadIdx.x;
+  if (row < n_rows) store_scalar<EP>(row, buf[threadIdx.x], y, ep);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // CSR-vector, scalar: G lanes per row
 template <int G, int EP>

@@ -290,6 +290,41 @@ def test_fused_presmooth_restriction_matches_oracle(monkeypatch, cycle):
     assert _rel(y, x) < 1e-13
 
 
+def test_folded_post_smoothing_matches_literal_sequence_and_oracle(monkeypatch):
+    """V-cycle with the Jacobi post-smoothing folded into the prolongation (x' = z + Q x_c, Q = (I - w Dinv A) P) against
+    the literal kernel sequence (AMGX_NO_FOLD) and the oracle; Q in every device format it can take."""
+    from oracle.pyoracle import Oracle
+    p, H = poisson_case((23, 22, 21), "right|top", 20)
+    b = rhs(p, 5)
+    ref = Oracle(H.levels, sm_type="jacobi").apply(b)
+    seen = set()
+    for env in ({}, {"AMGX_SELL_MAX_LANES": "1"}, {"AMGX_SELL_MAX_LANES": "1", "AMGX_NO_SELL_WINDOW": "1"},
+                {"AMGX_Q_MAX_PAD": "1.0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = _dev(H, sm_type="jacobi")
+        seen.add(dev.matrix_info(0, "Q")["fmt"])
+        x = np.full(p.n, np.nan)
+        dev.Mult(b, x)
+        assert _rel(x, ref) < 1e-12, env
+        xd = np.full(p.n, np.nan)          # direct launches instead of graph replay
+        _dev(H, sm_type="jacobi", use_graph=False).Mult(b, xd)
+        assert _rel(xd, x) == 0.0
+        for k in env:
+            monkeypatch.delenv(k)
+    assert {"sellwin", "sell", "csrvec"} <= seen, seen
+    monkeypatch.setenv("AMGX_NO_FOLD", "1")
+    lit = _dev(H, sm_type="jacobi")
+    assert lit.matrix_info(0, "Q")["fmt"] is None
+    y = np.empty(p.n)
+    lit.Mult(b, y)
+    assert _rel(y, ref) < 1e-12 and _rel(y, x) < 1e-13
+    # other cycles never fold (their post-smoothing is not the last operation on the level)
+    monkeypatch.delenv("AMGX_NO_FOLD")
+    w = _dev(H, sm_type="jacobi", mg_cycle="W")
+    assert w.matrix_info(0, "Q")["fmt"] is None
+
+
 @pytest.mark.parametrize("sm", ["jacobi", "gs"])
 def test_size_independent_properties_at_large_size(sm):
     """1.1 M DOF (the one-thread-per-row SELL path, 16-bit column deltas, graph replay): properties that need no oracle --
@@ -300,6 +335,8 @@ def test_size_independent_properties_at_large_size(sm):
     p, H = poisson_case((103, 103, 103), "right|top", 50)
     dev = _dev(H, sm_type=sm)
     assert dev.matrix_info(0, "A")["fmt"] == "sell" and dev.matrix_info(0, "A")["lanes"] == 1
+    if sm == "jacobi":
+        assert dev.matrix_info(0, "Q")["fmt"] == "sellwin"
     rng = np.random.default_rng(0)
     free = torch.from_numpy(p.free.astype(np.float64)).cuda()
     u = torch.from_numpy(rng.standard_normal(p.n)).cuda() * free

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "q_csr": {"AMGX_Q_MAX_PAD": "1.0"},
+    "no_window": {"AMGX_NO_SELL_WINDOW": "1"},
 }
 
 
