@@ -216,23 +216,39 @@ def main():
     applies_per_s = world * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    # ---- roofline of the dominant kernel: level-0 residual SpMV r = b - A x ---------------------------
-    # algorithmic bytes per launch: B(A_0) + 3 V_0
+    # ---- roofline of the dominant kernel ---------------------------------------------------------------
+    # Jacobi cycle: sell_pre_restrict_kernel on level 0 = Jacobi pre-smoothing from zero, residual and restriction in one
+    # pass.  Algorithmic bytes per launch (the un-fused op sequence it replaces):
+    #   x = w Dinv b: 3 V_0;  r = b - A x: B(A_0) + 3 V_0;  b_c = P^T r: B(PT_0) + V_0 + V_1
+    # Gauss-Seidel cycle (or no fused kernel): level-0 residual SpMV r = b - A x: B(A_0) + 3 V_0
     lv0 = H.levels[0]
-    spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.n * lv0.bs
+    V0 = 8 * lv0.n * lv0.bs
     with torch.cuda.stream(stream):
         amg.Mult(b, x)
         stream.synchronize()
-    k_ms = amg.time_op(0, 0, reps=50)
+    folded = amg.matrix_info(0, "Q")["fmt"] is not None
+    k_name, tname = "sell_spmv_kernel<EP_RES> (level 0: r = b - A x)", "traffic_spmv_l0.json"
+    spmv_bytes = matrix_bytes(lv0.A) + 3 * V0
+    k_ms = None
+    if args.smoother == "jacobi":
+        try:
+            k_ms = amg.time_op(0, 7, reps=50)
+            spmv_bytes = matrix_bytes(lv0.A) + matrix_bytes(lv0.PT) + 7 * V0 + 8 * H.levels[1].n * H.levels[1].bs
+            k_name = "sell_pre_restrict_kernel<512> (level 0: x = w Dinv b, r = b - A x, b_c = P^T r in one pass)"
+            tname = "traffic_pre_restrict_l0.json"
+        except Exception:
+            k_ms = None
+    if k_ms is None:
+        k_ms = amg.time_op(0, 0, reps=50)
     achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_spmv_l0.json")
+    tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and nv == 215:
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "sell_spmv_kernel<EP_RES> (level 0: r = b - A x)",
+    roofline = {"bound": "hbm", "kernel": k_name,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(spmv_bytes),
@@ -242,6 +258,11 @@ def main():
 
     if args.ops and rank == 0:
         names = {0: "residual r=b-Ax", 1: "jacobi fused", 2: "restrict PT r", 3: "prolong x+P xc"}
+        for l in range(H.n_levels - 1):
+            qi = amg.matrix_info(l, "Q")
+            log(f"level {l} cycle step down (pre-smooth + restrict) {amg.time_op(l, 5, reps=50) * 1e3:9.1f} us   "
+                f"up (correct + post-smooth) {amg.time_op(l, 6, reps=50) * 1e3:9.1f} us   Q fmt={qi['fmt']} lanes={qi['lanes']} "
+                f"stream={qi['stream_bytes'] / 1e6:.1f} MB")
         for l in range(H.n_levels):
             for op in range(4):
                 if op >= 2 and l + 1 >= H.n_levels:
@@ -292,7 +313,9 @@ def main():
                                    f"Dirichlet right|top, {args.smoother} omega=0.9, V(1,1), max_coarse_size=50",
                        "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
                        "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} independent per-rank problems (weak; halo exchange not built yet)"},
+                       "post_smoothing": ("folded into the prolongation: x' = z + (I - w Dinv A) P x_c, same result up to rounding "
+                                          "(AMGX_NO_FOLD=1 runs the literal kernel sequence)") if folded else "literal",
+                       "parallelism": "1 GPU"},
             "x_norm": x_norm,
             "roofline": roofline,
         }

@@ -144,7 +144,8 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *   op = 2: restriction  b_c = P^T r      op = 3: prolongation  x += P x_c
  *   op = 4: one whole cycle (amgx_apply on internal vectors)
  *   op = 5: pre-smoothing + restriction as the V-cycle runs it on this level (fused / folded where built)
- *   op = 6: coarse-grid correction + post-smoothing as the V-cycle runs it on this level */
+ *   op = 6: coarse-grid correction + post-smoothing as the V-cycle runs it on this level
+ *   op = 7: sell_pre_restrict_kernel alone (op 5 without the small restrict_sum_kernel); error if the level has none */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
 
 #ifdef __cplusplus

@@ -486,6 +486,7 @@ struct Handle {
   DevBuf<double> coarse_inv;
   hipStream_t own_stream = nullptr, stream = nullptr;
   bool use_graph = true;
+  bool skip_rsum = false;               // amgx_time_op(op 7): time sell_pre_restrict_kernel alone
   int ep_nt = 1;                        // non-temporal epilogue operands (AMGX_NO_EP_NT=1 disables)
   int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
   int tail_ops = 0;
@@ -801,8 +802,9 @@ struct Handle {
       else
         hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
                            L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
-      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
-                         R.oidx.p, R.part.p, b_coarse);
+      if (!skip_rsum)
+        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                           R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
       return;
     }
@@ -1569,7 +1571,7 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
     if (reps < 1 || !avg_ms) throw amgx::Err("amgx_time_op: bad arguments");
     amgx::DevLevel& L = h.lev[level];
     const bool has_c = level + 1 < h.n_levels();
-    if ((op == 2 || op == 3 || op == 5 || op == 6) && !has_c) throw amgx::Err("amgx_time_op: no transfer on the coarsest level");
+    if ((op == 2 || op == 3 || op == 5 || op == 6 || op == 7) && !has_c) throw amgx::Err("amgx_time_op: no transfer on the coarsest level");
     if (op == 1 && (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI)) throw amgx::Err("amgx_time_op: level has no Jacobi smoother");
     auto launch = [&]() {
       switch (op) {
@@ -1580,6 +1582,12 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
         case 4: h.run_cycle(h.lev[0].x.p, h.lev[0].rhs.p, true); break;
         case 5: h.pre_smooth_restrict(level, L.x.p, L.rhs.p, L.res.p, h.lev[level + 1].rhs.p, h.folded(L)); break;
         case 6: h.post_smooth(level, L.x.p, L.rhs.p, L.res.p, h.lev[level + 1].x.p, h.folded(L)); break;
+        case 7:
+          if (L.RF.empty()) throw amgx::Err("amgx_time_op: level has no fused pre-smoothing + restriction kernel");
+          h.skip_rsum = true;
+          try { h.pre_smooth_restrict(level, L.x.p, L.rhs.p, L.res.p, h.lev[level + 1].rhs.p, h.folded(L)); } catch (...) { h.skip_rsum = false; throw; }
+          h.skip_rsum = false;
+          break;
         default: throw amgx::Err("amgx_time_op: unknown op");
       }
     };
