@@ -61,6 +61,11 @@ typedef struct amgx_level_desc {
   int32_t sm_symm;            /* ngs_amg_sm_symm                                                     */
   const int32_t* color;       /* [n] colour of each free row (required for AMGX_SM_GS), -1 otherwise  */
   int32_t n_colors;
+  amgx_matrix Q;              /* optional (rowptr == NULL: none).  Folded post-smoothing prolongation                */
+                              /*   Q = (I - omega*Dinv*A) P  of a Jacobi level of the V-cycle, n_rows x (coarse n_cols). */
+                              /*   Square levels: the library builds it itself.  Rank-partitioned levels (A has ghost  */
+                              /*   columns): the caller, who holds the P rows of the ghost vertices, supplies it; its    */
+                              /*   columns index the coarse level's [owned | ghost] vector (see amgx_cycle_up).          */
 } amgx_level_desc;
 
 typedef struct amgx_hierarchy_desc {
@@ -108,6 +113,16 @@ int amgx_smooth_v_from_level(amgx_handle h, int level, double* x, const double* 
  *   amgx_prolong    : x_out = x_in + fac * P x_coarse   (ProlMap::AddC2F, dof_map.cpp:697-709, out of place)
  *   amgx_jacobi_post: x_out = x_in + omega*Dinv*(b - A x_in)   x_in: n_cols entries (ghosts valid), x_out != x_in */
 int amgx_jacobi_pre(amgx_handle h, int level, const double* b, double* x, double* r, int flags);
+/* The same two stages in the form the single-GPU V-cycle runs them (fused pre-smoothing + restriction, post-smoothing
+ * folded into the prolongation); only for Jacobi levels that have Q (amgx_matrix_info(which = 4) reports it):
+ *   amgx_cycle_down : z = S(S0(b)) stored to x (two Jacobi steps from zero WITHOUT coarse correction), and
+ *                     b_coarse = P^T (b - A omega*Dinv*b)         b: n_cols entries (ghosts valid); x: n_rows;
+ *                     b_coarse: owned rows of the coarse level     (amg_matrix.cpp:193-212)
+ *   amgx_cycle_up   : x += Q x_coarse  => x = result of  x_pre + P x_c  followed by the Jacobi post-smoothing step
+ *                     x_coarse: Q.n_cols entries (coarse [owned | ghost], ghosts valid)   (amg_matrix.cpp:263-302)
+ * One halo exchange per stage (b before down, the coarse x before up) instead of two per level. */
+int amgx_cycle_down(amgx_handle h, int level, const double* b, double* x, double* b_coarse, int flags);
+int amgx_cycle_up(amgx_handle h, int level, double* x, const double* x_coarse, int flags);
 /* r = b - A_level x   (BaseSmoother::CalcResiduum, base_smoother.hpp:132-142); x: n_cols entries, b, r: n_rows.
  * With amgx_smooth (whose x may carry ghost entries too: they are read, never written) this gives the stages of the
  * hybrid Gauss-Seidel smoother of rank-partitioned levels: local sweep on the owned rows with the off-rank values

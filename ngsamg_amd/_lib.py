@@ -180,7 +180,7 @@ class amgx_matrix(C.Structure):
 class amgx_level_desc(C.Structure):
     _fields_ = [("A", amgx_matrix), ("P", amgx_matrix), ("PT", amgx_matrix), ("dinv", c_f64p),
                 ("free_dofs", c_u8p), ("sm_type", C.c_int32), ("omega", C.c_double), ("sm_steps", C.c_int32),
-                ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32)]
+                ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32), ("Q", amgx_matrix)]
 
 
 class amgx_hierarchy_desc(C.Structure):
@@ -197,6 +197,7 @@ AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
 AMGX_SYMBOLS = [
     "amgx_last_error", "amgx_create", "amgx_destroy", "amgx_set_stream", "amgx_synchronize", "amgx_apply",
     "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_jacobi_pre", "amgx_jacobi_post", "amgx_residual",
+    "amgx_cycle_down", "amgx_cycle_up",
     "amgx_prolong", "amgx_matvec", "amgx_transfer_f2c",
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op",
@@ -228,6 +229,8 @@ def hip():
     lib.amgx_smooth.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.amgx_smooth_v_from_level.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.amgx_jacobi_pre.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    lib.amgx_cycle_down.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    lib.amgx_cycle_up.argtypes = [vp, C.c_int, dp, dp, C.c_int]
     lib.amgx_residual.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.amgx_jacobi_post.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
     lib.amgx_prolong.argtypes = [vp, C.c_int, C.c_double, dp, dp, dp, C.c_int]

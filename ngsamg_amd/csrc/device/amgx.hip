@@ -1160,26 +1160,32 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
         // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
         // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
-        if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 && s.A.n_rows == s.A.n_cols &&
+        if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 &&
             s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
         {
           L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
           if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
           build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
         }
-        // post-smoothing folded into the prolongation (V-cycle, square levels only: a rank-partitioned level is
-        // driven stage by stage through amgx_jacobi_pre / amgx_prolong / amgx_jacobi_post and keeps the literal form)
-        if (d->cycle == AMGX_CYCLE_V && s.P.br == 1 && s.P.bc == 1 && s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows &&
-            !std::getenv("AMGX_NO_FOLD"))
-        {
-          HostCsr q;
-          fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
-          if (q.rowptr[s.A.n_rows] < (int64_t)2147483647) {
-            amgx_matrix Qm = s.P;
-            Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
-            double qpad = 1.6;
-            if (const char* e = std::getenv("AMGX_Q_MAX_PAD")) qpad = std::atof(e);
-            upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+        // post-smoothing folded into the prolongation (V-cycle).  Square levels: Q is built here.  Rank-partitioned
+        // levels: Q needs the P rows of the ghost vertices, so the caller supplies it (amgx_level_desc.Q) and drives
+        // the level through amgx_cycle_down / amgx_cycle_up.
+        if (d->cycle == AMGX_CYCLE_V && s.P.br == 1 && s.P.bc == 1 && !std::getenv("AMGX_NO_FOLD")) {
+          double qpad = 1.6;
+          if (const char* e = std::getenv("AMGX_Q_MAX_PAD")) qpad = std::atof(e);
+          if (s.Q.rowptr) {
+            if (s.Q.n_rows != s.A.n_rows || s.Q.br != 1 || s.Q.bc != 1 || s.Q.n_cols < c.A.n_rows || s.Q.n_cols > c.A.n_cols)
+              throw Err("Q does not match the level matrices");
+            if (s.Q.rowptr[s.Q.n_rows] >= (int64_t)2147483647) throw Err("Q: too many entries");
+            upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+          } else if (s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows) {
+            HostCsr q;
+            fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
+            if (q.rowptr[s.A.n_rows] < (int64_t)2147483647) {
+              amgx_matrix Qm = s.P;
+              Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
+              upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+            }
           }
         }
       }
@@ -1448,6 +1454,38 @@ int amgx_jacobi_pre(amgx_handle hh, int level, const double* b, double* x, doubl
     h.pre_smooth(L, dx, db, dr);
     st.out(1, x, L.len());
     st.out(2, r, L.len());
+    st.finish();
+  });
+}
+
+int amgx_cycle_down(amgx_handle hh, int level, const double* b, double* x, double* b_coarse, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_cycle_down: level out of range");
+    amgx::DevLevel& L = h.lev[level];
+    if (!h.folded(L)) throw amgx::Err("amgx_cycle_down: level has no folded prolongation Q (use amgx_jacobi_pre / amgx_transfer_f2c)");
+    if (!b || !x || !b_coarse) throw amgx::Err("amgx_cycle_down: null vector");
+    Staged st(h, flags);
+    const double* db = st.in(0, b, L.ext_len());
+    double* dx = st.inout(1, x, L.len(), false);
+    double* dc = st.inout(2, b_coarse, h.lev[level + 1].len(), false);
+    h.pre_smooth_restrict(level, dx, db, L.res.p, dc, true);
+    st.out(1, x, L.len());
+    st.out(2, b_coarse, h.lev[level + 1].len());
+    st.finish();
+  });
+}
+
+int amgx_cycle_up(amgx_handle hh, int level, double* x, const double* x_coarse, int flags) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_cycle_up: level out of range");
+    amgx::DevLevel& L = h.lev[level];
+    if (!h.folded(L)) throw amgx::Err("amgx_cycle_up: level has no folded prolongation Q (use amgx_prolong / amgx_jacobi_post)");
+    if (!x || !x_coarse) throw amgx::Err("amgx_cycle_up: null vector");
+    Staged st(h, flags);
+    double* dx = st.inout(0, x, L.len(), true);
+    const double* dc = st.in(1, x_coarse, L.Q.n_cols);
+    h.post_smooth(level, dx, nullptr, L.res.p, dc, true);
+    st.out(0, x, L.len());
     st.finish();
   });
 }

@@ -78,6 +78,9 @@ class DeviceAMGMatrix:
             d.sm_symm = int(bool(sm_symm))
             d.color = _lib.ptr(lv.color, C.c_int32)
             d.n_colors = int(lv.n_colors)
+            q = getattr(lv, "Q", None)        # caller-supplied folded prolongation (rank-partitioned levels, dist.py)
+            if q is not None:
+                d.Q = q.desc(_lib.amgx_matrix)
         desc = _lib.amgx_hierarchy_desc()
         desc.n_levels = n
         desc.levels = arr
@@ -173,6 +176,24 @@ class DeviceAMGMatrix:
     def JacobiPre(self, level, b_ext, x, r):
         vb, vx, vr = _Vec(b_ext, self.ext_sizes[level], "b"), _Vec(x, self._size(level), "x", True), _Vec(r, self._size(level), "r", True)
         self._ck(self._lib.amgx_jacobi_pre(self._h, level, vb.addr, vx.addr, vr.addr, self._flags(vb, vx, vr)))
+
+    def CycleDown(self, level, b_ext, x, b_coarse):
+        """x = two Jacobi steps from zero on b (no coarse correction yet), b_coarse = P^T (b - A w Dinv b)"""
+        vb, vx = _Vec(b_ext, self.ext_sizes[level], "b"), _Vec(x, self._size(level), "x", True)
+        vc = _Vec(b_coarse, self._size(level + 1), "b_coarse", True)
+        self._ck(self._lib.amgx_cycle_down(self._h, level, vb.addr, vx.addr, vc.addr, self._flags(vb, vx, vc)))
+
+    def CycleUp(self, level, x, x_coarse_ext):
+        """x += Q x_coarse: coarse-grid correction and Jacobi post-smoothing in one product"""
+        vx, vc = _Vec(x, self._size(level), "x", True), _Vec(x_coarse_ext, self.q_cols(level), "x_coarse")
+        self._ck(self._lib.amgx_cycle_up(self._h, level, vx.addr, vc.addr, self._flags(vx, vc)))
+
+    def is_folded(self, level):
+        return self.matrix_info(level, "Q")["fmt"] is not None
+
+    def q_cols(self, level):
+        q = getattr(self.hierarchy.levels[level], "Q", None)
+        return q.n_cols if q is not None else self.hierarchy.levels[level].P.n_cols
 
     def JacobiPost(self, level, x_in_ext, b, x_out):
         vi, vb, vo = _Vec(x_in_ext, self.ext_sizes[level], "x_in"), _Vec(b, self._size(level), "b"), _Vec(x_out, self._size(level), "x_out", True)

@@ -437,6 +437,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         AP = _spmm(s.A, P_ext)
         c.A = _spmm(sp.csr_matrix(P.T), AP)
         c.A.sort_indices()
+        s.AP, s.P_own_ext = AP, P_own_ext          # for the folded prolongation Q = P - w Dinv (A P), see _fold
         s.P = sp.csr_matrix(P)
         s.P.sort_indices()
         s.PT = sp.csr_matrix(P.T)
@@ -454,6 +455,17 @@ def _dinv_ext(comm, states):
     gh = _exchange_ghost_values(comm, states, dins)
     for s, di, g in zip(states, dins, gh):
         s.dinv_ext = np.concatenate([di, g])
+
+
+def _fold(states, omega):
+    """Q = (I - omega Dinv A) P on the owned rows, columns = coarse [owned | ghost]: the Jacobi post-smoothing folded
+    into the prolongation (amgx.h: amgx_level_desc.Q, amgx_cycle_up).  A P is a by-product of the Galerkin product."""
+    for s in states:
+        wd = omega * s.dinv_ext[:s.n]
+        Q = sp.csr_matrix(s.P_own_ext - sp.diags(wd) @ s.AP)
+        Q.sort_indices()
+        s.Q = Q
+        del s.AP, s.P_own_ext
 
 
 def _hybrid_gs_data(comm, states):
@@ -484,7 +496,7 @@ def _hybrid_gs_data(comm, states):
 class _TopHierarchy:
     """duck-typed Hierarchy holding the rank-partitioned levels of one rank (for DeviceAMGMatrix)"""
 
-    def __init__(self, states, gs=False):
+    def __init__(self, states, gs=False, fold=False):
         self.levels = []
         for i, s in enumerate(states):
             last = i + 1 == len(states)
@@ -493,7 +505,8 @@ class _TopHierarchy:
             dinv = s.dinv_gs_ext if use_gs else s.dinv_ext
             self.levels.append(Level(A=_mat(s.A), P=None if last else _mat(s.P), PT=None if last else _mat(s.PT),
                                      free=s.free, dinv=np.ascontiguousarray(dinv), coords=None, color=color,
-                                     n_colors=s.n_colors if use_gs else 0, agg=None))
+                                     n_colors=s.n_colors if use_gs else 0, agg=None,
+                                     Q=_mat(s.Q) if (fold and not last and not use_gs) else None))
         self.coarse_n = 0
         self.coarse_inv = np.empty(0)
         self.n_levels = len(self.levels)
@@ -508,10 +521,13 @@ class DistributedAMG:
     """
 
     def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=50000, max_dist_levels=3, device=0,
-                 backend=None, sm_type="jacobi", **opts):
+                 backend=None, sm_type="jacobi", fold=True, **opts):
         if sm_type not in ("jacobi", "gs"):
             raise NgsAMGError("DistributedAMG: sm_type must be jacobi or gs")
         self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
+        # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
+        # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
+        self.fold = bool(fold) and sm_type == "jacobi"
         _send_lists(comm, states0)
         levels = [states0]
         while len(levels) <= max_dist_levels:
@@ -527,6 +543,9 @@ class DistributedAMG:
         if sm_type == "gs":
             for lv in levels[:-1]:
                 _hybrid_gs_data(comm, lv)
+        if self.fold:
+            for lv in levels[:-1]:
+                _fold(lv, omega)
         self.dist_levels = levels
         self.k = len(levels) - 1                      # levels 0..k-1 are smoothed in distributed form, level k is gathered
         # ---- gather level k and build the replicated tail ---------------------------------------------
@@ -551,7 +570,7 @@ class DistributedAMG:
         topts["first_aaf"] = opts.get("aaf", 2.0 ** -dim)
         self.tail_hier = Hierarchy(_mat(Ag), None, None, dim=dim, energy=0, **topts)
         # ---- per-rank execution objects --------------------------------------------------------------------
-        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type == "gs")) for i in range(len(states0))]
+        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type == "gs"), fold=self.fold) for i in range(len(states0))]
         if backend is None:
             backend = _device_backend(device, omega, sm_type)
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
@@ -569,7 +588,7 @@ class DistributedAMG:
                 b["text"].append(ops.zeros(next_))
                 b["x"].append(ops.zeros(s.n))
                 b["r"].append(ops.zeros(s.n))
-                b.setdefault("xext", []).append(ops.zeros(next_) if self.sm_type == "gs" else None)
+                b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type == "gs" or self.fold) else None)
                 b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type == "gs" else None)
                 # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
                 peers = sorted(s.send)
@@ -586,6 +605,11 @@ class DistributedAMG:
             b["bglob"] = ops.zeros(int(self.offs[-1]))
             b["xglob"] = ops.zeros(int(self.offs[-1]))
             b["nk"] = sk.n
+            if self.fold:
+                # level k in the [owned | ghost] layout of this rank, picked from the replicated tail solution
+                gmap = np.concatenate([self.offs[sk.rank] + np.arange(sk.n), self.offs[sk.ghost_owner] + sk.ghost_rindex])
+                b["kmap"] = ops.index(gmap)
+                b["xk_ext"] = ops.zeros(gmap.size)
             self.buf.append(b)
 
     def _halo(self, l, key):
@@ -609,6 +633,8 @@ class DistributedAMG:
         """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind)"""
         if self.sm_type == "gs":
             return self._mult_gs(bs, xs)
+        if self.fold:
+            return self._mult_folded(bs, xs)
         k = self.k
         for l in range(k):
             for i, ops in enumerate(self.ops):
@@ -639,6 +665,36 @@ class DistributedAMG:
                 s, b = self.dist_levels[l][i], self.buf[i]
                 xl = xs[i] if l == 0 else b["x"][l]
                 ops.jacobi_post(l, b["text"][l], b["bext"][l][:s.n], xl)
+        return xs
+
+    def _mult_folded(self, bs, xs):
+        """Jacobi V(1,1) in the form the single-GPU cycle runs: down = fused pre-smoothing + restriction
+        writing z = S(S0 b); up = x = z + Q x_c.  Exchanges: b before every down stage, x of the levels 1..k-1 after their
+        up stage (level k comes replicated from the tail) -- 2k - 1 instead of 2k."""
+        k = self.k
+        for l in range(k):
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                if l == 0 and bs[i].data_ptr() != b["bext"][0].data_ptr():
+                    b["bext"][0][:s.n].copy_(bs[i])
+            self._halo(l, "bext")
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                xl = xs[i] if l == 0 else b["xext"][l][:s.n]
+                nxt = b["bext"][l + 1][:self.dist_levels[l + 1][i].n] if l + 1 < k else b["bk"][:b["nk"]]
+                ops.cycle_down(l, b["bext"][l], xl, nxt)
+        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], self.counts)
+        for i, ops in enumerate(self.ops):
+            b = self.buf[i]
+            ops.tail_apply(b["bglob"], b["xglob"])
+            ops.gather(b["xglob"], b["kmap"], b["xk_ext"])
+        for l in range(k - 1, -1, -1):
+            for i, ops in enumerate(self.ops):
+                s, b = self.dist_levels[l][i], self.buf[i]
+                xl = xs[i] if l == 0 else b["xext"][l][:s.n]
+                ops.cycle_up(l, xl, b["xext"][l + 1] if l + 1 < k else b["xk_ext"])
+            if l > 0:
+                self._halo(l, "xext")
         return xs
 
     def _mult_gs(self, bs, xs):
@@ -765,6 +821,12 @@ def _device_backend(device, omega, sm_type="jacobi"):
 
         def jacobi_pre(self, l, bext, x, r):
             self.top.JacobiPre(l, bext, x, r)
+
+        def cycle_down(self, l, bext, x, bc):
+            self.top.CycleDown(l, bext, x, bc)
+
+        def cycle_up(self, l, x, xc_ext):
+            self.top.CycleUp(l, x, xc_ext)
 
         def restrict(self, l, r, bc):
             self.top.TransferF2C(l, r, bc)

@@ -26,6 +26,7 @@ class Level:
     color: np.ndarray      # int32 [n]
     n_colors: int
     agg: np.ndarray | None
+    Q: Matrix | None = None     # rank-partitioned levels only: caller-built (I - w Dinv A) P (amgx_level_desc.Q)
 
     @property
     def n(self):

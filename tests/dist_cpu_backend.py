@@ -14,6 +14,7 @@ def cpu_backend(omega=0.9, sm_type="jacobi"):
             self.top = top
             self.A = [L.A.to_scipy() for L in top.levels]
             self.P = [L.P.to_scipy() if L.P is not None else None for L in top.levels]
+            self.Q = [L.Q.to_scipy() if getattr(L, "Q", None) is not None else None for L in top.levels]
             if id(tail_hier) not in tails:
                 tails[id(tail_hier)] = Oracle(tail_hier.levels, sm_type="jacobi" if sm_type == "jacobi" else "gs_mc", omega=omega)
             # rank-local smoother objects: one single-level oracle per distributed level (rectangular A, no coarse solve)
@@ -37,6 +38,18 @@ def cpu_backend(omega=0.9, sm_type="jacobi"):
             xe = omega * L.dinv * be                       # ghost entries of x from ghost dinv * ghost b
             x.numpy()[:] = xe[:n]
             r.numpy()[:] = be[:n] - self.A[l] @ xe
+
+        def cycle_down(self, l, bext, x, bc):
+            L = self.top.levels[l]
+            n = L.A.n_rows
+            be = bext.numpy()
+            xe = omega * L.dinv * be
+            r = be[:n] - self.A[l] @ xe
+            x.numpy()[:] = xe[:n] + omega * L.dinv[:n] * r      # second Jacobi step, no coarse correction yet
+            bc.numpy()[:] = self.P[l].T @ r
+
+        def cycle_up(self, l, x, xc_ext):
+            x.numpy()[:] += self.Q[l] @ xc_ext.numpy()
 
         def restrict(self, l, r, bc):
             bc.numpy()[:] = self.P[l].T @ r.numpy()

@@ -11,12 +11,12 @@ from oracle.pyoracle import Oracle
 from tests.dist_cpu_backend import cpu_backend
 
 
-def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi"):
+def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
     amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dist_min_rows, backend=cpu_backend(sm_type=sm),
-                           max_coarse_size=10, sm_type=sm)
+                           max_coarse_size=10, sm_type=sm, fold=fold)
     rng = np.random.default_rng(0)
     bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
     xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
@@ -29,9 +29,12 @@ def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi"):
 
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (12, 12, 12), 3, 100), (4, (10, 10, 10), 3, 50), (8, (8, 8, 8), 3, 20),
                                             (4, (24, 24), 2, 50), (2, (12, 12, 12), 3, 10 ** 9)])
-def test_loopback_matches_serial_oracle(R, box, dim, dmin):
-    amg, got, ref = _run_loopback(R, box, dim, dmin)
-    assert amg.k >= 1
+@pytest.mark.parametrize("fold", [True, False])
+def test_loopback_matches_serial_oracle(R, box, dim, dmin, fold):
+    """fold = True: stages as the single-GPU cycle runs them (z = S(S0 b) on the way down, x = z + Q x_c on the way up);
+    fold = False: the literal stage sequence.  Both must equal the serial oracle's literal cycle."""
+    amg, got, ref = _run_loopback(R, box, dim, dmin, fold=fold)
+    assert amg.k >= 1 and amg.fold == fold
     assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
 
 

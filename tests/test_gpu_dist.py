@@ -9,15 +9,17 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (8, (10, 10, 10), 3, 40),
                                             (4, (40, 40), 2, 100)])
-def test_loopback_device_matches_serial_oracle(R, box, dim, dmin):
+@pytest.mark.parametrize("fold", [True, False])
+def test_loopback_device_matches_serial_oracle(R, box, dim, dmin, fold):
     import torch
     from ngsamg_amd import dist as D
     from oracle.pyoracle import Oracle
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
-    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10)
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10, fold=fold)
     assert amg.k >= 1
+    assert all(op.top.is_folded(l) == fold for op in amg.ops for l in range(amg.k))
     rng = np.random.default_rng(0)
     bh = [rng.standard_normal(s.n) * s.free for s in states]
     bs = [torch.from_numpy(b).cuda() for b in bh]
