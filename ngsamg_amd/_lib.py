@@ -53,7 +53,10 @@ _hip = None
 
 
 def _load(name):
+    # NGSAMG_HIP_LIB: alternative build of the device library (kernel A/B experiments, tools/ab_cycle.py)
     path = os.path.join(LIBDIR, name)
+    if name == "libngsamg_hip.so" and os.environ.get("NGSAMG_HIP_LIB"):
+        path = os.environ["NGSAMG_HIP_LIB"]
     if not os.path.exists(path):
         raise NgsAMGError(f"{path} not found - run `python __graft_entry__.py` (build()) first")
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -607,9 +607,9 @@ struct Handle {
   }
 
   void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr, 0}); }
-  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr, 0}); }
+  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr, ep_nt & EPF_HOIST}); }
   // y = yin + s * M x
-  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr, 0}); }
+  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr, ep_nt & EPF_HOIST}); }
   // xout = xin + omega * dinv * (b - A xin)
   void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout) {
     if (xin == xout) throw Err("jacobi_fused: in-place update is not allowed");
@@ -1111,7 +1111,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
   h->cycle = d->cycle;
   h->clev = d->clev;
   h->use_graph = d->use_graph != 0;
-  h->ep_nt = std::getenv("AMGX_NO_EP_NT") ? 0 : 1;   // A/B: -0.4 % cycle time (profiles/r01/restrict_fused.txt)
+  h->ep_nt = (std::getenv("AMGX_NO_EP_NT") ? 0 : EPF_NT) | (std::getenv("AMGX_NO_EP_HOIST") ? 0 : EPF_HOIST);   // A/B: -0.4 % cycle time (profiles/r01/restrict_fused.txt)
   if (d->cycle < 0 || d->cycle > 2) throw Err("amgx_create: unknown cycle");
   HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;

@@ -49,8 +49,10 @@ struct EpArgs {
   int nt;        // bit 0: stream the epilogue's own-row operands / results non-temporally (read / written once per cycle)
                  // bit 1 (EP_PRE): second output is z = x + omega*Dinv*r, the pre-smoothed iterate smoothed once more
                  //        without a coarse correction (cycle with the post-smoothing folded into the prolongation)
+                 // bit 2: request the own-row operands BEFORE the row product (their latency then overlaps the matrix
+                 //        stream instead of extending every wave's life by one dependent memory round trip)
 };
-constexpr int EPF_NT = 1, EPF_FOLD = 2;
+constexpr int EPF_NT = 1, EPF_FOLD = 2, EPF_HOIST = 4;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int q = nblocks >> 3, r = nblocks & 7;
@@ -84,6 +86,43 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
   }
 }
 
+// own-row operands of an epilogue, loaded ahead of the row product (EPF_HOIST)
+struct EpOps { double b, d, yin; };
+template <int EP>
+__device__ __forceinline__ EpOps ep_operands(int64_t row, const EpArgs& ep, bool have_xd) {
+  EpOps o{0.0, 0.0, 0.0};
+  const bool nt = ep.nt & EPF_NT;
+  if (EP == EP_RES) o.b = ep.b[row];
+  else if (EP == EP_AXPY) o.yin = ep.yin[row];
+  else if (EP == EP_JAC) {
+    o.d = nt ? ld_nt(ep.dinv + row) : ep.dinv[row];
+    o.b = nt ? ld_nt(ep.b + row) : ep.b[row];
+    if (!have_xd) o.yin = ep.yin[row];
+  } else if (EP == EP_PRE) {
+    o.d = nt ? ld_nt(ep.dinv + row) : ep.dinv[row];
+    if (!have_xd) o.b = ep.b[row];
+  }
+  return o;
+}
+template <int EP>
+__device__ __forceinline__ void store_scalar_ops(int64_t row, double acc, double* y, const EpArgs& ep, const EpOps& o, bool have_xd, double xd) {
+  const bool nt = ep.nt & EPF_NT;
+  if (EP == EP_MULT) y[row] = acc;
+  else if (EP == EP_RES) y[row] = o.b - acc;
+  else if (EP == EP_AXPY) y[row] = o.yin + ep.s * acc;
+  else if (EP == EP_JAC) {
+    const double v = (have_xd ? xd : o.yin) + ep.s * (o.d * (o.b - acc));
+    if (nt) __builtin_nontemporal_store(v, y + row); else y[row] = v;
+  } else {
+    const double bi = have_xd ? xd : o.b;
+    const double r = bi - acc;
+    y[row] = r;
+    double xi = ep.s * (o.d * bi);
+    if (ep.nt & EPF_FOLD) xi += ep.s * (o.d * r);
+    if (nt) __builtin_nontemporal_store(xi, ep.y2 + row); else ep.y2[row] = xi;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // SELL-64-pair view.  Column indices come in two encodings, chosen per slice at build time:
 //   32-bit:  col32[o]                                         (bit 0 of slice_ptr[s] clear)
@@ -101,6 +140,99 @@ struct SellMat {
   int diag_first;             // G == 1 only: entry 0 of every row is its diagonal, so the gathered x[row] comes for free
 };
 
+// SELL row product, software-pipelined in batches of K pair-steps: the matrix loads (values + packed indices) of batch
+// i+1 are requested BEFORE the gathers of batch i are consumed, so a wave always has a matrix batch in flight while it
+// waits for gathered x values.  Batch size: measured (profiles/r01/unroll_ab.txt) -- the rows of this path are short
+// (7 pair-steps for A at cfg 2, 1..8 for Q) and small batches win: K = 2, 3 beat K = 4 by 5 % and K = 8 by 7 %; a
+// `#pragma unroll 4` loop was worst (3 of 7 steps in a one-at-a-time remainder loop).
+#ifndef SELL_BATCH
+#define SELL_BATCH 2
+#endif
+#ifndef SELL_PIPELINE
+#define SELL_PIPELINE 1
+#endif
+
+template <int K>
+struct SellRegs {
+  double v0[K], v1[K];
+  uint32_t ca[K], cb2[K];    // C16: ca = packed 16-bit pair; 32-bit: ca, cb2 = the two columns
+};
+
+template <int K, bool C16>
+__device__ __forceinline__ void sell_load(SellRegs<K>& R, const double* __restrict__ vb, const void* __restrict__ cpv, int p, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int q = p + k;
+    R.v0[k] = ld_nt(vb + (q * WAVE + lane) * 2);
+    R.v1[k] = ld_nt(vb + (q * WAVE + lane) * 2 + 1);
+    if (C16) R.ca[k] = ld_nt(static_cast<const uint32_t*>(cpv) + q * WAVE + lane);
+    else {
+      const int32_t* __restrict__ cp = static_cast<const int32_t*>(cpv);
+      R.ca[k] = (uint32_t)ld_nt(cp + (q * WAVE + lane) * 2);
+      R.cb2[k] = (uint32_t)ld_nt(cp + (q * WAVE + lane) * 2 + 1);
+    }
+  }
+}
+
+template <int K, bool C16>
+__device__ __forceinline__ void sell_consume(const SellRegs<K>& R, const int32_t* __restrict__ cb, int r0, int p,
+                                             const double* __restrict__ x, double& acc0, double& acc1, double* xd) {
+  double x0[K], x1[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int q = p + k;
+    const int c0 = C16 ? r0 + cb[2 * q] + (int)(R.ca[k] & 0xffffu) : (int)R.ca[k];
+    const int c1 = C16 ? r0 + cb[2 * q + 1] + (int)(R.ca[k] >> 16) : (int)R.cb2[k];
+    x0[k] = x[c0];
+    x1[k] = x[c1];
+  }
+  if (xd && p == 0) *xd = x0[0];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { acc0 += R.v0[k] * x0[k]; acc1 += R.v1[k] * x1[k]; }
+}
+
+// remainder batch of REM < K steps; `last` (may be null) is a full batch whose gathers are consumed after the
+// remainder's matrix loads went out
+template <int K, int REM, bool C16>
+__device__ __forceinline__ void sell_tail(int rem, const SellRegs<K>* last, int p_last, const double* __restrict__ vb,
+                                          const void* __restrict__ cpv, const int32_t* __restrict__ cb, int r0, int p, int lane,
+                                          const double* __restrict__ x, double& acc0, double& acc1, double* xd) {
+  if (rem == REM) {
+    SellRegs<REM> R;
+    sell_load<REM, C16>(R, vb, cpv, p, lane);
+    if (last) sell_consume<K, C16>(*last, cb, r0, p_last, x, acc0, acc1, xd);
+    sell_consume<REM, C16>(R, cb, r0, p, x, acc0, acc1, xd);
+  } else if constexpr (REM > 1) sell_tail<K, REM - 1, C16>(rem, last, p_last, vb, cpv, cb, r0, p, lane, x, acc0, acc1, xd);
+}
+
+template <bool C16>
+__device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb, const void* __restrict__ cpv, const int32_t* __restrict__ cb,
+                                           int r0, int lane, const double* __restrict__ x, double& acc0, double& acc1, double* xd) {
+  constexpr int K = SELL_BATCH;
+  const int nfull = np / K, rem = np - nfull * K;
+#if SELL_PIPELINE
+  if (nfull > 0) {
+    SellRegs<K> A;
+    sell_load<K, C16>(A, vb, cpv, 0, lane);
+    for (int b = 1; b < nfull; ++b) {
+      SellRegs<K> B;
+      sell_load<K, C16>(B, vb, cpv, b * K, lane);
+      sell_consume<K, C16>(A, cb, r0, (b - 1) * K, x, acc0, acc1, xd);
+      A = B;
+    }
+    if (K > 1 && rem) sell_tail<K, (K > 1 ? K - 1 : 1), C16>(rem, &A, (nfull - 1) * K, vb, cpv, cb, r0, nfull * K, lane, x, acc0, acc1, xd);
+    else sell_consume<K, C16>(A, cb, r0, (nfull - 1) * K, x, acc0, acc1, xd);
+  } else if (K > 1 && rem) sell_tail<K, (K > 1 ? K - 1 : 1), C16>(rem, nullptr, 0, vb, cpv, cb, r0, 0, lane, x, acc0, acc1, xd);
+#else
+  for (int b = 0; b < nfull; ++b) {
+    SellRegs<K> A;
+    sell_load<K, C16>(A, vb, cpv, b * K, lane);
+    sell_consume<K, C16>(A, cb, r0, b * K, x, acc0, acc1, xd);
+  }
+  if (K > 1 && rem) sell_tail<K, (K > 1 ? K - 1 : 1), C16>(rem, nullptr, 0, vb, cpv, cb, r0, nfull * K, lane, x, acc0, acc1, xd);
+#endif
+}
+
 // dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
 // xd (optional): receives the x value gathered for entry 0 of this lane's row (meaningful when M.diag_first)
 __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd = nullptr) {
@@ -110,45 +242,23 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
   const int np = w >> 1;
   const double* __restrict__ vb = M.val + base;
   double acc0 = 0.0, acc1 = 0.0;
-  if (sp0 & 1) {
-    const uint32_t* __restrict__ cp = reinterpret_cast<const uint32_t*>(M.col16 + base);
-    const int32_t* __restrict__ cb = M.cbase + (base >> 6);
-    const int r0 = M.rowrel ? row : 0;
-#pragma unroll 4
-    for (int p = 0; p < np; ++p) {
-      const double v0 = ld_nt(vb + (p * WAVE + lane) * 2), v1 = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
-      const uint32_t c = ld_nt(cp + p * WAVE + lane);
-      const int c0 = r0 + cb[2 * p] + (int)(c & 0xffffu);
-      const int c1 = r0 + cb[2 * p + 1] + (int)(c >> 16);
-      const double x0 = x[c0];
-      if (xd && p == 0) *xd = x0;
-      acc0 += v0 * x0;
-      acc1 += v1 * x[c1];
-    }
-    if (w & 1) {
-      const int64_t o = (int64_t)(w - 1) * WAVE + lane;
-      const int c0 = r0 + cb[w - 1] + (int)ld_nt(M.col16 + base + o);
-      const double x0 = x[c0];
-      if (xd && np == 0) *xd = x0;
-      acc0 += ld_nt(vb + o) * x0;
-    }
-  } else {
-    const int32_t* __restrict__ cp = M.col32 + base;
-#pragma unroll 4
-    for (int p = 0; p < np; ++p) {
-      const double v0 = ld_nt(vb + (p * WAVE + lane) * 2), v1 = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
-      const int c0 = ld_nt(cp + (p * WAVE + lane) * 2), c1 = ld_nt(cp + (p * WAVE + lane) * 2 + 1);
-      const double x0 = x[c0];
-      if (xd && p == 0) *xd = x0;
-      acc0 += v0 * x0;
-      acc1 += v1 * x[c1];
-    }
-    if (w & 1) {
-      const int64_t o = (int64_t)(w - 1) * WAVE + lane;
-      const double x0 = x[ld_nt(cp + o)];
-      if (xd && np == 0) *xd = x0;
-      acc0 += ld_nt(vb + o) * x0;
-    }
+  const bool c16 = sp0 & 1;
+  const int32_t* __restrict__ cb = M.cbase + (base >> 6);
+  const int r0 = (c16 && M.rowrel) ? row : 0;
+  // odd trailing column: its matrix loads go out first, its gather comes last
+  double vs = 0.0;
+  int cs = 0;
+  if (w & 1) {
+    const int64_t o = (int64_t)(w - 1) * WAVE + lane;
+    vs = ld_nt(vb + o);
+    cs = c16 ? (int)ld_nt(M.col16 + base + o) : ld_nt(M.col32 + base + o);
+  }
+  if (c16) sell_pairs<true>(np, vb, M.col16 + base, cb, r0, lane, x, acc0, acc1, xd);
+  else sell_pairs<false>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
+  if (w & 1) {
+    const double x0 = x[c16 ? r0 + cb[w - 1] + cs : cs];
+    if (xd && np == 0) *xd = x0;
+    acc0 += vs * x0;
   }
   return acc0 + acc1;
 }
@@ -164,10 +274,17 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
   const int row = s * (WAVE / G) + lane / G;
   double xd = 0.0;
   const bool use_xd = G == 1 && (EP == EP_JAC || EP == EP_PRE) && M.diag_first;
+  const bool writer = (lane % G) == 0 && row < n_rows;
+  const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
+  EpOps ops{0.0, 0.0, 0.0};
+  if (hoist && writer) ops = ep_operands<EP>(row, ep, use_xd);
   double acc = sell_row_dot(M, s, lane, row, x, use_xd ? &xd : nullptr);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-  if ((lane % G) == 0 && row < n_rows) store_scalar<EP>(row, acc, y, ep, use_xd, xd);
+  if (writer) {
+    if (!hoist) ops = ep_operands<EP>(row, ep, use_xd);
+    store_scalar_ops<EP>(row, acc, y, ep, ops, use_xd, xd);
+  }
 }
 
 // Windowed SELL, one thread per row: a workgroup owns WB consecutive rows, stored in order of decreasing length
@@ -181,10 +298,16 @@ __global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, SellM
   const int lane = threadIdx.x & (WAVE - 1);
   const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (WB / WAVE) + (threadIdx.x >> 6));
   const int64_t slot = (int64_t)s * WAVE + lane;
+  const int64_t row = (int64_t)blockIdx.x * WB + threadIdx.x;
+  const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
+  EpOps ops{0.0, 0.0, 0.0};
+  if (hoist && row < n_rows) ops = ep_operands<EP>(row, ep, false);
   if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, x);
   __syncthreads();
-  const int64_t row = (int64_t)blockIdx.x * WB + threadIdx.x;
-  if (row < n_rows) store_scalar<EP>(row, buf[threadIdx.x], y, ep);
+  if (row < n_rows) {
+    if (!hoist) ops = ep_operands<EP>(row, ep, false);
+    store_scalar_ops<EP>(row, buf[threadIdx.x], y, ep, ops, false, 0.0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -545,11 +668,12 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
   double r = 0.0;
   if (s < n_slices) {
+    double bi = 0.0, di = 0.0;
+    if ((nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
     const double acc = sell_row_dot(M, s, lane, row, b);
     if (row < n_rows) {
-      const double bi = b[row];
+      if (!(nt & EPF_HOIST)) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
       r = bi - acc;
-      const double di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row];
       double xi = omega * (di * bi);
       if (nt & EPF_FOLD) xi += omega * (di * r);
       if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);

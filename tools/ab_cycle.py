@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "no_window": {"AMGX_NO_SELL_WINDOW": "1"},
+    "no_hoist": {"AMGX_NO_EP_HOIST": "1"},
 }
 
 
@@ -25,6 +25,8 @@ def main():
     hs = {}
     for inst in range(int(os.environ.get("AB_INSTANCES", "2"))):                      # two instances per variant: allocation placement alone moves the time by ~2 %
         for name, env in VARIANTS.items():
+            if os.environ.get("AB_ONLY") and name != os.environ["AB_ONLY"]:
+                continue
             for k, v in env.items():
                 os.environ[k] = v
             if sm == "gs" and name == "no_fused_restrict":
