@@ -315,7 +315,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF, Jacobi V(1,1))",
+            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel"),
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -419,6 +419,20 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
   const int w = (int)(M.slice_ptr[s + 1] - k0);
   const double* __restrict__ vb = M.val + k0 * (BS * WAVE);
   const int32_t* __restrict__ cb = M.col + k0 * RB;
+  const int64_t i = brow * BS + r;
+  // own-row epilogue operands requested ahead of the matrix stream (EPF_HOIST, see sell_spmv_kernel)
+  const bool hoist = (ep.nt & EPF_HOIST) && active && EP != EP_MULT;
+  double ob = 0.0, oy = 0.0, od[BS];
+#pragma unroll
+  for (int c = 0; c < BS; ++c) od[c] = 0.0;
+  if (hoist) {
+    if (EP == EP_RES || EP == EP_JAC) ob = ep.b[i];
+    if (EP == EP_AXPY || EP == EP_JAC) oy = ep.yin[i];
+    if (EP == EP_JAC) {
+#pragma unroll
+      for (int c = 0; c < BS; ++c) od[c] = ep.dinv[brow * (BS * BS) + r * BS + c];
+    }
+  }
   double acc = 0.0;
 #pragma unroll 2
   for (int k = 0; k < w; ++k) {
@@ -432,22 +446,21 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
     }
     if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
   }
-  const int64_t i = brow * BS + r;
   double out = 0.0;
   if (EP == EP_JAC) {
-    const double t = active ? ep.b[i] - acc : 0.0;
+    const double t = active ? (hoist ? ob : ep.b[i]) - acc : 0.0;
     const int base = lane - r;
     double u = 0.0;
 #pragma unroll
     for (int c = 0; c < BS; ++c) {
       const double tc = __shfl(t, base + c, WAVE);
-      if (active) u += ep.dinv[brow * (BS * BS) + r * BS + c] * tc;
+      if (active) u += (hoist ? od[c] : ep.dinv[brow * (BS * BS) + r * BS + c]) * tc;
     }
-    if (active) out = ep.yin[i] + ep.s * u;
+    if (active) out = (hoist ? oy : ep.yin[i]) + ep.s * u;
   } else if (active) {
     if (EP == EP_MULT) out = acc;
-    else if (EP == EP_RES) out = ep.b[i] - acc;
-    else out = ep.yin[i] + ep.s * acc;
+    else if (EP == EP_RES) out = (hoist ? ob : ep.b[i]) - acc;
+    else out = (hoist ? oy : ep.yin[i]) + ep.s * acc;
   }
   if (active) y[i] = out;
 }
