@@ -743,7 +743,7 @@ struct Handle {
   }
 
   bool plain(const DevLevel& L) const { return L.sm_steps <= 1 && !L.sm_symm; }
-  bool folded(const DevLevel& L) const { return plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Apre.empty() && !L.Q.empty(); }
+  bool folded(const DevLevel& L) const { return plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Q.empty() && (L.bs > 1 || !L.Apre.empty()); }
 
   // pre-smoothing step of the cycles: x = 0; r = b; Smooth(x, b, r, 1, 1, 1)   (amg_matrix.cpp:193-206)
   // fold (only with folded(L)): x receives z = x + omega*Dinv*r, to be completed by post_smooth(..., fold = true)
@@ -752,8 +752,15 @@ struct Handle {
       // one pass: r = b - A' b, x = omega * Dinv * b   (A' = A * omega*Dinv built at create time)
       spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x, ep_nt | (fold ? EPF_FOLD : 0)});
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
-      diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
-      residual(L.A, x, b, r);              // r = b - A x
+      if (fold && L.bs > 1) {
+        // x_pre = omega * Dinv * b into tmp; then ONE pass: r = b - A x_pre and z = x_pre + omega * Dinv * r
+        diag_apply(L, b, L.tmp.p, false);
+        spmv_ep<EP_JAC>(L.A, L.tmp.p, x, EpArgs{b, L.tmp.p, L.dinv.p, L.omega, r, ep_nt});
+      } else {
+        diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
+        residual(L.A, x, b, r);              // r = b - A x
+        if (fold) diag_apply(L, r, x, true); // z = x + omega * Dinv * r  (folded post-smoothing, see fold_prolongation)
+      }
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gs.has_split && L.bs == 1) {
       // forward sweep from x = 0: only couplings to lower colours contribute; afterwards b - L x - D x = 0 on every
       // swept row, hence r = -U x (r on non-free rows is not needed: their prolongation rows are empty)
@@ -1045,8 +1052,10 @@ struct HostCsr {
   std::vector<double> val;
 };
 
+// (block form: A has bs x bs blocks, P and Q bs x bc blocks, dinv bs x bs per block row)
 static void fold_prolongation(const amgx_matrix& A, const amgx_matrix& P, const double* dinv, double omega, HostCsr& Q) {
   const int64_t n = A.n_rows, nc = P.n_cols;
+  const int bs = A.br, bc = P.bc, bb = bs * bc;
   int T = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
   if (const char* e = std::getenv("OMP_NUM_THREADS")) T = std::max(1, std::min(T, std::atoi(e)));
   T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n / 4096 + 1));
@@ -1055,31 +1064,58 @@ static void fold_prolongation(const amgx_matrix& A, const amgx_matrix& P, const 
   Q.rowptr.assign(n + 1, 0);
   auto work = [&](int t) {
     const int64_t r0 = n * t / T, r1 = n * (t + 1) / T;
-    std::vector<int32_t> mark(nc, -1), cols;
-    std::vector<double> acc;
-    std::vector<std::pair<int32_t, double>> row;
+    std::vector<int32_t> mark(nc, -1), cols, order;
+    std::vector<double> own, acc, tmp(bb);    // own = P_i blocks, acc = sum_j A_ij P_j blocks (same slot numbering)
     Part& out = parts[t];
     for (int64_t i = r0; i < r1; ++i) {
-      cols.clear(); acc.clear();
-      auto add = [&](int32_t c, double v) {
+      cols.clear(); own.clear(); acc.clear();
+      auto slot = [&](int32_t c) -> int32_t {
         int32_t& m = mark[c];
-        if (m < 0) { m = (int32_t)cols.size(); cols.push_back(c); acc.push_back(v); }
-        else acc[m] += v;
+        if (m < 0) { m = (int32_t)cols.size(); cols.push_back(c); own.resize(own.size() + bb, 0.0); acc.resize(acc.size() + bb, 0.0); }
+        return m;
       };
-      for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) add(P.col[k], P.val[k]);
-      const double wd = omega * dinv[i];
-      if (wd != 0.0)
+      for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) {
+        const int32_t sl = slot(P.col[k]);          // (may reallocate own: take the pointer afterwards)
+        double* o = own.data() + (size_t)sl * bb;
+        for (int e = 0; e < bb; ++e) o[e] += P.val[k * bb + e];
+      }
+      const double* d = dinv + i * bs * bs;
+      bool dzero = true;
+      for (int e = 0; e < bs * bs; ++e) if (d[e] != 0.0) { dzero = false; break; }
+      if (!dzero)
         for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
           const int64_t j = A.col[k];
           if (j >= P.n_rows) continue;
-          const double a = -wd * A.val[k];
-          for (int64_t q = P.rowptr[j]; q < P.rowptr[j + 1]; ++q) add(P.col[q], a * P.val[q]);
+          const double* a = A.val + k * bs * bs;
+          for (int64_t q = P.rowptr[j]; q < P.rowptr[j + 1]; ++q) {
+            const double* pv = P.val + q * bb;
+            const int32_t sl = slot(P.col[q]);       // (may reallocate acc: take the pointer afterwards)
+            double* o = acc.data() + (size_t)sl * bb;
+            for (int r = 0; r < bs; ++r)
+              for (int m = 0; m < bs; ++m) {
+                const double arm = a[r * bs + m];
+                for (int c = 0; c < bc; ++c) o[r * bc + c] += arm * pv[m * bc + c];
+              }
+          }
         }
-      row.clear();
-      for (size_t q = 0; q < cols.size(); ++q) { row.emplace_back(cols[q], acc[q]); mark[cols[q]] = -1; }
-      std::sort(row.begin(), row.end(), [](const std::pair<int32_t, double>& a, const std::pair<int32_t, double>& b) { return a.first < b.first; });
-      for (const auto& e : row) { out.col.push_back(e.first); out.val.push_back(e.second); }
-      Q.rowptr[i + 1] = (int64_t)row.size();
+      order.resize(cols.size());
+      for (size_t q = 0; q < cols.size(); ++q) order[q] = (int32_t)q;
+      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cols[a] < cols[b]; });
+      for (int32_t q : order) {
+        const double* o = own.data() + (size_t)q * bb;
+        const double* sa = acc.data() + (size_t)q * bb;
+        // Q block = P block - omega * Dinv_i * (A P) block
+        for (int r = 0; r < bs; ++r)
+          for (int c = 0; c < bc; ++c) {
+            double u = 0.0;
+            for (int m = 0; m < bs; ++m) u += d[r * bs + m] * sa[m * bc + c];
+            tmp[r * bc + c] = o[r * bc + c] - omega * u;
+          }
+        out.col.push_back(cols[q]);
+        out.val.insert(out.val.end(), tmp.begin(), tmp.end());
+        mark[cols[q]] = -1;
+      }
+      Q.rowptr[i + 1] = (int64_t)cols.size();
     }
   };
   if (T == 1) work(0);
@@ -1090,11 +1126,11 @@ static void fold_prolongation(const amgx_matrix& A, const amgx_matrix& P, const 
   }
   for (int64_t i = 0; i < n; ++i) Q.rowptr[i + 1] += Q.rowptr[i];
   Q.col.resize((size_t)Q.rowptr[n]);
-  Q.val.resize((size_t)Q.rowptr[n]);
+  Q.val.resize((size_t)Q.rowptr[n] * bb);
   for (int t = 0; t < T; ++t) {
     const int64_t o = Q.rowptr[n * t / T];
     std::copy(parts[t].col.begin(), parts[t].col.end(), Q.col.begin() + o);
-    std::copy(parts[t].val.begin(), parts[t].val.end(), Q.val.begin() + o);
+    std::copy(parts[t].val.begin(), parts[t].val.end(), Q.val.begin() + o * bb);
     Part().col.swap(parts[t].col); Part().val.swap(parts[t].val);
   }
 }
@@ -1187,6 +1223,27 @@ static Handle* create(const amgx_hierarchy_desc* d) {
               upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
             }
           }
+        }
+      }
+      // block Jacobi levels of the V-cycle: the same fold in block form (Q has the block shape of P)
+      if (s.sm_type == AMGX_SM_JACOBI && s.A.br > 1 && s.sm_steps <= 1 && !s.sm_symm && d->cycle == AMGX_CYCLE_V &&
+          s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows && s.P.br == s.A.br && !std::getenv("AMGX_NO_FOLD") &&
+          !std::getenv("AMGX_NO_BLOCK_FOLD"))
+      {
+        HostCsr q;
+        fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
+        // Fold only where it pays: the way up then streams Q instead of A + P (+ the round trip of x + P x_c), but
+        // rectangular-block Q runs through the CSR block kernels (~4.5 TB/s) while square-block A streams as BSELL
+        // (~6.5 TB/s).  Measured at the cfg 3 shapes (profiles/r01/block_fold.txt): 3x3 fine level with 3x6 blocks in
+        // P: Q has 10.8 blocks/row = 1.6 GB vs A + P = 1.65 GB -> literal is 55 us faster; 6x6 levels: Q = 0.36 GB
+        // vs 1.04 GB -> folded is 100 us faster.
+        auto bytes = [](int64_t nnz, int br, int bc) { return (double)nnz * (8.0 * br * bc + 4.0); };
+        const double bq = bytes(q.rowptr[s.A.n_rows], s.P.br, s.P.bc);
+        const double blit = bytes(s.A.rowptr[s.A.n_rows], s.A.br, s.A.bc) + bytes(s.P.rowptr[s.P.n_rows], s.P.br, s.P.bc);
+        if (q.rowptr[s.A.n_rows] < (int64_t)2147483647 && bq < 0.7 * blit) {
+          amgx_matrix Qm = s.P;
+          Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
+          upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)");
         }
       }
     } else if (s.dinv) {

@@ -45,7 +45,7 @@ struct EpArgs {
   const double* yin;
   const double* dinv;
   double s;      // AXPY factor or Jacobi omega
-  double* y2;    // second output of EP_PRE
+  double* y2;    // second output of EP_PRE; block EP_JAC: optional output of the residual b - A x (nullptr: none)
   int nt;        // bit 0: stream the epilogue's own-row operands / results non-temporally (read / written once per cycle)
                  // bit 1 (EP_PRE): second output is z = x + omega*Dinv*r, the pre-smoothed iterate smoothed once more
                  //        without a coarse correction (cycle with the post-smoothing folded into the prolongation)
@@ -379,6 +379,10 @@ __global__ __launch_bounds__(BLOCK) void bcsrvec_spmv_kernel(int64_t n_rows, con
       double tt[BR];
 #pragma unroll
       for (int r = 0; r < BR; ++r) tt[r] = ep.b[row * BR + r] - acc[r];
+      if (ep.y2) {                       // block EP_JAC with a second output: the residual b - A x itself
+#pragma unroll
+        for (int r = 0; r < BR; ++r) ep.y2[row * BR + r] = tt[r];
+      }
       const double* __restrict__ d = ep.dinv + row * (BR * BR);
 #pragma unroll
       for (int r = 0; r < BR; ++r) {
@@ -404,6 +408,9 @@ struct BSellMat {
   const double* val;          // [steps * BS * 64]
 };
 
+#ifndef BSELL_UNROLL
+#define BSELL_UNROLL 2
+#endif
 template <int BS, int EP>
 __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n_slices, BSellMat M,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
     }
   }
   double acc = 0.0;
-#pragma unroll 2
+#pragma unroll BSELL_UNROLL
   for (int k = 0; k < w; ++k) {
     const int c = cb[k * RB + rbl];        // cached load: the RB*4-byte column chunks of consecutive steps share cache lines
     const double* __restrict__ xv = x + (int64_t)c * BS;
@@ -449,6 +456,7 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
   double out = 0.0;
   if (EP == EP_JAC) {
     const double t = active ? (hoist ? ob : ep.b[i]) - acc : 0.0;
+    if (active && ep.y2) ep.y2[i] = t;
     const int base = lane - r;
     double u = 0.0;
 #pragma unroll
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(BLOCK) void bcsr_rowlane_kernel(int64_t n_rows, con
   double out = 0.0;
   if (EP == EP_JAC) {           // square blocks only
     const double t = (active && g == 0) ? ep.b[i] - acc : 0.0;
+    if (active && g == 0 && ep.y2) ep.y2[i] = t;
     const int base = lane - r;
     double u = 0.0;
 #pragma unroll
