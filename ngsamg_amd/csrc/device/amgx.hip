@@ -496,6 +496,23 @@ struct Handle {
   std::map<GraphKey, hipGraphExec_t> graphs;
   // staging for host-pointer calls
   DevBuf<double> stage[3];
+  DevBuf<double> stage_raw[3];          // host vectors of permuted levels: raw copy before / after the renumbering
+  // Gauss-Seidel levels are stored in colour-major numbering (see LevelPerm in create()); perm[l][new] = old row of the
+  // caller's numbering, empty = identity.  Every C-ABI entry point translates its vectors (struct Staged).
+  std::vector<DevBuf<int32_t>> perm;
+  bool permuted(int l) const { return l >= 0 && l < (int)perm.size() && perm[l].n > 0; }
+  void perm_gather(int l, const double* src, double* dst) {
+    const int64_t len = lev[l].len();
+    if (!len) return;
+    hipLaunchKernelGGL(perm_gather_kernel, dim3(grid_for(len)), dim3(BLOCK), 0, stream, len, lev[l].bs, perm[l].p, src, dst);
+    HIPCHK(hipGetLastError());
+  }
+  void perm_scatter(int l, const double* src, double* dst) {
+    const int64_t len = lev[l].len();
+    if (!len) return;
+    hipLaunchKernelGGL(perm_scatter_kernel, dim3(grid_for(len)), dim3(BLOCK), 0, stream, len, lev[l].bs, perm[l].p, src, dst);
+    HIPCHK(hipGetLastError());
+  }
 
   ~Handle() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
@@ -990,7 +1007,9 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     g.color_slice_ptr.resize(nc + 1);
     for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / R);
     HostSell S;
-    build_sell(d.A, rows.data(), (int64_t)rows.size(), true, G, S);
+    // (absolute 16-bit column bases, not row-relative: the row product then does not depend on the rowid load)
+    const bool gs_rowrel = std::getenv("AMGX_GS_ROWREL") != nullptr;
+    build_sell(d.A, rows.data(), (int64_t)rows.size(), gs_rowrel, G, S);
     upload_sell(S, g.sell);
     g.rowid.upload(rows);
     g.n_slices_total = (int)(S.slice_ptr.size() - 1);
@@ -1022,7 +1041,7 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
         amgx_matrix F = d.A;
         F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
         HostSell SP;
-        build_sell(F, rows.data(), (int64_t)rows.size(), true, G, SP);
+        build_sell(F, rows.data(), (int64_t)rows.size(), gs_rowrel, G, SP);
         if ((int)(SP.slice_ptr.size() - 1) != g.n_slices_total) throw Err("build_gs: split copy has a different slice count");
         upload_sell(SP, part == 0 ? g.lower : g.upper);
       }
@@ -1135,6 +1154,104 @@ static void fold_prolongation(const amgx_matrix& A, const amgx_matrix& P, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Colour-major numbering of Gauss-Seidel levels.  A colour kernel touches the rows of ONE colour; in the caller's
+// numbering those are every ~8th row, so x, b and dinv were read and written with 1/8 line utilisation, eight times
+// per sweep (GS V-cycle at cfg 2: colour kernels at 2-3 TB/s).  With the rows of a colour stored contiguously the
+// same kernels stream.  The renumbering is internal: the host matrices are permuted once here (P A P^T, rows of P,
+// columns of P^T, ...) and the entry points translate vectors at the boundary (two extra passes over b and x per
+// application, ~60 us at cfg 2, against ~400 us saved).  AMGX_NO_GS_PERM=1 keeps the caller's numbering.
+struct LevelPerm {
+  std::vector<int32_t> perm, iperm;       // perm[new] = old, iperm[old] = new; empty = identity
+  HostCsr A, P, PT;
+  std::vector<double> dinv;
+  std::vector<uint8_t> free_dofs;
+  std::vector<int32_t> color;
+};
+
+// rows reordered by rperm (new -> old, or null), columns renumbered by ciperm (old -> new, or null), rows re-sorted
+static void permute_matrix(const amgx_matrix& M, const int32_t* rperm, const int32_t* ciperm, HostCsr& out) {
+  const int64_t n = M.n_rows;
+  const int bb = M.br * M.bc;
+  out.rowptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) { const int64_t o = rperm ? rperm[i] : i; out.rowptr[i + 1] = out.rowptr[i] + (M.rowptr[o + 1] - M.rowptr[o]); }
+  const int64_t nnz = out.rowptr[n];
+  out.col.resize((size_t)nnz);
+  out.val.resize((size_t)nnz * bb);
+  int T = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+  if (const char* e = std::getenv("OMP_NUM_THREADS")) T = std::max(1, std::min(T, std::atoi(e)));
+  T = (int)std::max<int64_t>(1, std::min<int64_t>(T, n / 8192 + 1));
+  auto work = [&](int t) {
+    std::vector<std::pair<int32_t, int64_t>> row;
+    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+      const int64_t o = rperm ? rperm[i] : i;
+      row.clear();
+      for (int64_t k = M.rowptr[o]; k < M.rowptr[o + 1]; ++k) row.emplace_back(ciperm ? ciperm[M.col[k]] : M.col[k], k);
+      if (ciperm) std::sort(row.begin(), row.end());
+      int64_t w = out.rowptr[i];
+      for (const auto& e : row) {
+        out.col[w] = e.first;
+        std::copy(M.val + e.second * bb, M.val + (e.second + 1) * bb, out.val.begin() + w * bb);
+        ++w;
+      }
+    }
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+}
+
+static void use_csr(amgx_matrix& M, const HostCsr& c) { M.rowptr = c.rowptr.data(); M.col = c.col.data(); M.val = c.val.data(); }
+
+// fills pl (mutable copies of the level descriptors) with colour-major versions of the GS levels; store owns the data
+static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_level_desc>& pl, std::vector<LevelPerm>& store) {
+  const int L = d->n_levels;
+  // Measured NON-win (profiles/r01/gs_perm.txt): the colour kernels gain 7-20 %, but the transfers lose far more
+  // (P^T gathers its ~30 fine residuals per coarse row from 8 colour blocks: 129 -> 370 us; P: 78 -> 132 us) and the two
+  // translation passes cost 125 us: cycle 2.35 -> 2.54 ms at cfg 2.  Off unless AMGX_GS_PERM=1 (kept under test).
+  if (!std::getenv("AMGX_GS_PERM")) return;
+  for (int l = 0; l < L; ++l) if (pl[l].A.n_rows != pl[l].A.n_cols) return;     // rank-partitioned handle: vectors carry ghosts
+  bool any = false;
+  for (int l = 0; l + 1 < L; ++l) {
+    const amgx_level_desc& s = pl[l];
+    if (s.sm_type != AMGX_SM_GS || !s.color || s.n_colors <= 0 || s.A.n_rows < 2) continue;
+    const int64_t n = s.A.n_rows;
+    LevelPerm& lp = store[l];
+    // stable counting sort by colour, rows without a colour (non-free) last
+    std::vector<int64_t> start(s.n_colors + 2, 0);
+    for (int64_t i = 0; i < n; ++i) { const int c = s.color[i]; if (c >= s.n_colors) throw Err("colour index out of range"); start[(c < 0 ? s.n_colors : c) + 1]++; }
+    for (int c = 0; c <= s.n_colors; ++c) start[c + 1] += start[c];
+    lp.perm.resize(n); lp.iperm.resize(n);
+    for (int64_t i = 0; i < n; ++i) { const int c = s.color[i] < 0 ? s.n_colors : s.color[i]; const int64_t q = start[c]++; lp.perm[q] = (int32_t)i; lp.iperm[i] = (int32_t)q; }
+    any = true;
+  }
+  if (!any) return;
+  for (int l = 0; l < L; ++l) {
+    amgx_level_desc& s = pl[l];
+    LevelPerm& lp = store[l];
+    const bool me = !lp.perm.empty();
+    const bool nxt = l + 1 < L && !store[l + 1].perm.empty();
+    if (me) {
+      const int64_t n = s.A.n_rows;
+      const int b2 = s.A.br * s.A.br;
+      permute_matrix(s.A, lp.perm.data(), lp.iperm.data(), lp.A);
+      use_csr(s.A, lp.A);
+      if (s.dinv) { lp.dinv.resize((size_t)n * b2); for (int64_t i = 0; i < n; ++i) std::copy(s.dinv + (int64_t)lp.perm[i] * b2, s.dinv + ((int64_t)lp.perm[i] + 1) * b2, lp.dinv.begin() + i * b2); s.dinv = lp.dinv.data(); }
+      if (s.free_dofs) { lp.free_dofs.resize(n); for (int64_t i = 0; i < n; ++i) lp.free_dofs[i] = s.free_dofs[lp.perm[i]]; s.free_dofs = lp.free_dofs.data(); }
+      if (s.color) { lp.color.resize(n); for (int64_t i = 0; i < n; ++i) lp.color[i] = s.color[lp.perm[i]]; s.color = lp.color.data(); }
+    }
+    if ((me || nxt) && l + 1 < L && s.P.rowptr) {
+      permute_matrix(s.P, me ? lp.perm.data() : nullptr, nxt ? store[l + 1].iperm.data() : nullptr, lp.P);
+      use_csr(s.P, lp.P);
+      permute_matrix(s.PT, nxt ? store[l + 1].perm.data() : nullptr, me ? lp.iperm.data() : nullptr, lp.PT);
+      use_csr(s.PT, lp.PT);
+    }
+  }
+}
+
 static Handle* create(const amgx_hierarchy_desc* d) {
   if (!d || d->n_levels < 1 || !d->levels) throw Err("amgx_create: empty hierarchy descriptor");
   int ndev = 0;
@@ -1152,8 +1269,14 @@ static Handle* create(const amgx_hierarchy_desc* d) {
   HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   h->lev.resize(d->n_levels);
+  std::vector<amgx_level_desc> pl(d->levels, d->levels + d->n_levels);
+  std::vector<LevelPerm> pstore(d->n_levels);
+  permute_gs_levels(d, pl, pstore);
+  h->perm.resize(d->n_levels);
+  for (int l = 0; l < d->n_levels; ++l) if (!pstore[l].perm.empty()) h->perm[l].upload(pstore[l].perm);
+  const amgx_level_desc* levels = pl.data();
   for (int l = 0; l < d->n_levels; ++l) {
-    const amgx_level_desc& s = d->levels[l];
+    const amgx_level_desc& s = levels[l];
     DevLevel& L = h->lev[l];
     // n_cols > n_rows: the trailing columns are ghost entries of a rank-partitioned level (filled by the caller's
     // halo exchange before every operation that gathers from them)
@@ -1165,7 +1288,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     // block GS walks the CSR arrays of A, so keep A in CSR there
     upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1);
     if (!last) {
-      const amgx_level_desc& c = d->levels[l + 1];
+      const amgx_level_desc& c = levels[l + 1];
       if (s.P.n_rows != s.A.n_rows || s.P.n_cols > c.A.n_cols || s.P.n_cols < c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
         throw Err("P does not match the level matrices");
       if (s.PT.n_rows != s.P.n_cols || s.PT.n_cols != s.P.n_rows || s.PT.br != s.P.bc || s.PT.bc != s.P.br)
@@ -1270,7 +1393,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     if (d->cycle == AMGX_CYCLE_V && d->clev == AMGX_CLEV_INV && L >= 2 && !std::getenv("AMGX_NO_TAIL_KERNEL")) {
       T = L - 1;
       while (T - 1 >= 1) {
-        const amgx_level_desc& s = d->levels[T - 1];
+        const amgx_level_desc& s = levels[T - 1];
         const int64_t cap = s.sm_type == AMGX_SM_GS ? TAIL_MAX_ROWS_GS : TAIL_MAX_ROWS;
         const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= cap &&
                         (s.sm_type == AMGX_SM_JACOBI || (s.sm_type == AMGX_SM_GS && s.color && s.n_colors > 0)) &&
@@ -1291,7 +1414,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
                               EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward});
       };
       for (int l = T; l + 1 < L; ++l) {
-        const amgx_level_desc& s = d->levels[l];
+        const amgx_level_desc& s = levels[l];
         DevLevel& V = h->lev[l];
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
         V.tA.upload(s.A); V.tP.upload(s.P); V.tPT.upload(s.PT);
@@ -1315,7 +1438,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
           spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p, 0});
         } else {                               // x = 0; forward sweep; r = b - A x
           prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0});
-          gs(V, d->levels[l].n_colors, 0);
+          gs(V, levels[l].n_colors, 0);
           spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr, 0});
         }
         spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, none);   // b_{l+1} = P^T r
@@ -1329,7 +1452,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
           spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr, 0});
         } else {                               // x += P x_{l+1} ; backward sweep
           spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.x.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr, 0});
-          gs(V, d->levels[l].n_colors, 1);
+          gs(V, levels[l].n_colors, 1);
         }
       }
       h->tail_prog.upload(prog);
@@ -1370,21 +1493,45 @@ struct Staged {
   amgx::Handle& h;
   bool host;
   Staged(amgx::Handle& hh, int flags) : h(hh), host(!(flags & AMGX_DEVICE_PTR)) {}
-  const double* in(int slot, const double* p, int64_t n) {
-    if (!host || !p) return p;
-    if ((int64_t)h.stage[slot].n < n) h.stage[slot].alloc(n);
-    HIPCHK(hipMemcpyAsync(h.stage[slot].p, p, n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+  static void fit(amgx::DevBuf<double>& b, int64_t n) { if ((int64_t)b.n < n) b.alloc(n); }
+  // lvl >= 0: the vector belongs to that level; if the level is stored in colour-major numbering the device copy is
+  // renumbered (device pointers too: the work then runs on the staging buffers)
+  const double* in(int slot, const double* p, int64_t n, int lvl = -1) {
+    if (!p) return p;
+    const bool pm = h.permuted(lvl);
+    if (!host && !pm) return p;
+    const double* src = p;
+    if (host) {
+      amgx::DevBuf<double>& dst = pm ? h.stage_raw[slot] : h.stage[slot];
+      fit(dst, n);
+      HIPCHK(hipMemcpyAsync(dst.p, p, n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+      if (!pm) return dst.p;
+      src = dst.p;
+    }
+    fit(h.stage[slot], n);
+    h.perm_gather(lvl, src, h.stage[slot].p);
     return h.stage[slot].p;
   }
-  double* inout(int slot, double* p, int64_t n, bool load) {
-    if (!host || !p) return p;
-    if ((int64_t)h.stage[slot].n < n) h.stage[slot].alloc(n);
-    if (load) HIPCHK(hipMemcpyAsync(h.stage[slot].p, p, n * sizeof(double), hipMemcpyHostToDevice, h.stream));
+  double* inout(int slot, double* p, int64_t n, bool load, int lvl = -1) {
+    if (!p) return p;
+    const bool pm = h.permuted(lvl);
+    if (!host && !pm) return p;
+    if (load) return const_cast<double*>(in(slot, p, n, lvl));
+    fit(h.stage[slot], n);
     return h.stage[slot].p;
   }
-  void out(int slot, double* p, int64_t n) {
-    if (!host || !p) return;
-    HIPCHK(hipMemcpyAsync(p, h.stage[slot].p, n * sizeof(double), hipMemcpyDeviceToHost, h.stream));
+  void out(int slot, double* p, int64_t n, int lvl = -1) {
+    if (!p) return;
+    const bool pm = h.permuted(lvl);
+    if (!host && !pm) return;
+    const double* src = h.stage[slot].p;
+    if (pm) {
+      double* dst = p;
+      if (host) { fit(h.stage_raw[slot], n); dst = h.stage_raw[slot].p; }
+      h.perm_scatter(lvl, src, dst);
+      src = dst;
+    }
+    if (host) HIPCHK(hipMemcpyAsync(p, src, n * sizeof(double), hipMemcpyDeviceToHost, h.stream));
   }
   void finish() { if (host) HIPCHK(hipStreamSynchronize(h.stream)); }
 };
@@ -1426,10 +1573,10 @@ int amgx_apply(amgx_handle hh, const double* b, double* x, int b_status, int fla
     if (b == x) throw amgx::Err("amgx_apply: b and x must not alias");
     const int64_t n = h.lev[0].len();
     Staged st(h, flags);
-    const double* db = st.in(0, b, n);
-    double* dx = st.inout(1, x, n, false);
+    const double* db = st.in(0, b, n, 0);
+    double* dx = st.inout(1, x, n, false, 0);
     h.run_cycle(dx, db, !(flags & AMGX_NO_GRAPH));
-    st.out(1, x, n);
+    st.out(1, x, n, 0);
     st.finish();
   });
 }
@@ -1439,11 +1586,11 @@ int amgx_apply_add(amgx_handle hh, double s, const double* b, double* x, int fla
     if (!b || !x) throw amgx::Err("amgx_apply_add: null vector");
     const int64_t n = h.lev[0].len();
     Staged st(h, flags);
-    const double* db = st.in(0, b, n);
-    double* dx = st.inout(1, x, n, true);
+    const double* db = st.in(0, b, n, 0);
+    double* dx = st.inout(1, x, n, true, 0);
     h.run_cycle(h.lev[0].x.p, db, !(flags & AMGX_NO_GRAPH));     // cycle into x_level[0] (amg_matrix.cpp:385-389)
     h.axpy(n, s, h.lev[0].x.p, dx);
-    st.out(1, x, n);
+    st.out(1, x, n, 0);
     st.finish();
   });
 }
@@ -1457,12 +1604,12 @@ int amgx_smooth(amgx_handle hh, int level, int dir, double* x, const double* b, 
     if (!x || !b || !res) throw amgx::Err("amgx_smooth: null vector");
     const int64_t n = L.len();
     Staged st(h, flags);
-    double* dx = st.inout(0, x, L.ext_len(), true);        // ghost entries (if any) are read, never written
-    const double* db = st.in(1, b, n);
-    double* dr = st.inout(2, res, n, true);
+    double* dx = st.inout(0, x, L.ext_len(), true, level);        // ghost entries (if any) are read, never written
+    const double* db = st.in(1, b, n, level);
+    double* dr = st.inout(2, res, n, true, level);
     h.level_smooth(L, dir, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
-    st.out(0, x, n);
-    st.out(2, res, n);
+    st.out(0, x, n, level);
+    st.out(2, res, n, level);
     st.finish();
   });
 }
@@ -1473,12 +1620,12 @@ int amgx_smooth_v_from_level(amgx_handle hh, int level, double* x, const double*
     if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_smooth_v_from_level: level out of range");
     const int64_t n = h.lev[level].len();
     Staged st(h, flags);
-    double* dx = st.inout(0, x, n, true);
-    const double* db = st.in(1, b, n);
-    double* dr = st.inout(2, res, n, true);
+    double* dx = st.inout(0, x, n, true, level);
+    const double* db = st.in(1, b, n, level);
+    double* dr = st.inout(2, res, n, true, level);
     h.smooth_v_from_level(level, dx, db, dr, res_updated != 0, update_res != 0, x_zero != 0);
-    st.out(0, x, n);
-    st.out(2, res, n);
+    st.out(0, x, n, level);
+    st.out(2, res, n, level);
     st.finish();
   });
 }
@@ -1489,11 +1636,11 @@ int amgx_residual(amgx_handle hh, int level, const double* x, const double* b, d
     if (!x || !b || !r || x == r) throw amgx::Err("amgx_residual: bad vectors");
     amgx::DevLevel& L = h.lev[level];
     Staged st(h, flags);
-    const double* dx = st.in(0, x, L.ext_len());
-    const double* db = st.in(1, b, L.len());
-    double* dr = st.inout(2, r, L.len(), false);
+    const double* dx = st.in(0, x, L.ext_len(), level);
+    const double* db = st.in(1, b, L.len(), level);
+    double* dr = st.inout(2, r, L.len(), false, level);
     h.residual(L.A, dx, db, dr);
-    st.out(2, r, L.len());
+    st.out(2, r, L.len(), level);
     st.finish();
   });
 }
@@ -1505,12 +1652,12 @@ int amgx_jacobi_pre(amgx_handle hh, int level, const double* b, double* x, doubl
     if (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI) throw amgx::Err("amgx_jacobi_pre: level has no Jacobi smoother");
     if (!b || !x || !r) throw amgx::Err("amgx_jacobi_pre: null vector");
     Staged st(h, flags);
-    const double* db = st.in(0, b, L.ext_len());
-    double* dx = st.inout(1, x, L.len(), false);
-    double* dr = st.inout(2, r, L.len(), false);
+    const double* db = st.in(0, b, L.ext_len(), level);
+    double* dx = st.inout(1, x, L.len(), false, level);
+    double* dr = st.inout(2, r, L.len(), false, level);
     h.pre_smooth(L, dx, db, dr);
-    st.out(1, x, L.len());
-    st.out(2, r, L.len());
+    st.out(1, x, L.len(), level);
+    st.out(2, r, L.len(), level);
     st.finish();
   });
 }
@@ -1522,12 +1669,12 @@ int amgx_cycle_down(amgx_handle hh, int level, const double* b, double* x, doubl
     if (!h.folded(L)) throw amgx::Err("amgx_cycle_down: level has no folded prolongation Q (use amgx_jacobi_pre / amgx_transfer_f2c)");
     if (!b || !x || !b_coarse) throw amgx::Err("amgx_cycle_down: null vector");
     Staged st(h, flags);
-    const double* db = st.in(0, b, L.ext_len());
-    double* dx = st.inout(1, x, L.len(), false);
-    double* dc = st.inout(2, b_coarse, h.lev[level + 1].len(), false);
+    const double* db = st.in(0, b, L.ext_len(), level);
+    double* dx = st.inout(1, x, L.len(), false, level);
+    double* dc = st.inout(2, b_coarse, h.lev[level + 1].len(), false, level + 1);
     h.pre_smooth_restrict(level, dx, db, L.res.p, dc, true);
-    st.out(1, x, L.len());
-    st.out(2, b_coarse, h.lev[level + 1].len());
+    st.out(1, x, L.len(), level);
+    st.out(2, b_coarse, h.lev[level + 1].len(), level + 1);
     st.finish();
   });
 }
@@ -1539,10 +1686,10 @@ int amgx_cycle_up(amgx_handle hh, int level, double* x, const double* x_coarse, 
     if (!h.folded(L)) throw amgx::Err("amgx_cycle_up: level has no folded prolongation Q (use amgx_prolong / amgx_jacobi_post)");
     if (!x || !x_coarse) throw amgx::Err("amgx_cycle_up: null vector");
     Staged st(h, flags);
-    double* dx = st.inout(0, x, L.len(), true);
-    const double* dc = st.in(1, x_coarse, L.Q.n_cols);
+    double* dx = st.inout(0, x, L.len(), true, level);
+    const double* dc = st.in(1, x_coarse, L.Q.n_cols, level + 1);
     h.post_smooth(level, dx, nullptr, L.res.p, dc, true);
-    st.out(0, x, L.len());
+    st.out(0, x, L.len(), level);
     st.finish();
   });
 }
@@ -1554,11 +1701,11 @@ int amgx_jacobi_post(amgx_handle hh, int level, const double* xin, const double*
     if (!L.dinv.p || L.sm_type != AMGX_SM_JACOBI) throw amgx::Err("amgx_jacobi_post: level has no Jacobi smoother");
     if (!xin || !b || !xout || xin == xout) throw amgx::Err("amgx_jacobi_post: bad vectors");
     Staged st(h, flags);
-    const double* dxi = st.in(0, xin, L.ext_len());
-    const double* db = st.in(1, b, L.len());
-    double* dxo = st.inout(2, xout, L.len(), false);
+    const double* dxi = st.in(0, xin, L.ext_len(), level);
+    const double* db = st.in(1, b, L.len(), level);
+    double* dxo = st.inout(2, xout, L.len(), false, level);
     h.jacobi_fused(L, dxi, db, dxo);
-    st.out(2, xout, L.len());
+    st.out(2, xout, L.len(), level);
     st.finish();
   });
 }
@@ -1568,11 +1715,11 @@ int amgx_prolong(amgx_handle hh, int level, double fac, const double* x_in, cons
     if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_prolong: level out of range");
     if (!x_in || !x_coarse || !x_out) throw amgx::Err("amgx_prolong: null vector");
     Staged st(h, flags);
-    const double* di = st.in(0, x_in, h.lev[level].len());
-    const double* dc = st.in(1, x_coarse, h.lev[level].P.n_cols * h.lev[level].P.bc);
-    double* dout = st.inout(2, x_out, h.lev[level].len(), false);
+    const double* di = st.in(0, x_in, h.lev[level].len(), level);
+    const double* dc = st.in(1, x_coarse, h.lev[level].P.n_cols * h.lev[level].P.bc, level + 1);
+    double* dout = st.inout(2, x_out, h.lev[level].len(), false, level);
     h.mult_add(h.lev[level].P, fac, dc, di, dout);
-    st.out(2, x_out, h.lev[level].len());
+    st.out(2, x_out, h.lev[level].len(), level);
     st.finish();
   });
 }
@@ -1583,10 +1730,10 @@ int amgx_matvec(amgx_handle hh, int level, const double* x, double* y, int flags
     if (!x || !y || x == y) throw amgx::Err("amgx_matvec: bad vectors");
     const int64_t n = h.lev[level].len();
     Staged st(h, flags);
-    const double* dx = st.in(0, x, h.lev[level].ext_len());
-    double* dy = st.inout(1, y, n, false);
+    const double* dx = st.in(0, x, h.lev[level].ext_len(), level);
+    double* dy = st.inout(1, y, n, false, level);
     h.mult(h.lev[level].A, dx, dy);
-    st.out(1, y, n);
+    st.out(1, y, n, level);
     st.finish();
   });
 }
@@ -1595,10 +1742,10 @@ int amgx_transfer_f2c(amgx_handle hh, int level, const double* xf, double* xc, i
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_transfer_f2c: level out of range");
     Staged st(h, flags);
-    const double* df = st.in(0, xf, h.lev[level].len());
-    double* dc = st.inout(1, xc, h.lev[level + 1].len(), false);
+    const double* df = st.in(0, xf, h.lev[level].len(), level);
+    double* dc = st.inout(1, xc, h.lev[level + 1].len(), false, level + 1);
     h.transfer_f2c(level, df, dc);
-    st.out(1, xc, h.lev[level + 1].len());
+    st.out(1, xc, h.lev[level + 1].len(), level + 1);
     st.finish();
   });
 }
@@ -1607,10 +1754,10 @@ int amgx_add_c2f(amgx_handle hh, int level, double fac, double* xf, const double
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level + 1 >= h.n_levels()) throw amgx::Err("amgx_add_c2f: level out of range");
     Staged st(h, flags);
-    double* df = st.inout(0, xf, h.lev[level].len(), true);
-    const double* dc = st.in(1, xc, h.lev[level + 1].len());
+    double* df = st.inout(0, xf, h.lev[level].len(), true, level);
+    const double* dc = st.in(1, xc, h.lev[level + 1].len(), level + 1);
     h.add_c2f(level, fac, df, dc);
-    st.out(0, xf, h.lev[level].len());
+    st.out(0, xf, h.lev[level].len(), level);
     st.finish();
   });
 }

@@ -549,10 +549,14 @@ __global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int sl
   // G lanes per row (SELL-G slices of 64/G rows): short dependent chains on the coarse levels, where a colour has
   // only a few hundred rows of ~50 entries and one thread per row would be pure latency
   const int row = rowid[(int64_t)s * (WAVE / G) + lane / G];
+  // own-row operands requested before the row product (one dependent round trip less per wave, see EPF_HOIST)
+  const bool writer = row >= 0 && (lane % G) == 0;
+  double dv = 0.0, bv = 0.0, xv = 0.0;
+  if (writer) { dv = dinv[row]; bv = b[row]; xv = x[row]; }
   double acc = row >= 0 ? sell_row_dot(M, s, lane, row, x) : 0.0;
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-  if (row >= 0 && (lane % G) == 0) x[row] += dinv[row] * (b[row] - acc);
+  if (writer) x[row] = xv + dv * (bv - acc);
 }
 
 // r = -(U x) on the colour-major rows: the residual right after a forward sweep from x = 0, where
@@ -869,6 +873,25 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
     }
     __syncthreads();     // workgroup-scope release/acquire: the next operation reads what this one wrote
   }
+}
+
+// dst[i] = src[perm[i]] (gather) / dst[perm[i]] = src[i] (scatter) on block vectors with bs entries per block row:
+// translation between the caller's numbering and the colour-major numbering of Gauss-Seidel levels (amgx.hip, LevelPerm)
+__global__ __launch_bounds__(BLOCK) void perm_gather_kernel(int64_t len, int bs, const int32_t* __restrict__ perm,
+                                                            const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= len) return;
+  const int64_t i = t / bs;
+  const int c = (int)(t - i * bs);
+  dst[t] = src[(int64_t)perm[i] * bs + c];
+}
+__global__ __launch_bounds__(BLOCK) void perm_scatter_kernel(int64_t len, int bs, const int32_t* __restrict__ perm,
+                                                             const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= len) return;
+  const int64_t i = t / bs;
+  const int c = (int)(t - i * bs);
+  dst[(int64_t)perm[i] * bs + c] = src[t];
 }
 
 // dense y = M x, one wave per row (coarsest-level inverse, n <= a few hundred)

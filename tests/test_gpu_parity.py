@@ -337,6 +337,47 @@ def test_folded_post_smoothing_matches_literal_sequence_and_oracle(monkeypatch):
     assert w.matrix_info(0, "Q")["fmt"] is None
 
 
+def test_gs_colour_major_numbering_option(monkeypatch):
+    """AMGX_GS_PERM=1 stores Gauss-Seidel levels in colour-major numbering and translates vectors at every entry point
+    (a measured non-win, off by default): cycles and stage calls must be unchanged for the caller"""
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    monkeypatch.setenv("AMGX_GS_PERM", "1")
+    for H, p in ((lambda t: (t[1], t[0]))(poisson_case((17, 17, 17), "right|top", 20)), (lambda t: (t[1], t[0]))(elasticity_case((9, 8, 7), False, 5, 0.12))):
+        b = rhs(p, 4)
+        orc = Oracle(H.levels, sm_type="gs_mc")
+        for cyc in ("V", "W"):
+            dev = _dev(H, sm_type="gs", mg_cycle=cyc)
+            x = np.full(b.size, np.nan)
+            dev.Mult(b, x)
+            assert _rel(x, Oracle(H.levels, sm_type="gs_mc", cycle=cyc).apply(b)) < 1e-10
+        dev = _dev(H, sm_type="gs")
+        rng = np.random.default_rng(2)
+        for l in range(H.n_levels - 1):
+            n = dev.sizes[l]
+            v = rng.standard_normal(n)
+            y = np.empty(n)
+            dev.MatVec(l, v, y)
+            assert _rel(y, orc.matvec(l, v)) < 1e-13
+            xc = np.empty(dev.sizes[l + 1])
+            dev.TransferF2C(l, v, xc)
+            assert _rel(xc, orc.transfer_f2c(l, v)) < 1e-13
+            a, c = v.copy(), v.copy()
+            xcr = rng.standard_normal(dev.sizes[l + 1])
+            dev.AddC2F(l, 1.0, a, xcr)
+            orc.add_c2f(l, 1.0, c, xcr)
+            assert _rel(a, c) < 1e-13
+            bb, x0 = rng.standard_normal(n), rng.standard_normal(n)
+            xo, ro, xg, rg = x0.copy(), np.zeros(n), x0.copy(), np.zeros(n)
+            orc.smooth(l, xo, bb, ro, False, True, False, True)
+            dev.Smooth(l, xg, bb, rg, False, True, False, back=True)
+            assert _rel(xg, xo) < 1e-10 and _rel(rg, ro) < 1e-9
+        import torch
+        bt, xt = torch.from_numpy(b).cuda(), torch.zeros(b.size, dtype=torch.float64, device="cuda")
+        dev.Mult(bt, xt)                       # device pointers: work runs on the renumbered staging buffers
+        assert _rel(xt.cpu().numpy(), orc.apply(b)) < 1e-10
+
+
 @pytest.mark.parametrize("sm", ["jacobi", "gs"])
 def test_size_independent_properties_at_large_size(sm):
     """1.1 M DOF (the one-thread-per-row SELL path, 16-bit column deltas, graph replay): properties that need no oracle --
