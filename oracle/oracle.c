@@ -9,6 +9,7 @@
 
 #define MAXBS 6
 
+#define ORC_MAX_OWNED 512
 struct orc_handle {
   int n_levels;
   orc_level* lev;            /* copies of the descriptors (arrays are borrowed) */
@@ -23,6 +24,8 @@ struct orc_handle {
   double* crs_L;             /* nf x nf lower factor */
   double* crs_tmp;
   double** x_old;            /* per level: snapshot of x for hybrid GS */
+  void* owned[ORC_MAX_OWNED];   /* arrays allocated by orc_first_touch (everything else is borrowed) */
+  int n_owned;
 };
 
 static struct orc_handle* g_cur = NULL;   /* set by the public entry points (the oracle is single-threaded at this level) */
@@ -36,6 +39,19 @@ void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 static int fail(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); return 1; }
 
 static inline int64_t vlen(const orc_level* L) { return L->A.n_rows * L->A.br; }
+
+/* vector helpers of the cycles, threaded like the sparse kernels (the multi-threaded CPU baseline would otherwise
+ * spend a fifth of its time in single-threaded memset / memcpy of 80 MB vectors) */
+static void vzero(double* x, int64_t n) {
+  if (g_threads <= 1) { memset(x, 0, sizeof(double) * n); return; }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i < n; i++) x[i] = 0.0;
+}
+static void vcopy(double* dst, const double* src, int64_t n) {
+  if (g_threads <= 1) { memcpy(dst, src, sizeof(double) * n); return; }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i < n; i++) dst[i] = src[i];
+}
 
 /* ---------------------------------------------------------------- sparse kernels (NGSolve's part) */
 
@@ -255,8 +271,8 @@ static void smooth_v_from_level(orc_handle* h, int start, double* x, const doubl
 static void prep_level(orc_handle* h, int l) {
   /* x_l = 0; r_l = b_l   (amg_matrix.cpp:193-202) */
   const int64_t n = vlen(&h->lev[l]);
-  memset(h->x_level[l], 0, sizeof(double) * n);
-  memcpy(h->res_level[l], h->rhs_level[l], sizeof(double) * n);
+  vzero(h->x_level[l], n);
+  vcopy(h->res_level[l], h->rhs_level[l], n);
 }
 
 static void cycle_v(orc_handle* h, double* x, const double* b) {
@@ -266,8 +282,8 @@ static void cycle_v(orc_handle* h, double* x, const double* b) {
     const double* bl = l == 0 ? b : h->rhs_level[l];
     double* rl = h->res_level[l];
     const int64_t n = vlen(&h->lev[l]);
-    memset(xl, 0, sizeof(double) * n);
-    memcpy(rl, bl, sizeof(double) * n);
+    vzero(xl, n);
+    vcopy(rl, bl, n);
     level_smooth(&h->lev[l], 0, xl, bl, rl, 1, 1, 1);
     transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
   }
@@ -291,8 +307,8 @@ static void w_rec(orc_handle* h, int l, double* x0, const double* b0) {
     const double* bl = l == 0 ? b0 : h->rhs_level[l];
     double* rl = h->res_level[l];
     const int64_t n = vlen(&h->lev[l]);
-    memset(xl, 0, sizeof(double) * n);
-    memcpy(rl, bl, sizeof(double) * n);
+    vzero(xl, n);
+    vcopy(rl, bl, n);
     level_smooth(&h->lev[l], 0, xl, bl, rl, 1, 1, 1);
     transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
     w_rec(h, l + 1, x0, b0);
@@ -316,8 +332,8 @@ static void cycle_bs(orc_handle* h, double* x, const double* b) {
     const double* bl = l == 0 ? b : h->rhs_level[l];
     double* rl = h->res_level[l];
     const int64_t n = vlen(&h->lev[l]);
-    memset(xl, 0, sizeof(double) * n);
-    memcpy(rl, bl, sizeof(double) * n);
+    vzero(xl, n);
+    vcopy(rl, bl, n);
     smooth_v_from_level(h, l, xl, bl, rl, 1, 1, 1);
     transfer_f2c(h, l, rl, h->rhs_level[l + 1]);
   }
@@ -438,8 +454,54 @@ int orc_create(const orc_desc* d, orc_handle** out) {
   return 0;
 }
 
+/* NUMA placement for the multi-threaded CPU baseline: private copies of the level data, every page first written by
+ * the thread that will stream it (same static row schedule as spmv / diag_add).  The caller's arrays usually were
+ * written by one thread, i.e. sit on one NUMA node. */
+static void* ft_copy_rows(const void* src, const int64_t* rowptr, int64_t n_rows, size_t bytes_per_entry) {
+  const int64_t nnz = rowptr ? rowptr[n_rows] : n_rows;
+  char* dst = (char*)malloc((size_t)(nnz > 0 ? nnz : 1) * bytes_per_entry);
+  if (!dst) return NULL;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i < n_rows; i++) {
+    const int64_t a = rowptr ? rowptr[i] : i, b = rowptr ? rowptr[i + 1] : i + 1;
+    memcpy(dst + (size_t)a * bytes_per_entry, (const char*)src + (size_t)a * bytes_per_entry, (size_t)(b - a) * bytes_per_entry);
+  }
+  return dst;
+}
+
+static int ft_matrix(orc_handle* h, orc_matrix* M) {
+  if (!M->rowptr || M->n_rows == 0) return 0;
+  int64_t* rp = (int64_t*)malloc(sizeof(int64_t) * (M->n_rows + 1));
+  if (!rp) return 1;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t i = 0; i <= M->n_rows; i++) rp[i] = M->rowptr[i];
+  int32_t* col = (int32_t*)ft_copy_rows(M->col, M->rowptr, M->n_rows, sizeof(int32_t));
+  double* val = (double*)ft_copy_rows(M->val, M->rowptr, M->n_rows, sizeof(double) * M->br * M->bc);
+  if (!col || !val) { free(rp); free(col); free(val); return 1; }
+  if (h->n_owned + 3 > ORC_MAX_OWNED) { free(rp); free(col); free(val); return 1; }
+  h->owned[h->n_owned++] = rp; h->owned[h->n_owned++] = col; h->owned[h->n_owned++] = val;
+  M->rowptr = rp; M->col = col; M->val = val;
+  return 0;
+}
+
+int orc_first_touch(orc_handle* h) {
+  if (!h) return fail("orc_first_touch: null handle");
+  for (int l = 0; l < h->n_levels; l++) {
+    orc_level* L = &h->lev[l];
+    if (ft_matrix(h, &L->A) || ft_matrix(h, &L->P) || ft_matrix(h, &L->PT)) return fail("orc_first_touch: out of memory");
+    if (L->dinv) {
+      double* d = (double*)ft_copy_rows(L->dinv, NULL, L->A.n_rows, sizeof(double) * L->A.br * L->A.br);
+      if (!d || h->n_owned + 1 > ORC_MAX_OWNED) { free(d); return fail("orc_first_touch: out of memory"); }
+      h->owned[h->n_owned++] = d;
+      L->dinv = d;
+    }
+  }
+  return 0;
+}
+
 void orc_destroy(orc_handle* h) {
   if (!h) return;
+  for (int i = 0; i < h->n_owned; i++) free(h->owned[i]);
   for (int l = 0; l < h->n_levels; l++) {
     if (h->x_level) free(h->x_level[l]);
     if (h->rhs_level) free(h->rhs_level[l]);

@@ -91,6 +91,9 @@ int orc_pcg(orc_handle* h, const orc_matrix* A, const double* b, double* x, doub
             double* errs, int* iters);
 /* number of OpenMP threads used for Jacobi / SpMV / transfers (GS stays sequential) */
 void orc_set_threads(int n);
+/* multi-threaded CPU baseline only: replace the borrowed level arrays by private copies whose pages are first written
+ * by the thread that streams them (NUMA placement); call after orc_set_threads / orc_create */
+int orc_first_touch(orc_handle* h);
 
 #ifdef __cplusplus
 }

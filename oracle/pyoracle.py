@@ -62,6 +62,7 @@ def lib():
     L.orc_pcg.argtypes = [vp, C.POINTER(orc_matrix), c_f64p, c_f64p, C.c_double, C.c_int, c_f64p, C.POINTER(C.c_int)]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_threads.restype = None
+    L.orc_first_touch.argtypes = [vp]
     _LIB = L
     return L
 
@@ -150,6 +151,10 @@ class Oracle:
         if getattr(self, "_h", None):
             lib().orc_destroy(self._h)
             self._h = None
+
+    def first_touch(self):
+        """NUMA placement of the level data for the multi-threaded CPU baseline (bench.py)"""
+        self._ck(lib().orc_first_touch(self._h))
 
     @staticmethod
     def set_threads(n):
