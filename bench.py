@@ -302,6 +302,12 @@ def main():
         except AttributeError:
             cores = os.cpu_count() or 1
         cores = min(cores, 64)                   # more threads than memory channels only adds OpenMP overhead
+        try:                                     # a container's CPU share (cgroup v2 cpu.max) is the real core count:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]      # threads beyond it are only throttled
+            if q != "max":
+                cores = max(1, min(cores, int(int(q) // int(per))))
+        except (OSError, ValueError):
+            pass
         orc = Oracle(H.levels, sm_type="jacobi" if args.smoother == "jacobi" else "gs", omega=0.9, threads=cores)
         if cores > 1:
             orc.first_touch()                    # NUMA placement: every thread first-writes the rows it streams
