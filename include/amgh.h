@@ -75,6 +75,20 @@ void amgh_destroy(amgh_hierarchy* h);
 int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, double* dinv_out);
 int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors);
 
+/* Block Gauss-Seidel data (reference BSmoother, src/base/smoothers/block_gssmoother.cpp:17-150).  Blocks are sets of
+ * block rows -- the aggregates of the level, as GetGSBlocks builds them (amg_pc_vertex_impl.hpp:1171-1269); block k owns
+ * block_rows[block_ptr[k] .. block_ptr[k+1]) (ascending).
+ * amgh_bgs_dinv: per block the inverse (pinv != 0: pseudo-inverse, utils_denseLA.hpp:1460-1570) of A restricted to the
+ *   block's scalar dofs: M_k x M_k, M_k = bs * |block k|, column-major, written at dinv_out + dinv_ptr[k]
+ *   (caller: dinv_ptr[k+1] = dinv_ptr[k] + M_k^2).
+ * amgh_bgs_coloring: greedy colouring of the block graph (blocks k, k' are coupled if A has an entry between their
+ *   rows): blocks of one colour can be relaxed in parallel (the reference colours for its shared-memory sweep too,
+ *   block_gssmoother.cpp:152-213). */
+int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows, int pinv,
+                  const int64_t* dinv_ptr, double* dinv_out);
+int amgh_bgs_coloring(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows,
+                      int32_t* color_out, int32_t* n_colors);
+
 /* sparse helpers exposed for tests and the Python utils mirror (SparseMM, reference python_utils.cpp:30-193) */
 int amgh_transpose_count(const amgh_matrix* A, int64_t* rowptr_out /*[n_cols+1]*/);
 int amgh_transpose_fill(const amgh_matrix* A, const int64_t* rowptr_T, int32_t* col_out, double* val_out);

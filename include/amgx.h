@@ -38,7 +38,9 @@ typedef struct amgx_matrix {
 /* smoother kinds = ngs_amg_sm_type (reference src/base/precond/amg_pc.cpp:1033-1138) */
 enum {
   AMGX_SM_JACOBI = 0,         /* JacobiSmoother<TM>, base_smoother.cpp:61-114         */
-  AMGX_SM_GS = 1              /* Gauss-Seidel (GSS3, gssmoother.cpp:196-398) executed as multicolour GS */
+  AMGX_SM_GS = 1,             /* Gauss-Seidel (GSS3, gssmoother.cpp:196-398) executed as multicolour GS */
+  AMGX_SM_BGS = 2             /* block Gauss-Seidel over aggregate blocks (BSmoother, block_gssmoother.cpp:17-498), */
+                              /*   blocks of one colour relaxed in parallel (the reference's sm_shm sweep does too) */
 };
 enum { AMGX_CYCLE_V = 0, AMGX_CYCLE_W = 1, AMGX_CYCLE_BS = 2 };   /* ngs_amg_mg_cycle, amg_matrix.hpp:37-43 */
 enum { AMGX_CLEV_NONE = 0, AMGX_CLEV_INV = 1 };                   /* ngs_amg_clev,     amg_matrix.cpp:217-247 */
@@ -61,6 +63,14 @@ typedef struct amgx_level_desc {
   int32_t sm_symm;            /* ngs_amg_sm_symm                                                     */
   const int32_t* color;       /* [n] colour of each free row (required for AMGX_SM_GS), -1 otherwise  */
   int32_t n_colors;
+  /* AMGX_SM_BGS only (amgh_bgs_dinv / amgh_bgs_coloring produce these): */
+  int32_t bgs_n_blocks;
+  const int32_t* bgs_block_ptr;   /* [n_blocks+1]; block k owns bgs_block_rows[ptr[k] .. ptr[k+1]) (disjoint sets)   */
+  const int32_t* bgs_block_rows;
+  const int64_t* bgs_dinv_ptr;    /* [n_blocks+1] offsets into bgs_dinv                                             */
+  const double* bgs_dinv;         /* per block the dense inverse of its diagonal block, M x M column-major, M = bs*size */
+  const int32_t* bgs_color;       /* [n_blocks] colour of each block; coupled blocks must differ                    */
+  int32_t bgs_n_colors;
   amgx_matrix Q;              /* optional (rowptr == NULL: none).  Folded post-smoothing prolongation                */
                               /*   Q = (I - omega*Dinv*A) P  of a Jacobi level of the V-cycle, n_rows x (coarse n_cols). */
                               /*   Square levels: the library builds it itself.  Rank-partitioned levels (A has ghost  */

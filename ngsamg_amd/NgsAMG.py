@@ -279,12 +279,14 @@ class _AMGPreconditioner:
         hier = Hierarchy(A, self._freedofs, self._coords, dim=dim, energy=self._energy, **opts)
         sm_type = str(f.get("sm_type", "gs")).lower()                     # amg_pc.hpp:63
         spec = f.get("sm_type_spec")
-        if sm_type not in ("gs", "jacobi"):
-            sm_type = "gs"                                                # bgs / dyn_block_gs ... fall back to gs (amg_pc_vertex_impl.hpp:587-593)
+        if sm_type not in ("gs", "jacobi", "bgs"):
+            sm_type = "gs"                                                # dyn_block_gs ... fall back to gs (amg_pc_vertex_impl.hpp:587-593)
         types = [sm_type] * hier.n_levels
         if spec:
             for i, t in enumerate(spec[: hier.n_levels]):
-                types[i] = t if t in ("gs", "jacobi") else "gs"
+                types[i] = t if t in ("gs", "jacobi", "bgs") else "gs"
+        if "bgs" in types:                                               # BuildBGSSmoother(mat, GetGSBlocks(level)), amg_pc.cpp:1060-1072
+            hier.build_bgs()
         clev = str(f.get("clev", "inv")).lower()
         dev = DeviceAMGMatrix(hier, sm_type=types, omega=float(f.get("sm_omega", 0.9)),
                               sm_steps=int(f.get("sm_steps", 1)), sm_symm=bool(f.get("sm_symm", False)),
@@ -476,6 +478,20 @@ def CreateHybridGSS(mat, freedofs=None, pinv=False, NG_MPI_overlap=True, NG_MPI_
                     symm_loc=False, nsteps=1, nsteps_loc=1, device=0):
     """single GPU: the hybrid smoother degenerates to (multicolour) Gauss-Seidel on the local matrix"""
     return _StandaloneSmoother(mat, freedofs, "gs", pinv=pinv, nsteps=nsteps, symm=symm, device=device)
+
+
+def CreateHybridBlockGSS(mat, blocks, NG_MPI_overlap=True, NG_MPI_thread=False, shm=True, sl2=False, bs2=True, pinv=False,
+                         blocks_no=False, symm=False, symm_loc=False, nsteps=1, nsteps_loc=1, device=0):
+    """stand-alone block Gauss-Seidel smoother over caller-given blocks (reference python_smoothers.cpp:197-275;
+    single GPU: the hybrid smoother degenerates to BSmoother on the local matrix).  blocks: iterable of row-index lists"""
+    from .hierarchy import bgs_data
+    A = _as_matrix(mat, 1)
+    hier = _SingleLevel(A, None, pinv)
+    rows = [np.sort(np.asarray(list(b), dtype=np.int32)) for b in blocks]
+    ptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int32)
+    hier.levels[0].bgs = bgs_data(A, ptr, np.concatenate(rows) if rows else np.empty(0, dtype=np.int32), pinv=pinv)
+    dev = DeviceAMGMatrix(hier, sm_type="bgs", sm_steps=nsteps, sm_symm=symm, clev="none", device=device)
+    return BaseSmoother(AMGMatrix(hier, dev), 0)
 
 
 class ProxySmoother(BaseSmoother):

@@ -81,6 +81,8 @@ def host():
     lib.amgh_destroy.restype = None
     lib.amgh_calc_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int, c_f64p]
     lib.amgh_coloring.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_i32p, c_i32p]
+    lib.amgh_bgs_dinv.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, C.c_int, c_i64p, c_f64p]
+    lib.amgh_bgs_coloring.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p]
     lib.amgh_transpose_count.argtypes = [C.POINTER(amgh_matrix), c_i64p]
     lib.amgh_transpose_fill.argtypes = [C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
     lib.amgh_matmul.argtypes = [C.POINTER(amgh_matrix), C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
@@ -183,7 +185,10 @@ class amgx_matrix(C.Structure):
 class amgx_level_desc(C.Structure):
     _fields_ = [("A", amgx_matrix), ("P", amgx_matrix), ("PT", amgx_matrix), ("dinv", c_f64p),
                 ("free_dofs", c_u8p), ("sm_type", C.c_int32), ("omega", C.c_double), ("sm_steps", C.c_int32),
-                ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32), ("Q", amgx_matrix)]
+                ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32),
+                ("bgs_n_blocks", C.c_int32), ("bgs_block_ptr", c_i32p), ("bgs_block_rows", c_i32p),
+                ("bgs_dinv_ptr", c_i64p), ("bgs_dinv", c_f64p), ("bgs_color", c_i32p), ("bgs_n_colors", C.c_int32),
+                ("Q", amgx_matrix)]
 
 
 class amgx_hierarchy_desc(C.Structure):
@@ -192,7 +197,7 @@ class amgx_hierarchy_desc(C.Structure):
                 ("use_graph", C.c_int32)]
 
 
-AMGX_SM_JACOBI, AMGX_SM_GS = 0, 1
+AMGX_SM_JACOBI, AMGX_SM_GS, AMGX_SM_BGS = 0, 1, 2
 AMGX_CYCLE = {"V": 0, "W": 1, "BS": 2}
 AMGX_CLEV_NONE, AMGX_CLEV_INV = 0, 1
 AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
@@ -209,7 +214,7 @@ AMGX_SYMBOLS = [
 AMGH_SYMBOLS = [
     "amgh_last_error", "amgh_default_options", "amgh_setup", "amgh_n_levels", "amgh_level_get",
     "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
-    "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble",
+    "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble", "amgh_bgs_dinv", "amgh_bgs_coloring",
 ]
 
 

@@ -110,6 +110,16 @@ struct DevGS {                          // colour-major data for multicolour Gau
   DevBuf<int32_t> rowlist;
 };
 
+struct DevBGS {                         // block Gauss-Seidel over aggregate blocks (bgs_block_kernel)
+  int n_colors = 0;
+  std::vector<int> color_ptr;           // [n_colors+1] ranges of the colour-major block list
+  DevBuf<int32_t> blocklist, block_ptr, block_rows;
+  DevBuf<int64_t> dinv_ptr;
+  DevBuf<double> dinv;
+  DevBuf<int32_t> rowptr, col;          // CSR of A (the level matrix itself may live in a SELL format)
+  DevBuf<double> val;
+};
+
 struct DevRestrict {                    // column-blocked P^T (see restrict_chunk_kernel)
   int n_chunks = 0;
   int64_t n_slots = 0;
@@ -143,6 +153,7 @@ struct DevLevel {
   DevMatrix Q;                          // scalar Jacobi levels of the V-cycle: (I - omega*Dinv*A) P, see fold_prolongation()
   DevBuf<double> dinv;
   DevGS gs;
+  DevBGS bgs;
   int sm_type = AMGX_SM_JACOBI;
   double omega = 0.9;
   int sm_steps = 1, sm_symm = 0;
@@ -438,6 +449,57 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   }
 }
 
+// block Gauss-Seidel data: validated (a wrong block colouring would be a data race), blocks listed colour-major
+static void build_bgs(const amgx_level_desc& d, DevLevel& L) {
+  const int64_t n = d.A.n_rows;
+  const int nb = d.bgs_n_blocks, nc = d.bgs_n_colors;
+  if (nb < 0 || (nb > 0 && (!d.bgs_block_ptr || !d.bgs_block_rows || !d.bgs_dinv_ptr || !d.bgs_dinv || !d.bgs_color || nc <= 0)))
+    throw Err("AMGX_SM_BGS needs blocks, their inverses and a block colouring (amgx_level_desc.bgs_*)");
+  DevBGS& g = L.bgs;
+  g.n_colors = nb ? nc : 0;
+  std::vector<int32_t> blockof(n, -1);
+  const int bs = d.A.br;
+  for (int k = 0; k < nb; ++k) {
+    const int64_t m = d.bgs_block_ptr[k + 1] - d.bgs_block_ptr[k];
+    if (m < 0 || m * bs > BGS_MAX_M) throw Err("block Gauss-Seidel: block with more than 1024 scalar dofs");
+    if ((m * bs) * (m * bs) != d.bgs_dinv_ptr[k + 1] - d.bgs_dinv_ptr[k]) throw Err("block Gauss-Seidel: bgs_dinv_ptr does not match the block sizes");
+    if (d.bgs_color[k] < 0 || d.bgs_color[k] >= nc) throw Err("block Gauss-Seidel: block colour out of range");
+    for (int q = d.bgs_block_ptr[k]; q < d.bgs_block_ptr[k + 1]; ++q) {
+      const int32_t i = d.bgs_block_rows[q];
+      if (i < 0 || i >= n || blockof[i] >= 0) throw Err("block Gauss-Seidel: blocks must be disjoint sets of valid rows");
+      blockof[i] = k;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const int k = blockof[i];
+    if (k < 0) continue;
+    for (int64_t e = d.A.rowptr[i]; e < d.A.rowptr[i + 1]; ++e) {
+      const int64_t j = d.A.col[e];
+      if (j >= n) continue;            // ghost column: frozen during the sweep
+      const int kj = blockof[j];
+      if (kj >= 0 && kj != k && d.bgs_color[kj] == d.bgs_color[k]) throw Err("invalid block colouring: two coupled blocks share a colour");
+    }
+  }
+  g.color_ptr.assign(nc + 1, 0);
+  for (int k = 0; k < nb; ++k) g.color_ptr[d.bgs_color[k] + 1]++;
+  for (int c = 0; c < nc; ++c) g.color_ptr[c + 1] += g.color_ptr[c];
+  std::vector<int32_t> list(nb);
+  std::vector<int> pos(g.color_ptr.begin(), g.color_ptr.end() - 1);
+  for (int k = 0; k < nb; ++k) list[pos[d.bgs_color[k]]++] = k;
+  g.blocklist.upload(list);
+  g.block_ptr.upload(d.bgs_block_ptr, (size_t)nb + 1);
+  g.block_rows.upload(d.bgs_block_rows, (size_t)d.bgs_block_ptr[nb]);
+  g.dinv_ptr.upload(d.bgs_dinv_ptr, (size_t)nb + 1);
+  g.dinv.upload(d.bgs_dinv, (size_t)d.bgs_dinv_ptr[nb]);
+  const int64_t nnz = d.A.rowptr[n];
+  if (nnz >= (int64_t)2147483647) throw Err("block Gauss-Seidel: too many entries for 32-bit offsets");
+  std::vector<int32_t> rp(n + 1);
+  for (int64_t i = 0; i <= n; ++i) rp[i] = (int32_t)d.A.rowptr[i];
+  g.rowptr.upload(rp);
+  g.col.upload(d.A.col, (size_t)nnz);
+  g.val.upload(d.A.val, (size_t)nnz * bs * bs);
+}
+
 static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES) {
   const int64_t nf = P.n_rows, nc = P.n_cols;
   const int64_t nch = (nf + CH - 1) / CH;
@@ -703,6 +765,27 @@ struct Handle {
     }
   }
 
+  // one block Gauss-Seidel sweep: colours of the block graph ascending (forward) or descending (backward)
+  void bgs_sweep(const DevLevel& L, int dir, double* x, const double* b) {
+    const DevBGS& g = L.bgs;
+    if (g.n_colors == 0 && L.n > 0 && g.block_ptr.n > 1) throw Err("block Gauss-Seidel requested but the level has no block colouring");
+    for (int q = 0; q < g.n_colors; ++q) {
+      const int c = dir == 0 ? q : g.n_colors - 1 - q;
+      const int b0 = g.color_ptr[c], b1 = g.color_ptr[c + 1];
+      if (b1 == b0) continue;
+#define LAUNCH_BGS(BS) hipLaunchKernelGGL((bgs_block_kernel<BS>), dim3(b1 - b0), dim3(BLOCK), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x)
+      switch (L.bs) {
+        case 1: LAUNCH_BGS(1); break;
+        case 2: LAUNCH_BGS(2); break;
+        case 3: LAUNCH_BGS(3); break;
+        case 6: LAUNCH_BGS(6); break;
+        default: throw Err("unsupported block size for block Gauss-Seidel");
+      }
+#undef LAUNCH_BGS
+      HIPCHK(hipGetLastError());
+    }
+  }
+
   void coarse_solve(const double* rhs, double* x) {
     const DevLevel& L = lev.back();
     if (clev != AMGX_CLEV_INV || coarse_n == 0) { zero(x, L.len()); return; }   // amg_matrix.cpp:242-246
@@ -731,6 +814,11 @@ struct Handle {
         if (!res_updated) residual(L.A, x, b, res);
         diag_apply(L, res, x, true);
       }
+      if (update_res) residual(L.A, x, b, res);
+    } else if (L.sm_type == AMGX_SM_BGS) {
+      // BSmoother::Smooth / SmoothBack (block_gssmoother.cpp:434-498): like GSS3 the reference updates the residual by
+      // row-transpose scatters when asked for it; here: gather (RHS) form + one residual SpMV, same x and res
+      bgs_sweep(L, dir, x, b);
       if (update_res) residual(L.A, x, b, res);
     } else {
       // GSS3::Smooth / SmoothBack (gssmoother.cpp:350-398).  The reference keeps the residual current with
@@ -1283,7 +1371,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     if (s.A.n_cols < s.A.n_rows || s.A.br != s.A.bc) throw Err("level matrix must have n_cols >= n_rows and square blocks");
     L.n = s.A.n_rows; L.ncols = s.A.n_cols; L.bs = s.A.br;
     L.sm_type = s.sm_type; L.omega = s.omega; L.sm_steps = s.sm_steps; L.sm_symm = s.sm_symm;
-    if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS) throw Err("unknown smoother type");
+    if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS && s.sm_type != AMGX_SM_BGS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
     // block GS walks the CSR arrays of A, so keep A in CSR there
     upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1);
@@ -1307,6 +1395,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       if (!s.dinv) throw Err("dinv missing");
       L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
+      if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
         // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
@@ -1372,6 +1461,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
+      if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
     const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);

@@ -875,6 +875,56 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Block Gauss-Seidel (reference BSmoother::Smooth_impl, block_gssmoother.cpp:287-328): one workgroup per block,
+// one launch per colour of the block graph.
+//   hr_j = b_j - A_j: x   for the rows j of the block        (G lanes per scalar row, reduced by shuffles)
+//   hu   = Dinv_B hr      (dense M x M, column-major: lane i reads column entries D[j*M + i] -> coalesced)
+//   x_B += hu
+// hr is complete (barrier) before any x_B is written, exactly like the reference's two loops.
+constexpr int BGS_MAX_M = 1024;      // scalar dofs per block (host side rejects bigger blocks)
+constexpr int BGS_G = 4;
+template <int BS>
+__global__ __launch_bounds__(BLOCK) void bgs_block_kernel(int list_begin, const int32_t* __restrict__ blocklist,
+                                                          const int32_t* __restrict__ block_ptr, const int32_t* __restrict__ block_rows,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                          const double* __restrict__ vals, const int64_t* __restrict__ dinv_ptr,
+                                                          const double* __restrict__ dinv, const double* __restrict__ b, double* x) {
+  __shared__ double hr[BGS_MAX_M];
+  const int k = blocklist[list_begin + blockIdx.x];
+  const int p0 = block_ptr[k];
+  const int M = (block_ptr[k + 1] - p0) * BS;
+  const int sub = threadIdx.x % BGS_G;
+  for (int t0 = 0; t0 < M; t0 += BLOCK / BGS_G) {          // trip count is workgroup-uniform: shuffles are safe
+    const int t = t0 + threadIdx.x / BGS_G;
+    double acc = 0.0;
+    int64_t row = 0;
+    int rr = 0;
+    if (t < M) {
+      row = block_rows[p0 + t / BS];
+      rr = t % BS;
+      const int e = rowptr[row + 1];
+      for (int p = rowptr[row] + sub; p < e; p += BGS_G) {
+        const double* __restrict__ a = vals + ((int64_t)p * BS + rr) * BS;
+        const double* xv = x + (int64_t)cols[p] * BS;
+#pragma unroll
+        for (int c = 0; c < BS; ++c) acc += a[c] * xv[c];
+      }
+    }
+#pragma unroll
+    for (int o = BGS_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, BGS_G);
+    if (t < M && sub == 0) hr[t] = b[row * BS + rr] - acc;
+  }
+  __syncthreads();
+  const double* __restrict__ D = dinv + dinv_ptr[k];
+  for (int i = threadIdx.x; i < M; i += BLOCK) {
+    double u = 0.0;
+    for (int j = 0; j < M; ++j) u += D[(int64_t)j * M + i] * hr[j];
+    const int64_t row = block_rows[p0 + i / BS];
+    x[row * BS + i % BS] += u;          // x_B is only read in the first phase, which is complete
+  }
+}
+
 // dst[i] = src[perm[i]] (gather) / dst[perm[i]] = src[i] (scatter) on block vectors with bs entries per block row:
 // translation between the caller's numbering and the colour-major numbering of Gauss-Seidel levels (amgx.hip, LevelPerm)
 __global__ __launch_bounds__(BLOCK) void perm_gather_kernel(int64_t len, int bs, const int32_t* __restrict__ perm,

@@ -138,6 +138,88 @@ int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* co
   });
 }
 
+int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows, int pinv,
+                  const int64_t* dinv_ptr, double* dinv_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->br != A->bc || A->n_rows != A->n_cols) throw amgh::Error("amgh_bgs_dinv: square matrix with square blocks expected");
+    if (n_blocks < 0 || !block_ptr || (!block_rows && block_ptr[n_blocks] > 0) || !dinv_ptr || !dinv_out) throw amgh::Error("amgh_bgs_dinv: bad arguments");
+    const int bs = A->br;
+    const int64_t n = A->n_rows;
+    for (int32_t q = 0; q < block_ptr[n_blocks]; q++) if (block_rows[q] < 0 || block_rows[q] >= n) throw amgh::Error("amgh_bgs_dinv: block row out of range");
+    int bad = 0;
+#pragma omp parallel
+    {
+      std::vector<int32_t> loc(n, -1);           // global row -> position inside the current block
+      std::vector<double> D;
+#pragma omp for schedule(dynamic, 64)
+      for (int32_t k = 0; k < n_blocks; k++) {
+        const int32_t p0 = block_ptr[k], m = block_ptr[k + 1] - p0;
+        const int M = m * bs;
+        if ((int64_t)M * M != dinv_ptr[k + 1] - dinv_ptr[k]) { bad = 1; continue; }
+        if (!m) continue;
+        for (int32_t q = 0; q < m; q++) loc[block_rows[p0 + q]] = q;
+        D.assign((size_t)M * M, 0.0);
+        for (int32_t q = 0; q < m; q++) {
+          const int64_t i = block_rows[p0 + q];
+          for (int64_t e = A->rowptr[i]; e < A->rowptr[i + 1]; e++) {
+            const int32_t lj = loc[A->col[e]];
+            if (lj < 0) continue;
+            for (int r = 0; r < bs; r++)
+              for (int c = 0; c < bs; c++) D[(size_t)(q * bs + r) * M + (lj * bs + c)] = A->val[(e * bs + r) * bs + c];
+          }
+        }
+        for (int32_t q = 0; q < m; q++) loc[block_rows[p0 + q]] = -1;
+        if (pinv) amgh::pseudo_inverse_try_normal(D.data(), M);
+        else if (!amgh::dense_inverse(D.data(), M)) bad = 2;
+        double* out = dinv_out + dinv_ptr[k];
+        for (int r = 0; r < M; r++)
+          for (int c = 0; c < M; c++) out[(size_t)c * M + r] = D[(size_t)r * M + c];      // column-major
+      }
+    }
+    if (bad == 1) throw amgh::Error("amgh_bgs_dinv: dinv_ptr does not match the block sizes");
+    if (bad == 2) throw amgh::Error("amgh_bgs_dinv: singular diagonal block (use pinv)");
+  });
+}
+
+int amgh_bgs_coloring(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows,
+                      int32_t* color_out, int32_t* n_colors) {
+  return guard([&] {
+    check_matrix(A);
+    if (n_blocks < 0 || !block_ptr || !color_out || !n_colors) throw amgh::Error("amgh_bgs_coloring: bad arguments");
+    const int64_t n = A->n_rows;
+    std::vector<int32_t> blockof(n, -1);
+    for (int32_t k = 0; k < n_blocks; k++)
+      for (int32_t q = block_ptr[k]; q < block_ptr[k + 1]; q++) {
+        if (block_rows[q] < 0 || block_rows[q] >= n || blockof[block_rows[q]] >= 0) throw amgh::Error("amgh_bgs_coloring: blocks must be disjoint sets of valid rows");
+        blockof[block_rows[q]] = k;
+      }
+    std::vector<int32_t> mark(64, -1);
+    int nc = 0;
+    for (int32_t k = 0; k < n_blocks; k++) {
+      color_out[k] = -1;
+      for (int32_t q = block_ptr[k]; q < block_ptr[k + 1]; q++) {
+        const int64_t i = block_rows[q];
+        for (int64_t e = A->rowptr[i]; e < A->rowptr[i + 1]; e++) {
+          const int64_t j = A->col[e];
+          if (j >= n) continue;
+          const int32_t kb = blockof[j];
+          if (kb < 0 || kb >= k) continue;          // only already-coloured (lower) blocks matter
+          const int32_t c = color_out[kb];
+          if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1);
+          mark[c] = k;
+        }
+      }
+      int c = 0;
+      while (c < (int)mark.size() && mark[c] == k) c++;
+      if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1);
+      color_out[k] = c;
+      nc = std::max(nc, c + 1);
+    }
+    *n_colors = nc;
+  });
+}
+
 int amgh_transpose_count(const amgh_matrix* A, int64_t* rowptr_out) {
   return guard([&] {
     check_matrix(A);

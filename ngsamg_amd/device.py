@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from ._lib import NgsAMGError
 
-_SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS}
+_SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS, "bgs": _lib.AMGX_SM_BGS}
 
 
 def _is_torch(v):
@@ -71,13 +71,22 @@ class DeviceAMGMatrix:
             d.dinv = _lib.ptr(lv.dinv, C.c_double)
             d.free_dofs = _lib.ptr(lv.free, C.c_uint8)
             if types[i] not in _SM:
-                raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs)")
+                raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs | bgs)")
             d.sm_type = _SM[types[i]]
             d.omega = float(omega)
             d.sm_steps = int(sm_steps)
             d.sm_symm = int(bool(sm_symm))
             d.color = _lib.ptr(lv.color, C.c_int32)
             d.n_colors = int(lv.n_colors)
+            g = getattr(lv, "bgs", None)
+            if types[i] == "bgs" and g is None and i + 1 < n:
+                raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")
+            if types[i] == "bgs" and g is not None:
+                self._keep.append(g)
+                d.bgs_n_blocks = int(g.n_blocks)
+                d.bgs_block_ptr, d.bgs_block_rows = _lib.ptr(g.block_ptr, C.c_int32), _lib.ptr(g.block_rows, C.c_int32)
+                d.bgs_dinv_ptr, d.bgs_dinv = _lib.ptr(g.dinv_ptr, C.c_int64), _lib.ptr(g.dinv, C.c_double)
+                d.bgs_color, d.bgs_n_colors = _lib.ptr(g.color, C.c_int32), int(g.n_colors)
             q = getattr(lv, "Q", None)        # caller-supplied folded prolongation (rank-partitioned levels, dist.py)
             if q is not None:
                 d.Q = q.desc(_lib.amgx_matrix)

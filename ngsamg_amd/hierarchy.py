@@ -27,6 +27,7 @@ class Level:
     n_colors: int
     agg: np.ndarray | None
     Q: Matrix | None = None     # rank-partitioned levels only: caller-built (I - w Dinv A) P (amgx_level_desc.Q)
+    bgs: "BGSData | None" = None  # block Gauss-Seidel data (Hierarchy.build_bgs)
 
     @property
     def n(self):
@@ -35,6 +36,53 @@ class Level:
     @property
     def bs(self):
         return self.A.br
+
+
+@dataclass
+class BGSData:
+    """block Gauss-Seidel data of one level (reference BSmoother, block_gssmoother.cpp:17-150)"""
+    n_blocks: int
+    block_ptr: np.ndarray      # int32 [n_blocks + 1]
+    block_rows: np.ndarray     # int32, block rows grouped by block, ascending inside a block
+    dinv_ptr: np.ndarray       # int64 [n_blocks + 1], offsets of the dense inverses
+    dinv: np.ndarray           # float64, M_k x M_k column-major per block, M_k = bs * |block k|
+    color: np.ndarray          # int32 [n_blocks]
+    n_colors: int
+
+
+def bgs_blocks_from_aggregates(agg, free=None):
+    """GetGSBlocks (amg_pc_vertex_impl.hpp:1171-1269): block cv = fine vertices k with vmap[k] == cv; vertices
+    without a coarse vertex (Dirichlet) are in no block"""
+    agg = np.asarray(agg, dtype=np.int64)
+    keep = agg >= 0
+    if free is not None:
+        keep &= np.asarray(free).astype(bool)
+    rows = np.nonzero(keep)[0]
+    order = np.argsort(agg[rows], kind="stable")
+    rows = rows[order]
+    nb = int(agg.max()) + 1 if agg.size and agg.max() >= 0 else 0
+    ptr = np.zeros(nb + 1, dtype=np.int64)
+    np.add.at(ptr, agg[rows] + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), rows.astype(np.int32)
+
+
+def bgs_data(A, block_ptr, block_rows, pinv=False):
+    """dense (pseudo-)inverses of the diagonal blocks + colouring of the block graph, through the host library"""
+    lib = _lib.host()
+    block_ptr = np.ascontiguousarray(block_ptr, dtype=np.int32)
+    block_rows = np.ascontiguousarray(block_rows, dtype=np.int32)
+    nb = block_ptr.size - 1
+    M = np.diff(block_ptr).astype(np.int64) * A.br
+    dinv_ptr = np.concatenate([[0], np.cumsum(M * M)]).astype(np.int64)
+    dinv = np.zeros(max(1, int(dinv_ptr[-1])), dtype=np.float64)
+    color = np.zeros(max(1, nb), dtype=np.int32)
+    nc = C.c_int32()
+    d = A.desc()
+    _lib.hcheck(lib.amgh_bgs_dinv(C.byref(d), nb, _lib.ptr(block_ptr, C.c_int32), _lib.ptr(block_rows, C.c_int32), int(bool(pinv)),
+                                  _lib.ptr(dinv_ptr, C.c_int64), _lib.ptr(dinv, C.c_double)))
+    _lib.hcheck(lib.amgh_bgs_coloring(C.byref(d), nb, _lib.ptr(block_ptr, C.c_int32), _lib.ptr(block_rows, C.c_int32),
+                                      _lib.ptr(color, C.c_int32), C.byref(nc)))
+    return BGSData(nb, block_ptr, block_rows, dinv_ptr, dinv, color[:nb], int(nc.value))
 
 
 # flag names follow the reference (prefix ngs_amg_, SURVEY.md section 5 "Config / flags")
@@ -104,6 +152,20 @@ class Hierarchy:
     @property
     def n_levels(self):
         return len(self.levels)
+
+    def build_bgs(self, pinv=None):
+        """attach block Gauss-Seidel data to every smoothed level: blocks = the level's aggregates (GetGSBlocks,
+        amg_pc_vertex_impl.hpp:1171-1269), (pseudo-)inverted diagonal blocks, colouring of the block graph.
+        pinv: pseudo-inverse like the reference's regularize_cmats (default: the hierarchy's option)"""
+        if pinv is None:
+            pinv = bool(self.options.regularize_cmats)
+        for lv in self.levels[:-1]:
+            if lv.bgs is None:
+                if lv.agg is None:
+                    raise NgsAMGError("block Gauss-Seidel needs the aggregates of the level")
+                bp, br = bgs_blocks_from_aggregates(lv.agg, lv.free)
+                lv.bgs = bgs_data(lv.A, bp, br, pinv=pinv)
+        return [lv.bgs for lv in self.levels]
 
     def operator_complexity(self):
         """sum_l nnz(A_l)*bs_l^2 / nnz(A_0)*bs_0^2  (reference Logger, base_factory.cpp:83-190)."""

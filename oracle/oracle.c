@@ -205,11 +205,82 @@ static void gs_smooth(const orc_level* L, int dir, double* x, const double* b, d
   }
 }
 
+/* ---------------------------------------------------------------- block Gauss-Seidel (block_gssmoother.cpp) */
+
+#define ORC_MAXBLOCK 4096
+/* one block, RHS form (:300-323): hr_j = b_j - A_j: x for the rows j of the block, hup = Dinv hr, x_B += hup */
+static void bgs_block_rhs(const orc_level* L, int32_t k, double* x, const double* b, double* hr, double* hup) {
+  const orc_matrix* A = &L->A;
+  const int bs = A->br;
+  const int32_t p0 = L->block_ptr[k], m = L->block_ptr[k + 1] - p0;
+  const int M = m * bs;
+  for (int32_t q = 0; q < m; q++) {
+    const int64_t j = L->block_rows[p0 + q];
+    double r[MAXBS] = {0, 0, 0, 0, 0, 0};
+    for (int64_t p = A->rowptr[j]; p < A->rowptr[j + 1]; p++) {
+      const double* a = A->val + p * bs * bs;
+      const double* xv = x + (int64_t)A->col[p] * bs;
+      for (int i = 0; i < bs; i++)
+        for (int c = 0; c < bs; c++) r[i] += a[i * bs + c] * xv[c];
+    }
+    for (int i = 0; i < bs; i++) hr[q * bs + i] = b[j * bs + i] - r[i];
+  }
+  const double* D = L->bdinv + L->bdinv_ptr[k];
+  for (int i = 0; i < M; i++) { double u = 0; for (int c = 0; c < M; c++) u += D[(int64_t)c * M + i] * hr[c]; hup[i] = u; }
+  for (int32_t q = 0; q < m; q++) { const int64_t j = L->block_rows[p0 + q]; for (int i = 0; i < bs; i++) x[j * bs + i] += hup[q * bs + i]; }
+}
+
+/* one block, RES form (:372-388): hr = res_B, hup = Dinv hr, res -= A_j:^T hup_j for the rows of the block, x_B += hup */
+static void bgs_block_res(const orc_level* L, int32_t k, double* x, double* res, double* hr, double* hup) {
+  const orc_matrix* A = &L->A;
+  const int bs = A->br;
+  const int32_t p0 = L->block_ptr[k], m = L->block_ptr[k + 1] - p0;
+  const int M = m * bs;
+  for (int32_t q = 0; q < m; q++) { const int64_t j = L->block_rows[p0 + q]; for (int i = 0; i < bs; i++) hr[q * bs + i] = res[j * bs + i]; }
+  const double* D = L->bdinv + L->bdinv_ptr[k];
+  for (int i = 0; i < M; i++) { double u = 0; for (int c = 0; c < M; c++) u += D[(int64_t)c * M + i] * hr[c]; hup[i] = u; }
+  for (int32_t q = 0; q < m; q++) {
+    const int64_t j = L->block_rows[p0 + q];
+    const double* w = hup + q * bs;
+    for (int64_t p = A->rowptr[j]; p < A->rowptr[j + 1]; p++) {
+      const double* a = A->val + p * bs * bs;
+      double* rc = res + (int64_t)A->col[p] * bs;
+      for (int c = 0; c < bs; c++) { double u = 0; for (int i = 0; i < bs; i++) u += a[i * bs + c] * w[i]; rc[c] -= u; }   /* Trans(A_jc) * hup_j */
+    }
+    for (int i = 0; i < bs; i++) x[j * bs + i] += w[i];
+  }
+}
+
+static int bgs_sweep(const orc_level* L, double* x, const double* b, double* res, int res_form, int backwards) {
+  double hr[ORC_MAXBLOCK], hup[ORC_MAXBLOCK];
+  const int32_t nb = L->n_blocks;
+  for (int32_t q = 0; q < nb; q++) {
+    const int32_t pos = backwards ? nb - 1 - q : q;
+    const int32_t k = L->block_order ? L->block_order[pos] : pos;
+    if ((L->block_ptr[k + 1] - L->block_ptr[k]) * L->A.br > ORC_MAXBLOCK) return 1;
+    if (res_form) bgs_block_res(L, k, x, res, hr, hup); else bgs_block_rhs(L, k, x, b, hr, hup);
+  }
+  return 0;
+}
+
+static void bgs_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
+                       int res_updated, int update_res, int x_zero) {
+  /* BSmoother::Smooth / SmoothBack, block_gssmoother.cpp:434-498 */
+  if (update_res) {
+    if (!res_updated) {          /* CalcResiduum(x, b, res, x_zero), base_smoother.hpp:132-142 */
+      if (x_zero) memcpy(res, b, sizeof(double) * vlen(L));
+      else spmv(&L->A, x, res, 1, 0.0, b);
+    }
+    bgs_sweep(L, x, b, res, 1, dir);
+  } else bgs_sweep(L, x, b, res, 0, dir);      /* "if res_updated, just forget about the residual vector" */
+}
+
 /* ---------------------------------------------------------------- smoother dispatch + ProxySmoother */
 
 static void base_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
                         int res_updated, int update_res, int x_zero) {
   if (L->sm_type == ORC_SM_JACOBI) jacobi_smooth(L, x, b, res, res_updated, update_res, x_zero);
+  else if (L->sm_type == ORC_SM_BGS) bgs_smooth(L, dir, x, b, res, res_updated, update_res, x_zero);
   else gs_smooth(L, dir, x, b, res, res_updated, update_res, x_zero);
 }
 

@@ -16,6 +16,8 @@
  *   Jacobi           src/base/smoothers/base_smoother.cpp:61-114
  *   Gauss-Seidel     src/base/smoothers/gssmoother.cpp:111-139 (free range), 196-257 (RHS), 261-315 (RES),
  *                    350-398 (Smooth / SmoothBack)
+ *   block GS         src/base/smoothers/block_gssmoother.cpp:216-283 (block order), 287-328 (RHS form), 356-392 (RES
+ *                    form), 434-498 (Smooth / SmoothBack flag logic)
  *   transfers        src/base/coarsening/dof_map.cpp:636-709
  *   coarse solve     src/base/precond/amg_pc.cpp:843-928 (exact inverse on the free dofs)
  */
@@ -35,7 +37,7 @@ typedef struct orc_matrix {
   const double* val;
 } orc_matrix;
 
-enum { ORC_SM_JACOBI = 0, ORC_SM_GS = 1 };
+enum { ORC_SM_JACOBI = 0, ORC_SM_GS = 1, ORC_SM_BGS = 2 };
 enum { ORC_CYCLE_V = 0, ORC_CYCLE_W = 1, ORC_CYCLE_BS = 2 };
 
 typedef struct orc_level {
@@ -53,6 +55,15 @@ typedef struct orc_level {
                               /*   HybridGSSmoother: local GS on M, G x_old moved to the right-hand side,           */
                               /*   hybrid_base_smoother.cpp:296-495, gssmoother.cpp:709-861); dinv then holds the   */
                               /*   inverse of the modified diagonal (hybrid_smoother_utils.hpp:111-142)             */
+  /* ORC_SM_BGS: block Gauss-Seidel (reference BSmoother, block_gssmoother.cpp:216-470): blocks of block rows with    */
+  /*   dense inverses of the diagonal blocks; natural block order forward, reversed backward (:266-283)               */
+  int32_t n_blocks;
+  const int32_t* block_ptr;   /* [n_blocks+1]                                                                      */
+  const int32_t* block_rows;  /* block rows grouped by block                                                        */
+  const int64_t* bdinv_ptr;   /* [n_blocks+1] offsets into bdinv                                                    */
+  const double* bdinv;        /* per block M x M column-major, M = bs * block size                                  */
+  const int32_t* block_order; /* NULL = natural (reference, sequential); else forward visiting order of the blocks  */
+                              /*   (colour-major = what the GPU kernel does)                                        */
 } orc_level;
 
 typedef struct orc_desc {

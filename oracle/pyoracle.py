@@ -18,7 +18,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_f64p = C.POINTER(C.c_double)
 c_u8p = C.POINTER(C.c_uint8)
 
-SM_JACOBI, SM_GS = 0, 1
+SM_JACOBI, SM_GS, SM_BGS = 0, 1, 2
 CYCLE_V, CYCLE_W, CYCLE_BS = 0, 1, 2
 
 
@@ -30,7 +30,9 @@ class orc_matrix(C.Structure):
 class orc_level(C.Structure):
     _fields_ = [("A", orc_matrix), ("P", orc_matrix), ("PT", orc_matrix), ("free", c_u8p), ("dinv", c_f64p),
                 ("sm_type", C.c_int32), ("omega", C.c_double), ("sm_steps", C.c_int32), ("sm_symm", C.c_int32),
-                ("gs_order", c_i32p), ("gs_order_len", C.c_int64), ("gs_block", c_i32p)]
+                ("gs_order", c_i32p), ("gs_order_len", C.c_int64), ("gs_block", c_i32p),
+                ("n_blocks", C.c_int32), ("block_ptr", c_i32p), ("block_rows", c_i32p), ("bdinv_ptr", c_i64p),
+                ("bdinv", c_f64p), ("block_order", c_i32p)]
 
 
 class orc_desc(C.Structure):
@@ -98,11 +100,13 @@ class Oracle:
     levels: sequence of objects with attributes A, P, PT (matrices with n_rows,n_cols,br,bc,rowptr,col,val),
             free, dinv, color (as ngsamg_amd.hierarchy.Level provides).
     sm_type: 'jacobi' | 'gs' (sequential natural order = reference GSS3) | 'gs_mc' (sequential in the
-            colour-major order = same arithmetic as the GPU multicolour kernel)
+            colour-major order = same arithmetic as the GPU multicolour kernel) | 'bgs' (block Gauss-Seidel in natural
+            block order = reference BSmoother) | 'bgs_mc' (blocks visited colour by colour, like the GPU);
+            the block smoothers need bgs = [BGSData or None per level] (ngsamg_amd.hierarchy.bgs_data)
     """
 
     def __init__(self, levels, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False, cycle="V", clev="inv",
-                 threads=1):
+                 threads=1, bgs=None):
         L = lib()
         self._keep = []
         n = len(levels)
@@ -116,7 +120,26 @@ class Oracle:
             self._keep += [free, dinv, lv]
             o.free, o.dinv = _p(free, C.c_uint8), _p(dinv, C.c_double)
             t = types[i]
-            o.sm_type = SM_JACOBI if t == "jacobi" else SM_GS
+            o.sm_type = SM_JACOBI if t == "jacobi" else (SM_BGS if t in ("bgs", "bgs_mc") else SM_GS)
+            if t in ("bgs", "bgs_mc"):
+                g = bgs[i] if bgs is not None else None
+                if g is None:
+                    if i + 1 < n:
+                        raise ValueError("block Gauss-Seidel level without BGSData")
+                    o.sm_type = SM_JACOBI          # coarsest level: no smoother is ever called there
+                else:
+                    bp = np.ascontiguousarray(g.block_ptr, dtype=np.int32)
+                    br = np.ascontiguousarray(g.block_rows, dtype=np.int32)
+                    dp = np.ascontiguousarray(g.dinv_ptr, dtype=np.int64)
+                    dv = np.ascontiguousarray(g.dinv, dtype=np.float64)
+                    self._keep += [bp, br, dp, dv]
+                    o.n_blocks = int(g.n_blocks)
+                    o.block_ptr, o.block_rows = _p(bp, C.c_int32), _p(br, C.c_int32)
+                    o.bdinv_ptr, o.bdinv = _p(dp, C.c_int64), _p(dv, C.c_double)
+                    if t == "bgs_mc":
+                        order = np.ascontiguousarray(np.argsort(np.asarray(g.color), kind="stable").astype(np.int32))
+                        self._keep.append(order)
+                        o.block_order = _p(order, C.c_int32)
             o.omega = omega
             o.sm_steps = int(sm_steps)
             o.sm_symm = int(bool(sm_symm))

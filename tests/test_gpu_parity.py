@@ -410,3 +410,96 @@ def test_size_independent_properties_at_large_size(sm):
     assert pd > 0
     ref = Oracle(H.levels, sm_type="jacobi" if sm == "jacobi" else "gs_mc", threads=8).apply(u.cpu().numpy())
     assert _rel(Cu.cpu().numpy(), ref) < (1e-12 if sm == "jacobi" else 1e-10)
+
+
+# ---- block Gauss-Seidel over aggregate blocks (reference BSmoother; amgx.h AMGX_SM_BGS) --------------------------------
+
+@pytest.mark.parametrize("kind", ["poisson", "elast3", "elast6"])
+def test_block_gs_cycles_and_stages_match_oracle(kind):
+    """GPU: blocks of one colour relaxed in parallel, colours in order == the oracle's sequential sweep over the same
+    colour-major block order ('bgs_mc'); stage flags as BSmoother::Smooth (block_gssmoother.cpp:434-498)"""
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    if kind == "poisson":
+        p, H = poisson_case((14, 13, 12), "right|top", 20)
+    else:
+        p, H = elasticity_case((9, 8, 7), kind == "elast6", 5, 0.12)
+    bgs = H.build_bgs()
+    b = rhs(p, 6)
+    for cyc in ("V", "W", "BS"):
+        dev = _dev(H, sm_type="bgs", mg_cycle=cyc)
+        x = np.full(b.size, np.nan)
+        dev.Mult(b, x)
+        assert _rel(x, Oracle(H.levels, sm_type="bgs_mc", bgs=bgs, cycle=cyc).apply(b)) < 1e-10
+    dev = _dev(H, sm_type="bgs")
+    orc = Oracle(H.levels, sm_type="bgs_mc", bgs=bgs)
+    rng = np.random.default_rng(4)
+    for l in range(H.n_levels - 1):
+        n = dev.sizes[l]
+        bb = rng.standard_normal(n)
+        for back in (False, True):
+            for ru, ur, xz in ((False, True, False), (False, False, False), (False, True, True), (True, True, False)):
+                x0 = np.zeros(n) if xz else rng.standard_normal(n)
+                r0 = bb - orc.matvec(l, x0) if ru else np.zeros(n)
+                xo, ro = x0.copy(), r0.copy()
+                orc.smooth(l, xo, bb, ro, ru, ur, xz, back)
+                xg, rg = x0.copy(), r0.copy()
+                dev.Smooth(l, xg, bb, rg, ru, ur, xz, back=back)
+                assert _rel(xg, xo) < 1e-10
+                if ur:
+                    assert _rel(rg, ro) < 1e-9
+    # symmetric k-step wrapper (ProxySmoother) around the block smoother
+    d2 = _dev(H, sm_type="bgs", sm_steps=2, sm_symm=True)
+    y = np.empty(b.size)
+    d2.Mult(b, y)
+    assert _rel(y, Oracle(H.levels, sm_type="bgs_mc", bgs=bgs, sm_steps=2, sm_symm=True).apply(b)) < 1e-10
+
+
+def test_block_gs_pcg_iterations_and_registry():
+    """ngs_amg_sm_type='bgs' through the Preconditioner surface; iteration count of the colour-ordered GPU smoother within
+    +15 % of the reference-order (sequential, natural block order) oracle"""
+    import torch
+    from oracle.pyoracle import Oracle
+    from ngsamg_amd import ngs_amg, Matrix
+    from ngsamg_amd.krylov import CGSolver
+    from tests.problems import elasticity_case
+    p, H = elasticity_case((16, 6, 6), False, 5, 0.12)
+    bgs = H.build_bgs()
+    _, it_ref, _ = Oracle(H.levels, sm_type="bgs", bgs=bgs).pcg(p.load, tol=1e-6, maxit=100)
+    dev = _dev(H, sm_type="bgs")
+    cg = CGSolver(dev, dev, tol=1e-6, maxsteps=100)
+    cg.Solve(torch.from_numpy(p.load).cuda())
+    assert cg.iterations <= int(np.ceil(1.15 * it_ref)) + 1 and cg.errors[-1] < 1e-5 * cg.errors[0]
+    a = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    pre = ngs_amg.elast_3d(a, p.free, coords=p.coords, ngs_amg_sm_type="bgs", ngs_amg_max_coarse_size=5, ngs_amg_first_aaf=0.12)
+    amg = pre.GetAMGMatrix()
+    assert all(amg._dev.hierarchy.levels[l].bgs is not None for l in range(amg.GetNLevels() - 1))
+    x = np.zeros(p.n * p.bs)
+    amg._dev.Mult(p.load, x)
+    assert np.isfinite(x).all() and np.linalg.norm(x) > 0
+
+
+def test_standalone_block_smoother():
+    """CreateHybridBlockGSS (python_smoothers.cpp:197-275) with caller-given blocks on one matrix"""
+    from oracle.pyoracle import Oracle
+    from ngsamg_amd import NgsAMG
+    from ngsamg_amd.hierarchy import bgs_data
+    p, H = poisson_case((10, 9, 8), "right|top", 20)
+    A = H.levels[0].A
+    free = np.nonzero(p.free)[0]
+    blocks = [free[i:i + 7] for i in range(0, free.size, 7)]             # arbitrary blocks of 7 consecutive free rows
+    sm = NgsAMG.CreateHybridBlockGSS(A, blocks)
+    ptr = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int32)
+    g = bgs_data(A, ptr, np.concatenate(blocks).astype(np.int32))
+
+    class L0:
+        pass
+    lv = H.levels[0]
+    orc = Oracle([lv], sm_type="bgs_mc", bgs=[g], clev="none")
+    rng = np.random.default_rng(1)
+    b, x0 = rng.standard_normal(p.n), rng.standard_normal(p.n)
+    xo, ro = x0.copy(), np.zeros(p.n)
+    orc.smooth(0, xo, b, ro, False, True, False)
+    xg, rg = x0.copy(), np.zeros(p.n)
+    sm.Smooth(xg, b, rg, False, True, False)
+    assert _rel(xg, xo) < 1e-10 and _rel(rg, ro) < 1e-9

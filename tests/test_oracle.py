@@ -85,3 +85,86 @@ def test_iteration_budgets_as_sanity_bounds():
     p, H = elasticity_case((9, 9, 9), False, 10)
     _, it, errs = Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-6, maxit=100)
     assert it < 60 and errs[-1] < 1e-6 * errs[0]
+
+
+# ---- block Gauss-Seidel (reference BSmoother, block_gssmoother.cpp) ---------------------------------------------------
+
+def _bgs_case(kind):
+    if kind == "poisson":
+        p, H = poisson_case((12, 12, 12), "right|top", 20)
+    elif kind == "elast3":
+        p, H = elasticity_case((9, 8, 7), False, 5, 0.12)
+    else:
+        p, H = elasticity_case((8, 7, 6), True, 5, 0.12)
+    return p, H, H.build_bgs()
+
+
+@pytest.mark.parametrize("kind", ["poisson", "elast3", "elast6"])
+def test_bgs_blocks_inverses_and_colouring(kind):
+    """host data of the block smoother: blocks = aggregates (disjoint, cover the free rows), Dinv_B A_BB = I (or the
+    Moore-Penrose identities with pinv), coupled blocks never share a colour"""
+    p, H, bgs = _bgs_case(kind)
+    for lv, g in zip(H.levels[:-1], bgs[:-1]):
+        A = lv.A.to_scipy().toarray() if lv.n * lv.bs <= 3000 else None
+        rows = np.sort(g.block_rows)
+        assert np.array_equal(rows, np.nonzero(lv.free & (lv.agg >= 0))[0])
+        blockof = -np.ones(lv.n, dtype=int)
+        for k in range(g.n_blocks):
+            r = g.block_rows[g.block_ptr[k]:g.block_ptr[k + 1]]
+            assert np.all(np.diff(r) > 0) and np.all(lv.agg[r] == lv.agg[r[0]])
+            blockof[r] = k
+            if A is not None:
+                idx = (r[:, None] * lv.bs + np.arange(lv.bs)[None, :]).ravel()
+                M = idx.size
+                D = g.dinv[g.dinv_ptr[k]:g.dinv_ptr[k + 1]].reshape(M, M).T          # column-major
+                AB = A[np.ix_(idx, idx)]
+                assert np.abs(AB @ D @ AB - AB).max() <= 1e-9 * np.abs(AB).max()
+        rr = np.repeat(np.arange(lv.A.n_rows), np.diff(lv.A.rowptr))        # block-row index of every stored block
+        bi, bj = blockof[rr], blockof[lv.A.col]
+        m = (bi >= 0) & (bj >= 0) & (bi != bj)
+        assert not np.any(g.color[bi[m]] == g.color[bj[m]])
+        assert g.color.max() + 1 == g.n_colors
+
+
+@pytest.mark.parametrize("kind", ["poisson", "elast3"])
+def test_bgs_res_form_equals_rhs_form_and_flags(kind):
+    """BSmoother::Smooth (block_gssmoother.cpp:434-498): update_res -> RES form (row-transpose scatter), else RHS form;
+    for symmetric A both give the same x and the RES form keeps res = b - A x"""
+    p, H, bgs = _bgs_case(kind)
+    n = p.n * H.levels[0].bs
+    A = H.levels[0].A.to_scipy()
+    rng = np.random.default_rng(3)
+    b = rhs(p, 2)
+    for sm in ("bgs", "bgs_mc"):
+        orc = Oracle(H.levels, sm_type=sm, bgs=bgs)
+        for back in (False, True):
+            x0 = rng.standard_normal(n)
+            xa, ra = orc.smooth(0, x0.copy(), b, np.zeros(n), False, True, False, back)
+            xb, _ = orc.smooth(0, x0.copy(), b, np.zeros(n), False, False, False, back)
+            r0 = b - A @ x0
+            xc, rc = orc.smooth(0, x0.copy(), b, r0.copy(), True, True, False, back)
+            assert np.linalg.norm(xa - xb) <= 1e-13 * np.linalg.norm(xb)
+            assert np.linalg.norm(xc - xb) <= 1e-13 * np.linalg.norm(xb)
+            assert np.linalg.norm(ra - (b - A @ xa)) <= 1e-12 * np.linalg.norm(b)
+            assert np.linalg.norm(rc - ra) <= 1e-12 * np.linalg.norm(b)
+        z, rz = orc.smooth(0, np.zeros(n), b, np.zeros(n), False, True, True)       # x_zero: res starts as b
+        assert np.linalg.norm(rz - (b - A @ z)) <= 1e-12 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("kind", ["poisson", "elast3", "elast6"])
+def test_bgs_cycle_is_symmetric_and_beats_point_gs(kind):
+    """forward pre- / backward post-smoothing over the same block order => symmetric preconditioner (amg_pc.cpp:162-173);
+    PCG needs no more iterations than with point Gauss-Seidel (why the reference recommends it for elasticity)"""
+    p, H, bgs = _bgs_case(kind)
+    n = p.n * H.levels[0].bs
+    rng = np.random.default_rng(0)
+    free = np.repeat(p.free, H.levels[0].bs)
+    u, v = rng.standard_normal(n) * free, rng.standard_normal(n) * free
+    for sm in ("bgs", "bgs_mc"):
+        orc = Oracle(H.levels, sm_type=sm, bgs=bgs)
+        a, b_ = float(orc.apply(u) @ v), float(u @ orc.apply(v))
+        assert abs(a - b_) <= 1e-11 * max(abs(a), abs(b_))
+    b = rhs(p, 1)
+    _, it_b, e_b = Oracle(H.levels, sm_type="bgs", bgs=bgs).pcg(b, tol=1e-8, maxit=100)
+    _, it_g, _ = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=100)
+    assert e_b[-1] <= 1e-8 * e_b[0] and it_b <= it_g + 1
