@@ -112,6 +112,7 @@ struct DevGS {                          // colour-major data for multicolour Gau
 
 struct DevBGS {                         // block Gauss-Seidel over aggregate blocks (bgs_block_kernel)
   int n_colors = 0;
+  int max_m = 0;                        // largest block (scalar dofs)
   std::vector<int> color_ptr;           // [n_colors+1] ranges of the colour-major block list
   DevBuf<int32_t> blocklist, block_ptr, block_rows;
   DevBuf<int64_t> dinv_ptr;
@@ -462,6 +463,7 @@ static void build_bgs(const amgx_level_desc& d, DevLevel& L) {
   for (int k = 0; k < nb; ++k) {
     const int64_t m = d.bgs_block_ptr[k + 1] - d.bgs_block_ptr[k];
     if (m < 0 || m * bs > BGS_MAX_M) throw Err("block Gauss-Seidel: block with more than 1024 scalar dofs");
+    g.max_m = std::max(g.max_m, (int)(m * bs));
     if ((m * bs) * (m * bs) != d.bgs_dinv_ptr[k + 1] - d.bgs_dinv_ptr[k]) throw Err("block Gauss-Seidel: bgs_dinv_ptr does not match the block sizes");
     if (d.bgs_color[k] < 0 || d.bgs_color[k] >= nc) throw Err("block Gauss-Seidel: block colour out of range");
     for (int q = d.bgs_block_ptr[k]; q < d.bgs_block_ptr[k + 1]; ++q) {
@@ -773,7 +775,8 @@ struct Handle {
       const int c = dir == 0 ? q : g.n_colors - 1 - q;
       const int b0 = g.color_ptr[c], b1 = g.color_ptr[c + 1];
       if (b1 == b0) continue;
-#define LAUNCH_BGS(BS) hipLaunchKernelGGL((bgs_block_kernel<BS>), dim3(b1 - b0), dim3(BLOCK), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x)
+#define LAUNCH_BGS(BS) { if (g.max_m <= 96) hipLaunchKernelGGL((bgs_block_kernel<BS, 64>), dim3(b1 - b0), dim3(64), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x); \
+                         else hipLaunchKernelGGL((bgs_block_kernel<BS, 256>), dim3(b1 - b0), dim3(256), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x); }
       switch (L.bs) {
         case 1: LAUNCH_BGS(1); break;
         case 2: LAUNCH_BGS(2); break;

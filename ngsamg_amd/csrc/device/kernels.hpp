@@ -884,8 +884,9 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
 // hr is complete (barrier) before any x_B is written, exactly like the reference's two loops.
 constexpr int BGS_MAX_M = 1024;      // scalar dofs per block (host side rejects bigger blocks)
 constexpr int BGS_G = 4;
-template <int BS>
-__global__ __launch_bounds__(BLOCK) void bgs_block_kernel(int list_begin, const int32_t* __restrict__ blocklist,
+// TH = workgroup size: 64 (one wave) for the usual aggregate blocks of <= ~100 scalar dofs, 256 for big blocks
+template <int BS, int TH>
+__global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int32_t* __restrict__ blocklist,
                                                           const int32_t* __restrict__ block_ptr, const int32_t* __restrict__ block_rows,
                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                           const double* __restrict__ vals, const int64_t* __restrict__ dinv_ptr,
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) void bgs_block_kernel(int list_begin, const 
   const int p0 = block_ptr[k];
   const int M = (block_ptr[k + 1] - p0) * BS;
   const int sub = threadIdx.x % BGS_G;
-  for (int t0 = 0; t0 < M; t0 += BLOCK / BGS_G) {          // trip count is workgroup-uniform: shuffles are safe
+  for (int t0 = 0; t0 < M; t0 += TH / BGS_G) {             // trip count is workgroup-uniform: shuffles are safe
     const int t = t0 + threadIdx.x / BGS_G;
     double acc = 0.0;
     int64_t row = 0;
@@ -917,8 +918,9 @@ __global__ __launch_bounds__(BLOCK) void bgs_block_kernel(int list_begin, const 
   }
   __syncthreads();
   const double* __restrict__ D = dinv + dinv_ptr[k];
-  for (int i = threadIdx.x; i < M; i += BLOCK) {
+  for (int i = threadIdx.x; i < M; i += TH) {
     double u = 0.0;
+#pragma unroll 4
     for (int j = 0; j < M; ++j) u += D[(int64_t)j * M + i] * hr[j];
     const int64_t row = block_rows[p0 + i / BS];
     x[row * BS + i % BS] += u;          // x_B is only read in the first phase, which is complete

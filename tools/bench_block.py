@@ -25,6 +25,8 @@ def main():
     A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
     t1 = time.time()
     H = Hierarchy(A, p.free, p.coords, dim=3, energy=1, max_coarse_size=50, regularize_cmats=0 if rot else 1)
+    if sm == "bgs":
+        H.build_bgs()
     t2 = time.time()
     amg = DeviceAMGMatrix(H, sm_type=sm, device=0)
     t3 = time.time()
