@@ -775,8 +775,13 @@ struct Handle {
       const int c = dir == 0 ? q : g.n_colors - 1 - q;
       const int b0 = g.color_ptr[c], b1 = g.color_ptr[c + 1];
       if (b1 == b0) continue;
-#define LAUNCH_BGS(BS) { if (g.max_m <= 96) hipLaunchKernelGGL((bgs_block_kernel<BS, 64>), dim3(b1 - b0), dim3(64), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x); \
-                         else hipLaunchKernelGGL((bgs_block_kernel<BS, 256>), dim3(b1 - b0), dim3(256), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x); }
+      // (TH, G): one pass over the block's rows where possible (M * G <= TH), G lanes per row ~ row length / 6
+      const double avg = L.A.n_rows ? (double)L.A.nnz / (double)L.A.n_rows : 0.0;
+      const int G = avg > 30.0 ? (g.max_m * 16 <= 1024 ? 16 : 8) : 4;
+      const int TH = g.max_m * G <= 256 ? 256 : (g.max_m * G <= 512 ? 512 : 1024);
+#define LAUNCH_BGS2(BS, TT, GG) hipLaunchKernelGGL((bgs_block_kernel<BS, TT, GG>), dim3(b1 - b0), dim3(TT), 0, stream, b0, g.blocklist.p, g.block_ptr.p, g.block_rows.p, g.rowptr.p, g.col.p, g.val.p, g.dinv_ptr.p, g.dinv.p, b, x)
+#define LAUNCH_BGS(BS) { if (G == 4 && TH == 256) LAUNCH_BGS2(BS, 256, 4); else if (G == 4 && TH == 512) LAUNCH_BGS2(BS, 512, 4); else if (G == 4) LAUNCH_BGS2(BS, 1024, 4); \
+                         else if (G == 8 && TH <= 512) LAUNCH_BGS2(BS, 512, 8); else if (G == 8) LAUNCH_BGS2(BS, 1024, 8); else LAUNCH_BGS2(BS, 1024, 16); }
       switch (L.bs) {
         case 1: LAUNCH_BGS(1); break;
         case 2: LAUNCH_BGS(2); break;
@@ -784,6 +789,7 @@ struct Handle {
         case 6: LAUNCH_BGS(6); break;
         default: throw Err("unsupported block size for block Gauss-Seidel");
       }
+#undef LAUNCH_BGS2
 #undef LAUNCH_BGS
       HIPCHK(hipGetLastError());
     }

@@ -883,21 +883,25 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
 //   x_B += hu
 // hr is complete (barrier) before any x_B is written, exactly like the reference's two loops.
 constexpr int BGS_MAX_M = 1024;      // scalar dofs per block (host side rejects bigger blocks)
-constexpr int BGS_G = 4;
-// TH = workgroup size: 64 (one wave) for the usual aggregate blocks of <= ~100 scalar dofs, 256 for big blocks
-template <int BS, int TH>
+// Both phases are latency-bound (a block has only ~50-120 scalar dofs): phase 2 is therefore split over all TH threads,
+// S = TH / M slices of the j-range per output row, partial sums combined through LDS (a single thread per row walking
+// all M columns cost ~30 dependent round trips per block).
+// G = lanes per scalar row in phase 1; the host picks (TH, G) so that M * G <= TH where possible (one pass): the coarse
+// levels have few, big blocks with long rows (6x6: M ~ 120, 45-60 blocks per row) and are pure latency otherwise.
+template <int BS, int TH, int G>
 __global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int32_t* __restrict__ blocklist,
-                                                          const int32_t* __restrict__ block_ptr, const int32_t* __restrict__ block_rows,
-                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                          const double* __restrict__ vals, const int64_t* __restrict__ dinv_ptr,
-                                                          const double* __restrict__ dinv, const double* __restrict__ b, double* x) {
+                                                       const int32_t* __restrict__ block_ptr, const int32_t* __restrict__ block_rows,
+                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                       const double* __restrict__ vals, const int64_t* __restrict__ dinv_ptr,
+                                                       const double* __restrict__ dinv, const double* __restrict__ b, double* x) {
   __shared__ double hr[BGS_MAX_M];
+  __shared__ double part[TH];
   const int k = blocklist[list_begin + blockIdx.x];
   const int p0 = block_ptr[k];
   const int M = (block_ptr[k + 1] - p0) * BS;
-  const int sub = threadIdx.x % BGS_G;
-  for (int t0 = 0; t0 < M; t0 += TH / BGS_G) {             // trip count is workgroup-uniform: shuffles are safe
-    const int t = t0 + threadIdx.x / BGS_G;
+  const int sub = threadIdx.x % G;
+  for (int t0 = 0; t0 < M; t0 += TH / G) {             // trip count is workgroup-uniform: shuffles are safe
+    const int t = t0 + threadIdx.x / G;
     double acc = 0.0;
     int64_t row = 0;
     int rr = 0;
@@ -905,7 +909,8 @@ __global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int
       row = block_rows[p0 + t / BS];
       rr = t % BS;
       const int e = rowptr[row + 1];
-      for (int p = rowptr[row] + sub; p < e; p += BGS_G) {
+#pragma unroll 4
+      for (int p = rowptr[row] + sub; p < e; p += G) {
         const double* __restrict__ a = vals + ((int64_t)p * BS + rr) * BS;
         const double* xv = x + (int64_t)cols[p] * BS;
 #pragma unroll
@@ -913,17 +918,35 @@ __global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int
       }
     }
 #pragma unroll
-    for (int o = BGS_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, BGS_G);
+    for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
     if (t < M && sub == 0) hr[t] = b[row * BS + rr] - acc;
   }
   __syncthreads();
   const double* __restrict__ D = dinv + dinv_ptr[k];
-  for (int i = threadIdx.x; i < M; i += TH) {
+  if (M <= TH) {
+    const int S = TH / M;                                   // slices of the column range
+    const int i = threadIdx.x % M, sl = threadIdx.x / M;
     double u = 0.0;
-#pragma unroll 4
-    for (int j = 0; j < M; ++j) u += D[(int64_t)j * M + i] * hr[j];
-    const int64_t row = block_rows[p0 + i / BS];
-    x[row * BS + i % BS] += u;          // x_B is only read in the first phase, which is complete
+    if (sl < S) {
+#pragma unroll 8
+      for (int j = sl; j < M; j += S) u += D[(int64_t)j * M + i] * hr[j];
+    }
+    part[threadIdx.x] = u;
+    __syncthreads();
+    if (threadIdx.x < M) {
+      double tot = 0.0;
+      for (int q = 0; q < S; ++q) tot += part[q * M + threadIdx.x];      // fixed order: deterministic
+      const int64_t row = block_rows[p0 + threadIdx.x / BS];
+      x[row * BS + threadIdx.x % BS] += tot;                // x_B is only read in the first phase, which is complete
+    }
+  } else {
+    for (int i = threadIdx.x; i < M; i += TH) {
+      double u = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < M; ++j) u += D[(int64_t)j * M + i] * hr[j];
+      const int64_t row = block_rows[p0 + i / BS];
+      x[row * BS + i % BS] += u;
+    }
   }
 }
 
