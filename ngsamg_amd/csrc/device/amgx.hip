@@ -124,7 +124,7 @@ struct DevBGS {                         // block Gauss-Seidel over aggregate blo
 struct DevRestrict {                    // column-blocked P^T (see restrict_chunk_kernel)
   int n_chunks = 0;
   int64_t n_slots = 0;
-  DevBuf<int32_t> chunk_slot, slot_ptr, optr, oidx;
+  DevBuf<int32_t> chunk_slot, slot_ptr, optr, oidx, dest;     // dest = inverse of oidx (empty: partials stay in slot order)
   DevBuf<double> w, part;
   DevBuf<uint16_t> fi;
   bool empty() const { return n_chunks == 0; }
@@ -533,7 +533,15 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   std::vector<int32_t> pos(optr.begin(), optr.end() - 1);
   for (int64_t sidx = 0; sidx < ns; ++sidx) oidx[pos[slot_col[sidx]]++] = (int32_t)sidx;   // ascending chunk order per row
   R.n_chunks = (int)nch; R.n_slots = ns;
-  R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr); R.oidx.upload(oidx);
+  R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr);
+  // Measured NON-win (profiles/r01/restrict_fused.txt): storing the partial sums row by row (scattered stores in the
+  // producer, streaming loads in restrict_sum_kernel) makes the cycle 2-4 % slower at cfg 2; off unless AMGX_RSUM_SORT=1.
+  if (!std::getenv("AMGX_RSUM_SORT")) R.oidx.upload(oidx);
+  else {
+    std::vector<int32_t> dest(ns);
+    for (int64_t k = 0; k < ns; ++k) dest[oidx[k]] = (int32_t)k;
+    R.dest.upload(dest);
+  }
   R.w.upload(w); R.fi.upload(fi);
   R.part.alloc((size_t)std::max<int64_t>(1, ns));
 }
@@ -807,7 +815,7 @@ struct Handle {
     const DevRestrict& R = lev[l].R;
     if (R.empty()) { mult(lev[l].PT, xf, xc); return; }
     hipLaunchKernelGGL(restrict_chunk_kernel, dim3(R.n_chunks), dim3(BLOCK), 0, stream, lev[l].n, R.chunk_slot.p, R.slot_ptr.p,
-                       R.w.p, R.fi.p, xf, R.part.p);
+                       R.w.p, R.fi.p, xf, R.part.p, R.dest.p);
     hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                        R.oidx.p, R.part.p, xc);
     HIPCHK(hipGetLastError());
@@ -916,13 +924,13 @@ struct Handle {
       if (grid != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
       if (FB == 256)
         hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
       else if (FB == 512)
         hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
       else
         hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p);
+                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
       if (!skip_rsum)
         hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                            R.oidx.p, R.part.p, b_coarse);

@@ -634,7 +634,8 @@ constexpr int RESTRICT_MAX_ENTRIES = 4096;    // entries of P per chunk (P has <
 __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, const int32_t* __restrict__ chunk_slot,
                                                                const int32_t* __restrict__ slot_ptr,
                                                                const double* __restrict__ w, const uint16_t* __restrict__ fi,
-                                                               const double* __restrict__ r, double* __restrict__ part) {
+                                                               const double* __restrict__ r, double* __restrict__ part,
+                                                               const int32_t* __restrict__ dest) {
   __shared__ double rl[RESTRICT_CHUNK];
   __shared__ double pr[RESTRICT_MAX_ENTRIES];
   const int c = blockIdx.x;
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
     const int a = slot_ptr[slot] - e0, b = slot_ptr[slot + 1] - e0;
     double acc = 0.0;
     for (int k = a; k < b; ++k) acc += pr[k];
-    part[slot] = acc;
+    part[dest ? dest[slot] : slot] = acc;
   }
 }
 
@@ -669,7 +670,8 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
                                                                         const int32_t* __restrict__ chunk_slot,
                                                                         const int32_t* __restrict__ slot_ptr,
                                                                         const double* __restrict__ w, const uint16_t* __restrict__ fi,
-                                                                        double* __restrict__ part) {
+                                                                        double* __restrict__ part,
+                                                                        const int32_t* __restrict__ dest) {
   constexpr int FUSED_MAX_ENTRIES = 4 * FUSED_BLOCK;
   __shared__ double rl[FUSED_BLOCK];
   __shared__ double pr[FUSED_MAX_ENTRIES];
@@ -690,6 +692,9 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
   }
   const int myslot = s0 + threadIdx.x;
+  // dest (optional, AMGX_RSUM_SORT=1): the partials of one coarse row stored next to each other, so that
+  // restrict_sum_kernel streams them -- scattered stores here instead of scattered loads there; measured slower overall
+  const int mydest = (dest && myslot < s1) ? dest[myslot] : myslot;
   const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
   const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
   double r = 0.0;
@@ -718,13 +723,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   if (myslot < s1) {
     double acc = 0.0;
     for (int k = pa; k < pb; ++k) acc += pr[k];
-    part[myslot] = acc;
+    part[mydest] = acc;
   }
   for (int slot = myslot + FUSED_BLOCK; slot < s1; slot += FUSED_BLOCK) {     // chunks with more than 1024 slots
     const int a = slot_ptr[slot] - e0, bnd = slot_ptr[slot + 1] - e0;
     double acc = 0.0;
     for (int k = a; k < bnd; ++k) acc += pr[k];
-    part[slot] = acc;
+    part[dest ? dest[slot] : slot] = acc;
   }
 }
 
@@ -740,7 +745,8 @@ __global__ __launch_bounds__(BLOCK) void restrict_sum_kernel(int64_t n_coarse, c
   double acc = 0.0;
   if (J < n_coarse) {
     const int e = optr[J + 1];
-    for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[oidx[k]];
+    if (oidx) { for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[oidx[k]]; }
+    else { for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[k]; }      // partials stored row by row (dest)
   }
   // fixed combination order: deterministic
 #pragma unroll

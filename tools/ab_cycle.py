@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "no_hoist": {"AMGX_NO_EP_HOIST": "1"},
+    "rsum_sort": {"AMGX_RSUM_SORT": "1"},
 }
 
 
