@@ -385,6 +385,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
             raise NgsAMGError("distributed coarsening got stuck on a rank")
         P = H.levels[0].P.to_scipy()
         P_owns.append(P)
+        s.agg = np.array(H.levels[0].agg, copy=True)      # blocks of the block smoother (never cross ranks)
         c = RankState()
         c.rank = s.rank
         c.n = P.shape[1]
@@ -493,10 +494,23 @@ def _hybrid_gs_data(comm, states):
         s.color, s.n_colors = color, int(nc.value)
 
 
+def _hybrid_bgs_data(states):
+    """hybrid block Gauss-Seidel (reference HybridBS, block_gssmoother.cpp:505-585): BSmoother on the rank-local matrix M
+    whose diagonal is replaced by the l1-modified one (mod_diag), blocks = local aggregates; needs _hybrid_gs_data first"""
+    from .hierarchy import bgs_blocks_from_aggregates, bgs_data
+    for s in states:
+        Aoo = sp.csr_matrix(s.A[:, :s.n])
+        md = np.where(s.dinv_gs_ext[:s.n] != 0, 1.0 / np.where(s.dinv_gs_ext[:s.n] != 0, s.dinv_gs_ext[:s.n], 1.0), Aoo.diagonal())
+        Amod = sp.csr_matrix(Aoo - sp.diags(Aoo.diagonal()) + sp.diags(md))
+        Amod.sort_indices()
+        bp, br = bgs_blocks_from_aggregates(s.agg, s.free)
+        s.bgs = bgs_data(_mat(Amod), bp, br, pinv=False)
+
+
 class _TopHierarchy:
     """duck-typed Hierarchy holding the rank-partitioned levels of one rank (for DeviceAMGMatrix)"""
 
-    def __init__(self, states, gs=False, fold=False):
+    def __init__(self, states, gs=False, fold=False, bgs=False):
         self.levels = []
         for i, s in enumerate(states):
             last = i + 1 == len(states)
@@ -506,7 +520,8 @@ class _TopHierarchy:
             self.levels.append(Level(A=_mat(s.A), P=None if last else _mat(s.P), PT=None if last else _mat(s.PT),
                                      free=s.free, dinv=np.ascontiguousarray(dinv), coords=None, color=color,
                                      n_colors=s.n_colors if use_gs else 0, agg=None,
-                                     Q=_mat(s.Q) if (fold and not last and not use_gs) else None))
+                                     Q=_mat(s.Q) if (fold and not last and not use_gs) else None,
+                                     bgs=s.bgs if (bgs and not last) else None))
         self.coarse_n = 0
         self.coarse_inv = np.empty(0)
         self.n_levels = len(self.levels)
@@ -522,8 +537,8 @@ class DistributedAMG:
 
     def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=50000, max_dist_levels=3, device=0,
                  backend=None, sm_type="jacobi", fold=True, **opts):
-        if sm_type not in ("jacobi", "gs"):
-            raise NgsAMGError("DistributedAMG: sm_type must be jacobi or gs")
+        if sm_type not in ("jacobi", "gs", "bgs"):
+            raise NgsAMGError("DistributedAMG: sm_type must be jacobi, gs or bgs")
         self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
@@ -540,9 +555,12 @@ class DistributedAMG:
             levels.append(coarsen_distributed_level(comm, levels[0], dim, True, opts))
         for lv in levels:
             _dinv_ext(comm, lv)
-        if sm_type == "gs":
+        if sm_type in ("gs", "bgs"):
             for lv in levels[:-1]:
                 _hybrid_gs_data(comm, lv)
+        if sm_type == "bgs":
+            for lv in levels[:-1]:
+                _hybrid_bgs_data(lv)
         if self.fold:
             for lv in levels[:-1]:
                 _fold(lv, omega)
@@ -569,8 +587,11 @@ class DistributedAMG:
         topts = {k: v for k, v in opts.items() if k != "first_aaf"}
         topts["first_aaf"] = opts.get("aaf", 2.0 ** -dim)
         self.tail_hier = Hierarchy(_mat(Ag), None, None, dim=dim, energy=0, **topts)
+        if sm_type == "bgs":
+            self.tail_hier.build_bgs(pinv=False)
         # ---- per-rank execution objects --------------------------------------------------------------------
-        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type == "gs"), fold=self.fold) for i in range(len(states0))]
+        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type in ("gs", "bgs")), fold=self.fold, bgs=(sm_type == "bgs"))
+                     for i in range(len(states0))]
         if backend is None:
             backend = _device_backend(device, omega, sm_type)
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
@@ -588,8 +609,8 @@ class DistributedAMG:
                 b["text"].append(ops.zeros(next_))
                 b["x"].append(ops.zeros(s.n))
                 b["r"].append(ops.zeros(s.n))
-                b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type == "gs" or self.fold) else None)
-                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type == "gs" else None)
+                b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type in ("gs", "bgs") or self.fold) else None)
+                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type in ("gs", "bgs") else None)
                 # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
                 peers = sorted(s.send)
                 allidx = np.concatenate([s.send[q] for q in peers]) if peers else np.empty(0, dtype=np.int64)
@@ -631,7 +652,7 @@ class DistributedAMG:
 
     def Mult(self, bs, xs):
         """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind)"""
-        if self.sm_type == "gs":
+        if self.sm_type in ("gs", "bgs"):
             return self._mult_gs(bs, xs)
         if self.fold:
             return self._mult_folded(bs, xs)
@@ -784,6 +805,28 @@ class DistributedAMG:
                     block.append(np.full(t[2].size, t[0], dtype=np.int32))
                 L.gs_order = np.concatenate(order).astype(np.int32)
                 L.gs_block = np.concatenate(block)
+            if self.sm_type == "bgs":
+                # hybrid block GS as ONE serial smoother: blocks of all ranks (global row ids), visited rank by rank and
+                # colour-major inside a rank; rows of another rank are read at their sweep-start values (gs_block)
+                from .hierarchy import BGSData
+                pg = [(s.rank, s.n, s.bgs.block_ptr, s.bgs.block_rows, s.bgs.dinv_ptr, s.bgs.dinv, s.bgs.color) for s in lv]
+                gg = sorted(comm.allgather(pg)[0], key=lambda t: t[0])
+                bptr, brow, dptr, dval, order, col, block = [np.zeros(1, dtype=np.int64)], [], [np.zeros(1, dtype=np.int64)], [], [], [], []
+                nb = 0
+                for r, nloc, bp, br, dp, dv, cc in gg:
+                    bptr.append(bptr[-1][-1] + np.asarray(bp[1:], dtype=np.int64))
+                    brow.append(off[r] + np.asarray(br, dtype=np.int64))
+                    dptr.append(dptr[-1][-1] + np.asarray(dp[1:], dtype=np.int64))
+                    dval.append(np.asarray(dv)[:int(dp[-1])])
+                    order.append(nb + np.argsort(np.asarray(cc), kind="stable"))
+                    col.append(np.asarray(cc))
+                    block.append(np.full(nloc, r, dtype=np.int32))
+                    nb += len(cc)
+                L.bgs = BGSData(nb, np.concatenate(bptr).astype(np.int32), np.concatenate(brow).astype(np.int32),
+                                np.concatenate(dptr).astype(np.int64), np.concatenate(dval) if dval else np.zeros(1),
+                                np.concatenate(col).astype(np.int32), int(max(c.max() for c in col) + 1) if nb else 0,
+                                order=np.concatenate(order).astype(np.int32))
+                L.gs_block = np.concatenate(block)
             out.append(L)
         return out + list(self.tail_hier.levels)
 
@@ -791,7 +834,13 @@ class DistributedAMG:
         """per-level smoother names for oracle.pyoracle.Oracle over global_levels()"""
         if self.sm_type == "jacobi":
             return ["jacobi"] * (self.k + self.tail_hier.n_levels)
+        if self.sm_type == "bgs":
+            return ["bgs_mc"] * (self.k + self.tail_hier.n_levels)
         return ["gs_order"] * self.k + ["gs_mc"] * self.tail_hier.n_levels
+
+    def oracle_bgs(self, levels):
+        """bgs=... argument for the oracle over global_levels() (block smoother only)"""
+        return [getattr(L, "bgs", None) for L in levels] if self.sm_type == "bgs" else None
 
 
 def _device_backend(device, omega, sm_type="jacobi"):

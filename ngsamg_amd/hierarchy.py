@@ -48,6 +48,7 @@ class BGSData:
     dinv: np.ndarray           # float64, M_k x M_k column-major per block, M_k = bs * |block k|
     color: np.ndarray          # int32 [n_blocks]
     n_colors: int
+    order: np.ndarray | None = None    # explicit visiting order of the blocks (oracle only; default: colour-major)
 
 
 def bgs_blocks_from_aggregates(agg, free=None):

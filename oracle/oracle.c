@@ -209,7 +209,9 @@ static void gs_smooth(const orc_level* L, int dir, double* x, const double* b, d
 
 #define ORC_MAXBLOCK 4096
 /* one block, RHS form (:300-323): hr_j = b_j - A_j: x for the rows j of the block, hup = Dinv hr, x_B += hup */
-static void bgs_block_rhs(const orc_level* L, int32_t k, double* x, const double* b, double* hr, double* hup) {
+/* xo != NULL: hybrid form (reference HybridBS, block_gssmoother.cpp:505-585 on top of hybrid_base_smoother.cpp:296-495) --
+ * entries whose column belongs to another rank ("gs_block" = owner of every row) read the sweep-start values xo */
+static void bgs_block_rhs(const orc_level* L, int32_t k, double* x, const double* b, double* hr, double* hup, const double* xo) {
   const orc_matrix* A = &L->A;
   const int bs = A->br;
   const int32_t p0 = L->block_ptr[k], m = L->block_ptr[k + 1] - p0;
@@ -219,7 +221,8 @@ static void bgs_block_rhs(const orc_level* L, int32_t k, double* x, const double
     double r[MAXBS] = {0, 0, 0, 0, 0, 0};
     for (int64_t p = A->rowptr[j]; p < A->rowptr[j + 1]; p++) {
       const double* a = A->val + p * bs * bs;
-      const double* xv = x + (int64_t)A->col[p] * bs;
+      const int64_t cj = A->col[p];
+      const double* xv = ((xo && L->gs_block[cj] != L->gs_block[j]) ? xo : x) + cj * bs;
       for (int i = 0; i < bs; i++)
         for (int c = 0; c < bs; c++) r[i] += a[i * bs + c] * xv[c];
     }
@@ -254,11 +257,18 @@ static void bgs_block_res(const orc_level* L, int32_t k, double* x, double* res,
 static int bgs_sweep(const orc_level* L, double* x, const double* b, double* res, int res_form, int backwards) {
   double hr[ORC_MAXBLOCK], hup[ORC_MAXBLOCK];
   const int32_t nb = L->n_blocks;
+  const double* xo = NULL;
+  if (L->gs_block) {           /* hybrid: freeze the off-rank values, gather form only (like gs_sweep) */
+    double* snap = g_cur->x_old[(int)(L - g_cur->lev)];
+    memcpy(snap, x, sizeof(double) * L->A.n_cols * L->A.bc);
+    xo = snap;
+    res_form = 0;
+  }
   for (int32_t q = 0; q < nb; q++) {
     const int32_t pos = backwards ? nb - 1 - q : q;
     const int32_t k = L->block_order ? L->block_order[pos] : pos;
     if ((L->block_ptr[k + 1] - L->block_ptr[k]) * L->A.br > ORC_MAXBLOCK) return 1;
-    if (res_form) bgs_block_res(L, k, x, res, hr, hup); else bgs_block_rhs(L, k, x, b, hr, hup);
+    if (res_form) bgs_block_res(L, k, x, res, hr, hup); else bgs_block_rhs(L, k, x, b, hr, hup, xo);
   }
   return 0;
 }
@@ -266,6 +276,11 @@ static int bgs_sweep(const orc_level* L, double* x, const double* b, double* res
 static void bgs_smooth(const orc_level* L, int dir, double* x, const double* b, double* res,
                        int res_updated, int update_res, int x_zero) {
   /* BSmoother::Smooth / SmoothBack, block_gssmoother.cpp:434-498 */
+  if (L->gs_block) {           /* hybrid block smoother: local sweep with frozen off-rank values, then the residual */
+    bgs_sweep(L, x, b, res, 0, dir);
+    if (update_res) spmv(&L->A, x, res, 1, 0.0, b);
+    return;
+  }
   if (update_res) {
     if (!res_updated) {          /* CalcResiduum(x, b, res, x_zero), base_smoother.hpp:132-142 */
       if (x_zero) memcpy(res, b, sizeof(double) * vlen(L));

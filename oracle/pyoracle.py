@@ -136,8 +136,15 @@ class Oracle:
                     o.n_blocks = int(g.n_blocks)
                     o.block_ptr, o.block_rows = _p(bp, C.c_int32), _p(br, C.c_int32)
                     o.bdinv_ptr, o.bdinv = _p(dp, C.c_int64), _p(dv, C.c_double)
+                    blk = getattr(lv, "gs_block", None)           # hybrid (rank-partitioned) block smoother: owner per row
+                    if blk is not None:
+                        blk = np.ascontiguousarray(blk, dtype=np.int32)
+                        self._keep.append(blk)
+                        o.gs_block = _p(blk, C.c_int32)
                     if t == "bgs_mc":
-                        order = np.ascontiguousarray(np.argsort(np.asarray(g.color), kind="stable").astype(np.int32))
+                        explicit = getattr(g, "order", None)      # e.g. rank-major, colour-major inside a rank (hybrid)
+                        order = np.ascontiguousarray((np.asarray(explicit) if explicit is not None else
+                                                      np.argsort(np.asarray(g.color), kind="stable")).astype(np.int32))
                         self._keep.append(order)
                         o.block_order = _p(order, C.c_int32)
             o.omega = omega

@@ -22,7 +22,7 @@ def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
     xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
     amg.Mult(bs, xs)
     glv = amg.global_levels()
-    ref = Oracle(glv, sm_type=amg.oracle_sm_types()).apply(np.concatenate([b.numpy() for b in bs]))
+    ref = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv)).apply(np.concatenate([b.numpy() for b in bs]))
     got = np.concatenate([x.numpy() for x in xs])
     return amg, got, ref
 
@@ -46,6 +46,20 @@ def test_loopback_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin):
     # and the hybrid smoother still gives a convergent preconditioner: PCG on the global system
     glv = amg.global_levels()
     orc = Oracle(glv, sm_type=amg.oracle_sm_types())
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
+    _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)
+    assert errs[-1] < 1e-8 * errs[0] and it < 60
+
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (12, 12, 12), 3, 100), (4, (10, 10, 10), 3, 50), (8, (8, 8, 8), 3, 20)])
+def test_loopback_hybrid_block_gs_matches_serial_hybrid_oracle(R, box, dim, dmin):
+    """rank-partitioned hybrid BLOCK Gauss-Seidel (reference HybridBS: BSmoother on the local matrix with the l1-modified
+    diagonal, blocks = local aggregates) == the oracle's serial block smoother with frozen off-rank values"""
+    amg, got, ref = _run_loopback(R, box, dim, dmin, "bgs")
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv))
     rng = np.random.default_rng(5)
     b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
     _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)

@@ -61,17 +61,19 @@ def test_distributed_equals_single_gpu_cycle_on_global_hierarchy():
     assert np.linalg.norm(got - x) <= 1e-12 * np.linalg.norm(x)
 
 
+@pytest.mark.parametrize("sm", ["gs", "bgs"])
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (8, (10, 10, 10), 3, 40), (4, (40, 40), 2, 100)])
-def test_loopback_device_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin):
+def test_loopback_device_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin, sm):
     """hybrid Gauss-Seidel on rank-partitioned levels (a5): local multicolour sweeps with frozen off-rank values and
-    the l1-type modified diagonal == the oracle's serial hybrid GS with blocks = ranks"""
+    the l1-type modified diagonal == the oracle's serial hybrid GS with blocks = ranks; sm = "bgs": the hybrid BLOCK
+    smoother (reference HybridBS: blocks = local aggregates, modified diagonal inside the diagonal blocks)"""
     import torch
     from ngsamg_amd import dist as D
     from oracle.pyoracle import Oracle
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
-    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type="gs")
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm)
     rng = np.random.default_rng(0)
     bh = [rng.standard_normal(s.n) * s.free for s in states]
     bs = [torch.from_numpy(b).cuda() for b in bh]
@@ -79,6 +81,7 @@ def test_loopback_device_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmi
     for rep in range(2):
         amg.Mult(bs, xs)
     torch.cuda.synchronize()
-    ref = Oracle(amg.global_levels(), sm_type=amg.oracle_sm_types()).apply(np.concatenate(bh))
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv)).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
