@@ -125,6 +125,21 @@ class BaseDOFMapStep:
     def GetProl(self):
         return self._amg._hier.levels[self._level].P
 
+    def Concatenate(self, other):
+        """this step followed by `other` as ONE prolongation matrix P_this * P_other (python_coarse.cpp:15-121)"""
+        return SparseMM(self.GetProl(), other.GetProl() if hasattr(other, "GetProl") else other)
+
+    def ProjectMatrix(self, mat):
+        """Galerkin projection P^T mat P of a fine-level matrix (dof_map.hpp: AssembleMatrix)"""
+        P = self.GetProl()
+        return SparseMM(self._amg._hier.levels[self._level].PT, SparseMM(_as_matrix(mat, P.br), P))
+
+    def PrintTo(self, stream=None):
+        import sys
+        P = self.GetProl()
+        print(f"ProlMap step {self._level}: {P.n_rows} x {P.n_cols}, blocks {P.br} x {P.bc}, {P.nnz} entries",
+              file=stream or sys.stdout)
+
 
 class DOFMap:
     """Container of the grid-transfer steps (reference dof_map.hpp:87-169)."""
@@ -152,6 +167,19 @@ class DOFMap:
 
     def AddC2F(self, level, fac, x_fine, x_coarse):
         return self.GetStep(level).AddC2F(fac, x_fine, x_coarse)
+
+    def SubMap(self, start):
+        """the steps start, start+1, ... as a map of their own (python_coarse.cpp: SubMap)"""
+        return self._amg.SubAMGMatrix(start).GetMap()
+
+    def ConcStep(self, la, lb):
+        """prolongation from level lb to level la (la < lb) as one sparse matrix: P_la * ... * P_(lb-1)"""
+        if not 0 <= la < lb <= self.GetNSteps():
+            raise NgsAMGError("ConcStep: need 0 <= la < lb <= number of steps")
+        P = self._amg._hier.levels[la].P
+        for l in range(la + 1, lb):
+            P = SparseMM(P, self._amg._hier.levels[l].P)
+        return P
 
     def TransferAtoB(self, la, lb, vin, vout):
         """move a host vector from level la to level lb through all steps in between (dof_map.cpp:500-573)"""
@@ -212,6 +240,19 @@ class AMGMatrix:
     def SmoothVFromLevel(self, level, x, b, res, res_updated=False, update_res=False, x_zero=False):
         return self._dev.SmoothVFromLevel(level, x, b, res, res_updated, update_res, x_zero)
 
+    def SubAMGMatrix(self, start_level):
+        """the cycle that starts at level start_level (python_solve.cpp:55-109): its own device handle over the levels
+        start_level .. L-1 with the same smoother / cycle configuration"""
+        if not 0 <= start_level < self._hier.n_levels:
+            raise NgsAMGError("SubAMGMatrix: level out of range")
+        if start_level == 0:
+            return self
+        sub = _SubHierarchy(self._hier, start_level)
+        cfg = dict(self._dev._cfg)
+        if isinstance(cfg.get("sm_type"), (list, tuple)):
+            cfg["sm_type"] = list(cfg["sm_type"][start_level:])
+        return AMGMatrix(sub, DeviceAMGMatrix(sub, **cfg))
+
     def CINV(self, sol, rhs):
         """restrict rhs to the coarsest level, solve there, prolongate back (amg_matrix.cpp:406-431)"""
         m = self.GetMap()
@@ -234,6 +275,16 @@ class AMGMatrix:
         e = np.zeros(n * bs)
         e[bs * dof + comp] = 1.0
         return self.GetMap().TransferAtoB(level, 0, e, vec)
+
+
+class _SubHierarchy:
+    """levels start .. L-1 of a hierarchy, as a hierarchy of their own"""
+
+    def __init__(self, hier, start):
+        self._parent = hier                     # keeps the level arrays alive
+        self.levels = list(hier.levels[start:])
+        self.coarse_n, self.coarse_inv = hier.coarse_n, hier.coarse_inv
+        self.n_levels = len(self.levels)
 
 
 class _AMGPreconditioner:
@@ -492,6 +543,106 @@ def CreateHybridBlockGSS(mat, blocks, NG_MPI_overlap=True, NG_MPI_thread=False, 
     hier.levels[0].bgs = bgs_data(A, ptr, np.concatenate(rows) if rows else np.empty(0, dtype=np.int32), pinv=pinv)
     dev = DeviceAMGMatrix(hier, sm_type="bgs", sm_steps=nsteps, sm_symm=symm, clev="none", device=device)
     return BaseSmoother(AMGMatrix(hier, dev), 0)
+
+
+class _DirectInverseSmoother(BaseSmoother):
+    """RichardsonSmoother(A, A^-1 on the free dofs, omega = 1): what CreateHybridDISmoother degenerates to on one
+    rank (python_smoothers.cpp:278-312)"""
+
+    def __init__(self, mat, freedofs, device=0):
+        A = _as_matrix(mat, 1)
+        hier = _SingleLevel(A, freedofs, False)
+        n = A.n_rows * A.br
+        if n > 4096:
+            raise NgsAMGError("CreateHybridDISmoother: the dense inverse is limited to 4096 scalar dofs")
+        D = A.to_scipy().toarray()
+        f = np.repeat(hier.levels[0].free.astype(bool), A.br)
+        inv = np.zeros((n, n))
+        inv[np.ix_(f, f)] = np.linalg.inv(D[np.ix_(f, f)])
+        hier.coarse_n, hier.coarse_inv = n, np.ascontiguousarray(inv.ravel())
+        dev = DeviceAMGMatrix(hier, sm_type="jacobi", clev="inv", device=device)
+        super().__init__(AMGMatrix(hier, dev), 0)
+
+    def _step(self, x, rhs, res, res_updated, update_res, x_zero):
+        dev = self._amg._dev
+        res = self._res(x, res)
+        if not res_updated:
+            dev.Residual(0, x, rhs, res)
+        d = np.zeros_like(np.asarray(res)) if not hasattr(res, "new_zeros") else res.new_zeros(res.shape)
+        dev.CoarseSolve(res, d)
+        x += d
+        if update_res:
+            dev.Residual(0, x, rhs, res)
+
+    def Smooth(self, x, rhs, res=None, res_updated=False, update_res=False, x_zero=False):
+        self._step(x, rhs, res, res_updated, update_res, x_zero)
+
+    SmoothBack = Smooth
+
+
+def CreateHybridDISmoother(mat, freedofs=None, NG_MPI_overlap=True, NG_MPI_thread=False, symm=False, nsteps=1, device=0):
+    sm = _DirectInverseSmoother(mat, freedofs, device=device)
+    return ProxySmoother(sm, nsteps, symm) if (nsteps > 1 or symm) else sm
+
+
+# ---- utils (reference src/base/utils/python_utils.cpp:30-193) ---------------------------------------------
+
+def SparseMM(A, B):
+    """C = A * B for (block-)sparse matrices"""
+    import ctypes as C
+    A, B = _as_matrix(A, 1), _as_matrix(B, 1)
+    if A.n_cols != B.n_rows or A.bc != B.br:
+        raise NgsAMGError("SparseMM: shapes do not match")
+    lib = _lib.host()
+    da, db = A.desc(), B.desc()
+    rp = np.zeros(A.n_rows + 1, dtype=np.int64)
+    _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), None, None))
+    col = np.zeros(max(1, int(rp[-1])), dtype=np.int32)
+    val = np.zeros(max(1, int(rp[-1])) * A.br * B.bc)
+    _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), _lib.ptr(col, C.c_int32), _lib.ptr(val, C.c_double)))
+    return Matrix(A.n_rows, B.n_cols, A.br, B.bc, rp, col[: int(rp[-1])], val[: int(rp[-1]) * A.br * B.bc])
+
+
+def CompressSparseMatrix(mat, tol=1e-20):
+    """drop the stored blocks whose entries are all <= tol in magnitude"""
+    A = _as_matrix(mat, 1)
+    bb = A.br * A.bc
+    keep = np.abs(np.asarray(A.val).reshape(-1, bb)).max(axis=1) > tol if A.nnz else np.zeros(0, dtype=bool)
+    rows = np.repeat(np.arange(A.n_rows), np.diff(A.rowptr))
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=A.n_rows))]).astype(np.int64)
+    return Matrix(A.n_rows, A.n_cols, A.br, A.bc, rp, np.asarray(A.col)[keep].astype(np.int32),
+                  np.asarray(A.val).reshape(-1, bb)[keep].ravel())
+
+
+def ToSparseMatrix(mat, compress=False, compressTol=1e-20):
+    A = _as_matrix(mat, 1)
+    return CompressSparseMatrix(A, compressTol) if compress else A
+
+
+def RestrictMatrixToBlocks(mat, rowBlocks, colBlocks=None, tol=1e-20):
+    """keep the entries (i, j) for which some k has i in rowBlocks[k] and j in colBlocks[k] (default: same blocks)"""
+    A = _as_matrix(mat, 1)
+    colBlocks = rowBlocks if colBlocks is None else colBlocks
+    rb = -np.ones(A.n_rows, dtype=np.int64)
+    cb = -np.ones(A.n_cols, dtype=np.int64)
+    for k, (r, c) in enumerate(zip(rowBlocks, colBlocks)):
+        rb[np.asarray(list(r), dtype=np.int64)] = k
+        cb[np.asarray(list(c), dtype=np.int64)] = k
+    rows = np.repeat(np.arange(A.n_rows), np.diff(A.rowptr))
+    keep = (rb[rows] >= 0) & (rb[rows] == cb[np.asarray(A.col)])
+    bb = A.br * A.bc
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=A.n_rows))]).astype(np.int64)
+    R = Matrix(A.n_rows, A.n_cols, A.br, A.bc, rp, np.asarray(A.col)[keep].astype(np.int32),
+               np.asarray(A.val).reshape(-1, bb)[keep].ravel())
+    return CompressSparseMatrix(R, tol)
+
+
+def GetMemoryUse(mat):
+    """bytes of the stored (block-)CSR arrays"""
+    if mat is None:
+        return 0
+    A = _as_matrix(mat, 1)
+    return int(np.asarray(A.rowptr).nbytes + np.asarray(A.col).nbytes + np.asarray(A.val).nbytes)
 
 
 class ProxySmoother(BaseSmoother):

@@ -54,6 +54,8 @@ class DeviceAMGMatrix:
                  clev="inv", device=0, use_graph=True):
         lib = _lib.hip()
         self._lib = lib
+        self._cfg = dict(sm_type=sm_type, omega=omega, sm_steps=sm_steps, sm_symm=sm_symm, mg_cycle=mg_cycle, clev=clev,
+                         device=device, use_graph=use_graph)
         self.hierarchy = hierarchy
         levels = hierarchy.levels
         n = len(levels)

@@ -128,3 +128,59 @@ def test_error_behaviour():
     e = fem.elasticity_fast((4, 4, 4))
     with pytest.raises(NgsAMGError):
         NgsAMG.elast_3d(_mat(e), e.free)                    # coordinates missing
+
+
+def test_sub_amg_matrix_concatenated_steps_and_utils():
+    """python_solve.cpp SubAMGMatrix, python_coarse.cpp ConcStep / Concatenate / ProjectMatrix, python_utils.cpp helpers"""
+    from ngsamg_amd import NgsAMG
+    from oracle.pyoracle import Oracle
+    p = fem.poisson_fast((15, 14, 13))
+    c = NgsAMG.h1_scal(_mat(p), p.free, ngs_amg_max_coarse_size=10, ngs_amg_sm_type="jacobi")
+    amg = c.GetAMGMatrix()
+    H = c.GetHierarchy()
+    assert amg.GetNLevels() >= 3
+    sub = amg.SubAMGMatrix(1)
+    n1 = sub.height
+    rng = np.random.default_rng(0)
+    b1 = rng.standard_normal(n1) * H.levels[1].free
+    x1 = np.zeros(n1)
+    sub.Mult(b1, x1)
+    ref = Oracle(H.levels[1:], sm_type="jacobi").apply(b1)
+    assert np.linalg.norm(x1 - ref) <= 1e-12 * np.linalg.norm(ref)
+    m = amg.GetMap()
+    P02 = m.ConcStep(0, 2).to_scipy()
+    ref02 = (H.levels[0].P.to_scipy() @ H.levels[1].P.to_scipy())
+    assert abs(P02 - ref02).max() < 1e-14
+    assert abs(m.GetStep(0).Concatenate(m.GetStep(1)).to_scipy() - ref02).max() < 1e-14
+    A1 = m.GetStep(0).ProjectMatrix(H.levels[0].A).to_scipy()
+    assert abs(A1 - H.levels[1].A.to_scipy()).max() <= 1e-12 * abs(A1).max()       # Galerkin identity
+    assert m.SubMap(1).GetNLevels() == amg.GetNLevels() - 1
+    # utils
+    A = H.levels[0].A
+    AA = NgsAMG.SparseMM(A, A).to_scipy()
+    As = A.to_scipy()
+    assert abs(AA - As @ As).max() <= 1e-12 * abs(AA).max()
+    assert NgsAMG.GetMemoryUse(A) == A.rowptr.nbytes + A.col.nbytes + A.val.nbytes
+    blocks = [np.arange(k, min(k + 5, A.n_rows)) for k in range(0, A.n_rows, 5)]
+    R = NgsAMG.RestrictMatrixToBlocks(A, blocks).to_scipy().tocoo()
+    assert np.all(R.row // 5 == R.col // 5) and R.nnz > 0
+    Z = As.copy()
+    Z.data[::3] = 0.0
+    Zc = NgsAMG.CompressSparseMatrix(Z.tocsr())
+    assert Zc.nnz == np.count_nonzero(Z.data) and abs(Zc.to_scipy() - Z).max() == 0.0
+    assert NgsAMG.ToSparseMatrix(Z.tocsr(), compress=True).nnz == Zc.nnz
+
+
+def test_direct_inverse_smoother():
+    """CreateHybridDISmoother on one rank = Richardson with the exact inverse: one step solves the system"""
+    from ngsamg_amd import NgsAMG
+    p = fem.poisson_fast((9, 8, 7))
+    sm = NgsAMG.CreateHybridDISmoother(_mat(p), p.free)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(p.n) * p.free
+    x = np.zeros(p.n)
+    res = np.zeros(p.n)
+    sm.Smooth(x, b, res, False, True, False)
+    A = _mat(p).to_scipy()
+    assert np.linalg.norm((b - A @ x) * p.free) <= 1e-10 * np.linalg.norm(b)
+    assert np.linalg.norm((res - (b - A @ x)) * p.free) <= 1e-10 * np.linalg.norm(b)
