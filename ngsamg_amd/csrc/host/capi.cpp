@@ -156,7 +156,11 @@ int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_p
       for (int32_t k = 0; k < n_blocks; k++) {
         const int32_t p0 = block_ptr[k], m = block_ptr[k + 1] - p0;
         const int M = m * bs;
-        if ((int64_t)M * M != dinv_ptr[k + 1] - dinv_ptr[k]) { bad = 1; continue; }
+        if ((int64_t)M * M != dinv_ptr[k + 1] - dinv_ptr[k]) {
+#pragma omp atomic write
+          bad = 1;
+          continue;
+        }
         if (!m) continue;
         for (int32_t q = 0; q < m; q++) loc[block_rows[p0 + q]] = q;
         D.assign((size_t)M * M, 0.0);
@@ -171,7 +175,10 @@ int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_p
         }
         for (int32_t q = 0; q < m; q++) loc[block_rows[p0 + q]] = -1;
         if (pinv) amgh::pseudo_inverse_try_normal(D.data(), M);
-        else if (!amgh::dense_inverse(D.data(), M)) bad = 2;
+        else if (!amgh::dense_inverse(D.data(), M)) {
+#pragma omp atomic write
+          bad = 2;
+        }
         double* out = dinv_out + dinv_ptr[k];
         for (int r = 0; r < M; r++)
           for (int c = 0; c < M; c++) out[(size_t)c * M + r] = D[(size_t)r * M + c];      // column-major
