@@ -77,12 +77,12 @@ struct DevMatrix {
     DevBuf<int32_t> col32, cbase;
     DevBuf<uint16_t> col16;
     DevBuf<double> val;
-    int rowrel = 0, diag_first = 0;
+    int rowrel = 0, diag_first = 0, wdiag = 0;
     // windowed form (sell_win_spmv_kernel): inside every window of `win` consecutive rows the rows are stored in order
     // of decreasing length (slice padding 1.42 -> 1.08 on Q at cfg 2); rowloc[slot] = row of the slot inside its window
     int win = 0;
     DevBuf<uint16_t> rowloc;
-    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first}; }
+    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first, wdiag}; }
   } sell;
   struct BSell {                       // block SELL (kernels.hpp, BSellMat)
     DevBuf<int64_t> slice_ptr;
@@ -314,6 +314,21 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
   }
 }
 
+// G == 1, diagonal-first SELL: overwrite the diagonal slot (entry 0) of every row (see SellMat::wdiag)
+static void patch_sell_diag(HostSell& S, int64_t n_rows, const double* dval) {
+  const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
+  for (int64_t s = 0; s < ns; ++s) {
+    const int64_t base = S.slice_ptr[s] & ~(int64_t)63;
+    const int w = (int)(((S.slice_ptr[s + 1] & ~(int64_t)63) - base) / WAVE);
+    if (w == 0) continue;
+    for (int l = 0; l < WAVE; ++l) {
+      const int64_t row = s * WAVE + l;
+      if (row >= n_rows) break;
+      S.val[w >= 2 ? base + l * 2 : base + l] = dval[row];
+    }
+  }
+}
+
 static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
   const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
   D.rowrel = S.rowrel;
@@ -385,7 +400,7 @@ static void check_matrix(const amgx_matrix& A, const char* what) {
 }
 
 static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true, bool rowrel_ok = false, bool keep_csr = false,
-                          double max_pad = 1.35, int win = 0) {
+                          double max_pad = 1.35, int win = 0, const double* diag_override = nullptr) {
   check_matrix(A, what);
   D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = A.br; D.bc = A.bc;
   D.nnz = A.rowptr[A.n_rows];
@@ -426,12 +441,15 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   } else if (sellG) {
     HostSell S;
     build_sell(A, nullptr, A.n_rows, rowrel_ok && A.n_cols >= A.n_rows, sellG, S, rowrel_ok);
+    const bool wdiag = diag_override && S.diag_first && sellG == 1;
+    if (wdiag) patch_sell_diag(S, A.n_rows, diag_override);
     D.fmt = FMT_SELL;
     D.lanes = sellG;
     D.n_slices = (int)(S.slice_ptr.size() - 1);
     D.stored = S.slice_ptr.back() & ~(int64_t)63;
     D.stream_bytes = S.stream_bytes;
     upload_sell(S, D.sell);
+    D.sell.wdiag = wdiag ? 1 : 0;
   } else {
     D.fmt = FMT_CSRVEC;
     D.stored = D.nnz;
@@ -1421,7 +1439,24 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
         amgx_matrix As = s.A;
         As.val = sv.data();
-        upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true);
+        // one-thread-per-row form: the diagonal slot carries omega*Dinv_i (SellMat::wdiag), the epilogue then needs no
+        // dinv stream (80 MB per pass at cfg 2); AMGX_NO_WDIAG=1 keeps A'_ii there
+        std::vector<double> wdv;
+        if (s.omega != 0.0 && !std::getenv("AMGX_NO_WDIAG")) {
+          // the epilogue re-inserts A'_ii b_i as omega*b_i (or 0 where dinv_i = 0): valid iff dinv is the plain inverse diagonal
+          bool plain = true;
+          for (int64_t i = 0; i < s.A.n_rows && plain; ++i) {
+            if (s.dinv[i] == 0.0) continue;
+            double aii = 0.0;
+            for (int64_t k = s.A.rowptr[i]; k < s.A.rowptr[i + 1]; ++k) if (s.A.col[k] == i) { aii = s.A.val[k]; break; }
+            if (!(std::fabs(s.dinv[i] * aii - 1.0) < 1e-13)) plain = false;
+          }
+          if (plain) {
+            wdv.resize((size_t)s.A.n_rows);
+            for (int64_t i = 0; i < s.A.n_rows; ++i) wdv[i] = s.omega * s.dinv[i];
+          }
+        }
+        upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
         // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
         // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
         // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.

@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
 // own-row operands of an epilogue, loaded ahead of the row product (EPF_HOIST)
 struct EpOps { double b, d, yin; };
 template <int EP>
-__device__ __forceinline__ EpOps ep_operands(int64_t row, const EpArgs& ep, bool have_xd) {
+__device__ __forceinline__ EpOps ep_operands(int64_t row, const EpArgs& ep, bool have_xd, bool skip_d = false) {
   EpOps o{0.0, 0.0, 0.0};
   const bool nt = ep.nt & EPF_NT;
   if (EP == EP_RES) o.b = ep.b[row];
@@ -99,7 +99,7 @@ __device__ __forceinline__ EpOps ep_operands(int64_t row, const EpArgs& ep, bool
     o.b = nt ? ld_nt(ep.b + row) : ep.b[row];
     if (!have_xd) o.yin = ep.yin[row];
   } else if (EP == EP_PRE) {
-    o.d = nt ? ld_nt(ep.dinv + row) : ep.dinv[row];
+    if (!skip_d) o.d = nt ? ld_nt(ep.dinv + row) : ep.dinv[row];
     if (!have_xd) o.b = ep.b[row];
   }
   return o;
@@ -138,6 +138,8 @@ struct SellMat {
   const double* val;
   int rowrel;
   int diag_first;             // G == 1 only: entry 0 of every row is its diagonal, so the gathered x[row] comes for free
+  int wdiag;                  // pre-smoothing image A' only (implies diag_first): the diagonal slot holds omega*Dinv_i instead of
+                              //   A'_ii (which is omega for a free row, 0 otherwise), so the epilogue needs no dinv stream
 };
 
 // SELL row product, software-pipelined in batches of K pair-steps: the matrix loads (values + packed indices) of batch
@@ -186,7 +188,7 @@ __device__ __forceinline__ void sell_consume(const SellRegs<K>& R, const int32_t
     x0[k] = x[c0];
     x1[k] = x[c1];
   }
-  if (xd && p == 0) *xd = x0[0];
+  if (xd && p == 0) { xd[0] = x0[0]; xd[1] = R.v0[0]; }
 #pragma unroll
   for (int k = 0; k < K; ++k) { acc0 += R.v0[k] * x0[k]; acc1 += R.v1[k] * x1[k]; }
 }
@@ -234,7 +236,8 @@ __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb
 }
 
 // dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
-// xd (optional): receives the x value gathered for entry 0 of this lane's row (meaningful when M.diag_first)
+// xd (optional, 2 doubles): receives the x value gathered for entry 0 of this lane's row and the matrix value of that
+// entry (meaningful when M.diag_first)
 __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd = nullptr) {
   const int64_t sp0 = M.slice_ptr[s];
   const int64_t base = sp0 & ~(int64_t)63;
@@ -257,7 +260,7 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
   else sell_pairs<false>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
   if (w & 1) {
     const double x0 = x[c16 ? r0 + cb[w - 1] + cs : cs];
-    if (xd && np == 0) *xd = x0;
+    if (xd && np == 0) { xd[0] = x0; xd[1] = vs; }
     acc0 += vs * x0;
   }
   return acc0 + acc1;
@@ -272,18 +275,25 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
   const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
   const int row = s * (WAVE / G) + lane / G;
-  double xd = 0.0;
+  double xd[2] = {0.0, 0.0};
   const bool use_xd = G == 1 && (EP == EP_JAC || EP == EP_PRE) && M.diag_first;
+  const bool wdiag = EP == EP_PRE && use_xd && M.wdiag;
   const bool writer = (lane % G) == 0 && row < n_rows;
   const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
   EpOps ops{0.0, 0.0, 0.0};
-  if (hoist && writer) ops = ep_operands<EP>(row, ep, use_xd);
-  double acc = sell_row_dot(M, s, lane, row, x, use_xd ? &xd : nullptr);
+  if (hoist && writer) ops = ep_operands<EP>(row, ep, use_xd, wdiag);
+  double acc = sell_row_dot(M, s, lane, row, x, use_xd ? xd : nullptr);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
   if (writer) {
-    if (!hoist) ops = ep_operands<EP>(row, ep, use_xd);
-    store_scalar_ops<EP>(row, acc, y, ep, ops, use_xd, xd);
+    if (!hoist) ops = ep_operands<EP>(row, ep, use_xd, wdiag);
+    if (wdiag) {
+      // diagonal slot = wd = omega*Dinv_i: take it out of the product and put the true A'_ii b_i (omega*b_i or 0) back
+      const double wd = xd[1], bi = xd[0];
+      acc = acc - wd * bi + (wd != 0.0 ? ep.s * bi : 0.0);
+      ops.d = wd / ep.s;                       // store_scalar_ops forms ep.s * (d * .)
+    }
+    store_scalar_ops<EP>(row, acc, y, ep, ops, use_xd, xd[0]);
   }
 }
 
@@ -700,10 +710,18 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   double r = 0.0;
   if (s < n_slices) {
     double bi = 0.0, di = 0.0;
-    if ((nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
-    const double acc = sell_row_dot(M, s, lane, row, b);
+    double xd[2] = {0.0, 0.0};
+    const bool wdiag = M.wdiag && M.diag_first;
+    if (!wdiag && (nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+    double acc = sell_row_dot(M, s, lane, row, b, wdiag ? xd : nullptr);
     if (row < n_rows) {
-      if (!(nt & EPF_HOIST)) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+      if (wdiag) {
+        // diagonal slot = omega*Dinv_i (no dinv stream, b_i from the gather): see sell_spmv_kernel
+        bi = xd[0];
+        const double wd = xd[1];
+        acc = acc - wd * bi + (wd != 0.0 ? omega * bi : 0.0);
+        di = wd / omega;
+      } else if (!(nt & EPF_HOIST)) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
       r = bi - acc;
       double xi = omega * (di * bi);
       if (nt & EPF_FOLD) xi += omega * (di * r);

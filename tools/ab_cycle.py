@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "rsum_sort": {"AMGX_RSUM_SORT": "1"},
+    "no_wdiag": {"AMGX_NO_WDIAG": "1"},
 }
 
 
