@@ -300,7 +300,10 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
 // Windowed SELL, one thread per row: a workgroup owns WB consecutive rows, stored in order of decreasing length
 // (host: upload_matrix), so that the 64 rows of a slice have (nearly) the same length.  The row sums go through LDS
 // back to natural order, so the epilogue's own-row reads and the store stay coalesced.
-constexpr int SELL_WIN = 512;
+#ifndef SELL_WIN_SIZE
+#define SELL_WIN_SIZE 512      // A/B (profiles/r01/unroll_ab.txt): 256 is 2 % slower, 1024 ties
+#endif
+constexpr int SELL_WIN = SELL_WIN_SIZE;
 template <int WB, int EP>
 __global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, SellMat M, const uint16_t* __restrict__ rowloc,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {

@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "no_wdiag": {"AMGX_NO_WDIAG": "1"},
+    "fb256": {"AMGX_FUSED_BLOCK": "256"},
+    "fb1024": {"AMGX_FUSED_BLOCK": "1024"},
 }
 
 
