@@ -339,8 +339,15 @@ class _AMGPreconditioner:
         if "bgs" in types:                                               # BuildBGSSmoother(mat, GetGSBlocks(level)), amg_pc.cpp:1060-1072
             hier.build_bgs()
         clev = str(f.get("clev", "inv")).lower()
+        # per-level overrides of the first levels, like the reference's SpecOpt flags (amg_pc.cpp:1079-1082 GetOpt(level))
+        steps = [int(f.get("sm_steps", 1))] * hier.n_levels
+        for i, v in enumerate(list(f.get("sm_steps_spec") or [])[: hier.n_levels]):
+            steps[i] = int(v)
+        symm = [bool(f.get("sm_symm", False))] * hier.n_levels
+        for i, v in enumerate(list(f.get("sm_symm_spec") or [])[: hier.n_levels]):
+            symm[i] = bool(v)
         dev = DeviceAMGMatrix(hier, sm_type=types, omega=float(f.get("sm_omega", 0.9)),
-                              sm_steps=int(f.get("sm_steps", 1)), sm_symm=bool(f.get("sm_symm", False)),
+                              sm_steps=steps, sm_symm=symm,
                               mg_cycle=str(f.get("mg_cycle", "V")).upper(), clev="inv" if clev == "inv" else "none",
                               device=self._device, use_graph=bool(f.get("use_graph", True)))
         self._amg = AMGMatrix(hier, dev)

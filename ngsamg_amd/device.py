@@ -76,8 +76,8 @@ class DeviceAMGMatrix:
                 raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs | bgs)")
             d.sm_type = _SM[types[i]]
             d.omega = float(omega)
-            d.sm_steps = int(sm_steps)
-            d.sm_symm = int(bool(sm_symm))
+            d.sm_steps = int(sm_steps[i] if isinstance(sm_steps, (list, tuple)) else sm_steps)      # per level: ..._spec flags
+            d.sm_symm = int(bool(sm_symm[i] if isinstance(sm_symm, (list, tuple)) else sm_symm))
             d.color = _lib.ptr(lv.color, C.c_int32)
             d.n_colors = int(lv.n_colors)
             g = getattr(lv, "bgs", None)

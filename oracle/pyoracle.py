@@ -148,8 +148,8 @@ class Oracle:
                         self._keep.append(order)
                         o.block_order = _p(order, C.c_int32)
             o.omega = omega
-            o.sm_steps = int(sm_steps)
-            o.sm_symm = int(bool(sm_symm))
+            o.sm_steps = int(sm_steps[i] if isinstance(sm_steps, (list, tuple)) else sm_steps)
+            o.sm_symm = int(bool(sm_symm[i] if isinstance(sm_symm, (list, tuple)) else sm_symm))
             if t == "gs_mc":
                 order = color_order(lv.color)
                 self._keep.append(order)

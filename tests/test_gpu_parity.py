@@ -503,3 +503,22 @@ def test_standalone_block_smoother():
     xg, rg = x0.copy(), np.zeros(p.n)
     sm.Smooth(xg, b, rg, False, True, False)
     assert _rel(xg, xo) < 1e-10 and _rel(rg, ro) < 1e-9
+
+
+def test_per_level_smoother_specification():
+    """reference example examples/elasticity/simple.py: 2 x block GS on the coarse levels, 1 x GS on level 0
+    (ngs_amg_sm_type_spec / ngs_amg_sm_steps_spec): mixed smoother kinds and step counts per level"""
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    p, H = elasticity_case((9, 8, 7), False, 5, 0.12)
+    bgs = H.build_bgs()
+    L = H.n_levels
+    types_dev = ["gs"] + ["bgs"] * (L - 1)
+    types_orc = ["gs_mc"] + ["bgs_mc"] * (L - 1)
+    steps = [1] + [2] * (L - 1)
+    b = rhs(p, 7)
+    dev = _dev(H, sm_type=types_dev, sm_steps=steps)
+    x = np.empty(b.size)
+    dev.Mult(b, x)
+    ref = Oracle(H.levels, sm_type=types_orc, sm_steps=steps, bgs=bgs).apply(b)
+    assert _rel(x, ref) < 1e-10
