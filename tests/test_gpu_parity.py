@@ -522,3 +522,37 @@ def test_per_level_smoother_specification():
     dev.Mult(b, x)
     ref = Oracle(H.levels, sm_type=types_orc, sm_steps=steps, bgs=bgs).apply(b)
     assert _rel(x, ref) < 1e-10
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_randomised_shapes_all_paths(seed, monkeypatch):
+    """small random grids (odd / prime extents, random Dirichlet faces, random coarse sizes) through every smoother and
+    cycle, once with the default format choices and once with the one-thread-per-row kernels forced (fused down step,
+    windowed Q, diagonal slot tricks) -- partial last slices / windows / chunks, 1-entry rows, tiny coarsest levels"""
+    from oracle.pyoracle import Oracle
+    rng = np.random.default_rng(100 + seed)
+    faces = ["left", "right", "top", "bottom", "front", "back"]
+    for case in range(3):
+        dim = int(rng.integers(2, 4))
+        shape = tuple(int(v) for v in rng.choice([5, 7, 9, 11, 13, 17, 19, 23], size=dim))
+        if dim == 2:
+            shape = tuple(3 * v for v in shape)
+        diri = "|".join(rng.choice(faces[: 2 * dim], size=int(rng.integers(1, 3)), replace=False))
+        mcs = int(rng.integers(3, 30))
+        p, H = poisson_case(shape, diri, mcs)
+        if H.n_levels < 2:
+            continue
+        bgs = H.build_bgs()
+        b = rhs(p, int(rng.integers(0, 1000)))
+        for env in ({}, {"AMGX_SELL_MAX_LANES": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for sm, osm, tol in (("jacobi", "jacobi", 1e-12), ("gs", "gs_mc", 1e-10), ("bgs", "bgs_mc", 1e-10)):
+                for cyc in ("V", "W", "BS"):
+                    dev = _dev(H, sm_type=sm, mg_cycle=cyc)
+                    x = np.full(p.n, np.nan)
+                    dev.Mult(b, x)
+                    ref = Oracle(H.levels, sm_type=osm, cycle=cyc, bgs=bgs).apply(b)
+                    assert _rel(x, ref) < tol, (shape, diri, mcs, env, sm, cyc)
+            for k in env:
+                monkeypatch.delenv(k)
