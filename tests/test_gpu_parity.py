@@ -556,3 +556,30 @@ def test_randomised_shapes_all_paths(seed, monkeypatch):
                     assert _rel(x, ref) < tol, (shape, diri, mcs, env, sm, cyc)
             for k in env:
                 monkeypatch.delenv(k)
+
+
+def test_cycle_down_up_stage_calls_compose_to_the_cycle():
+    """amgx_cycle_down / amgx_cycle_up (the stage form of the folded V-cycle, used by the rank-partitioned path) with HOST
+    vectors on a square hierarchy: down on every level, exact coarse solve, up on every level == amgx_apply"""
+    p, H = poisson_case((15, 14, 13), "right|top", 20)
+    dev = _dev(H, sm_type="jacobi")
+    L = H.n_levels
+    assert all(dev.is_folded(l) for l in range(L - 1))
+    b = rhs(p, 9)
+    bs, xs = [b], []
+    for l in range(L - 1):
+        x = np.full(dev.sizes[l], np.nan)
+        bc = np.full(dev.sizes[l + 1], np.nan)
+        dev.CycleDown(l, bs[l], x, bc)
+        xs.append(x)
+        bs.append(bc)
+    xc = np.empty(dev.sizes[L - 1])
+    dev.CoarseSolve(bs[L - 1], xc)
+    for l in range(L - 2, -1, -1):
+        dev.CycleUp(l, xs[l], xc)
+        xc = xs[l]
+    ref = np.empty(p.n)
+    dev.Mult(b, ref)
+    assert _rel(xc, ref) < 1e-14
+    with pytest.raises(Exception):
+        _dev(H, sm_type="gs").CycleDown(0, b, np.empty(p.n), np.empty(dev.sizes[1]))      # not a folded Jacobi level
