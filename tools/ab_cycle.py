@@ -10,8 +10,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "default": {},
-    "fb256": {"AMGX_FUSED_BLOCK": "256"},
-    "fb1024": {"AMGX_FUSED_BLOCK": "1024"},
+    "no_fold": {"AMGX_NO_FOLD": "1"},         # edit this table for the experiment at hand (DESIGN.md 5.6 lists the switches)
 }
 
 
