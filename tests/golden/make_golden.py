@@ -85,6 +85,26 @@ def main():
             d[f"{sm}_V_symm2"] = Oracle(H.levels, sm_type=sm, sm_steps=2, sm_symm=True).apply(b)
             _, it, errs = orc.pcg(p.load, tol=1e-8, maxit=100)
             d[f"{sm}_pcg_errs"] = errs
+        # block Gauss-Seidel over the aggregates (reference BSmoother): block tables, inverted diagonal blocks, block
+        # colours of every smoothed level + the same stage / cycle vectors ("bgs" natural, "bgs_mc" colour-major order)
+        bgs = H.build_bgs()
+        for l, g in enumerate(bgs[:-1]):
+            d[f"l{l}_bgs_block_ptr"] = g.block_ptr.copy()
+            d[f"l{l}_bgs_block_rows"] = g.block_rows.copy()
+            d[f"l{l}_bgs_dinv_ptr"] = g.dinv_ptr.copy()
+            d[f"l{l}_bgs_dinv"] = g.dinv[: int(g.dinv_ptr[-1])].copy()
+            d[f"l{l}_bgs_color"] = g.color.copy()
+        for sm in ("bgs", "bgs_mc"):
+            orc = Oracle(H.levels, sm_type=sm, bgs=bgs)
+            x = np.zeros_like(b)
+            r = b.copy()
+            orc.smooth(0, x, b, r, True, True, True)
+            d[f"{sm}_x_pre"] = x.copy()
+            d[f"{sm}_r_pre"] = r.copy()
+            d[f"{sm}_V"] = orc.apply(b)
+            d[f"{sm}_W"] = Oracle(H.levels, sm_type=sm, cycle="W", bgs=bgs).apply(b)
+            _, it, errs = orc.pcg(p.load, tol=1e-8, maxit=100)
+            d[f"{sm}_pcg_errs"] = errs
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
         print(name, "levels", H.n_levels, "n", p.n, "bs", p.bs)
 

@@ -29,6 +29,13 @@ def load(name):
                                       coords=None, agg=None))
         levels[-1].n = levels[-1].A.n_rows
         levels[-1].bs = levels[-1].A.br
+        levels[-1].bgs = None
+        if f"l{l}_bgs_block_ptr" in z:
+            from ngsamg_amd.hierarchy import BGSData
+            col = z[f"l{l}_bgs_color"]
+            levels[-1].bgs = BGSData(int(col.size), z[f"l{l}_bgs_block_ptr"], z[f"l{l}_bgs_block_rows"], z[f"l{l}_bgs_dinv_ptr"],
+                                     np.ascontiguousarray(z[f"l{l}_bgs_dinv"]) if z[f"l{l}_bgs_dinv"].size else np.zeros(1),
+                                     col, int(col.max()) + 1 if col.size else 0)
     return z, levels
 
 

@@ -30,6 +30,23 @@ def test_oracle_reproduces_golden(name, sm):
     assert np.linalg.norm(got - z[f"{sm}_V_symm2"]) <= 1e-13 * np.linalg.norm(z[f"{sm}_V_symm2"])
 
 
+@pytest.mark.parametrize("name", golden_io.NAMES)
+@pytest.mark.parametrize("sm", ["bgs", "bgs_mc"])
+def test_oracle_block_gs_reproduces_golden(name, sm):
+    """block Gauss-Seidel pins: block tables and inverses come from the fixture, not from a fresh setup"""
+    z, levels = golden_io.load(name)
+    b = z["b"]
+    bgs = [L.bgs for L in levels]
+    orc = Oracle(levels, sm_type=sm, bgs=bgs)
+    x, r = np.zeros_like(b), b.copy()
+    orc.smooth(0, x, b, r, True, True, True)
+    assert np.allclose(x, z[f"{sm}_x_pre"], rtol=0, atol=1e-13 * np.abs(z[f"{sm}_x_pre"]).max())
+    assert np.allclose(r, z[f"{sm}_r_pre"], rtol=0, atol=1e-13 * np.abs(b).max())
+    for cyc in ("V", "W"):
+        got = Oracle(levels, sm_type=sm, cycle=cyc, bgs=bgs).apply(b)
+        assert np.linalg.norm(got - z[f"{sm}_{cyc}"]) <= 1e-13 * np.linalg.norm(z[f"{sm}_{cyc}"])
+
+
 @pytest.mark.parametrize("sm", ["jacobi", "gs", "gs_mc"])
 @pytest.mark.parametrize("cycle", ["V", "W"])
 def test_preconditioner_is_symmetric(sm, cycle):
