@@ -70,6 +70,7 @@ def main():
         rng = np.random.default_rng(0)
         b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
         d["b"] = b
+        d["load"] = np.asarray(p.load, dtype=np.float64).copy()      # right-hand side of the PCG histories below
         for sm in ("jacobi", "gs", "gs_mc"):
             orc = Oracle(H.levels, sm_type=sm)
             x = np.zeros_like(b)

@@ -589,3 +589,22 @@ def test_cycle_down_up_stage_calls_compose_to_the_cycle():
     assert _rel(xc, ref) < 1e-14
     with pytest.raises(Exception):
         _dev(H, sm_type="gs").CycleDown(0, b, np.empty(p.n), np.empty(dev.sizes[1]))      # not a folded Jacobi level
+
+
+@pytest.mark.parametrize("name", ["poisson2d_17", "poisson3d_9", "elast3d_4_bs3", "elast3d_4_bs6"])
+@pytest.mark.parametrize("sm,osm", [("jacobi", "jacobi"), ("gs", "gs_mc"), ("bgs", "bgs_mc")])
+def test_gpu_pcg_history_matches_golden_fixture(name, sm, osm):
+    """device-resident PCG with the HIP preconditioner against the fixture's residual history: same iteration count,
+    err_k within 1e-6 relative while the iteration is far from stagnation"""
+    import torch
+    from tests import golden_io
+    from ngsamg_amd.krylov import CGSolver
+    z, levels = golden_io.load(name)
+    H = golden_io.FixtureHierarchy(levels)
+    dev = _dev(H, sm_type=sm)
+    ref = z[f"{osm}_pcg_errs"]
+    cg = CGSolver(dev, dev, tol=1e-8, maxsteps=100)
+    cg.Solve(torch.from_numpy(np.ascontiguousarray(z["load"])).cuda())
+    assert abs(cg.iterations + 1 - ref.size) <= 1
+    m = min(len(cg.errors), ref.size, 6)
+    assert np.allclose(cg.errors[:m], ref[:m], rtol=1e-6)

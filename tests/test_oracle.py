@@ -31,6 +31,18 @@ def test_oracle_reproduces_golden(name, sm):
 
 
 @pytest.mark.parametrize("name", golden_io.NAMES)
+@pytest.mark.parametrize("sm", ["jacobi", "gs", "gs_mc", "bgs", "bgs_mc"])
+def test_oracle_pcg_history_reproduces_golden(name, sm):
+    """PCG residual histories (err_k = sqrt(<C r_k, r_k>), tol 1e-8) pinned per smoother kind"""
+    z, levels = golden_io.load(name)
+    orc = Oracle(levels, sm_type=sm, bgs=[L.bgs for L in levels])
+    _, it, errs = orc.pcg(z["load"], tol=1e-8, maxit=100)
+    ref = z[f"{sm}_pcg_errs"]
+    assert it + 1 == ref.size
+    assert np.allclose(errs, ref, rtol=1e-7, atol=1e-9 * ref[0])     # late iterates amplify rounding differences
+
+
+@pytest.mark.parametrize("name", golden_io.NAMES)
 @pytest.mark.parametrize("sm", ["bgs", "bgs_mc"])
 def test_oracle_block_gs_reproduces_golden(name, sm):
     """block Gauss-Seidel pins: block tables and inverses come from the fixture, not from a fresh setup"""
