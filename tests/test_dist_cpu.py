@@ -122,3 +122,65 @@ def test_two_gloo_processes_match_serial_oracle():
     for p in procs:
         assert p.exitcode == 0
     assert q.get(timeout=10) < 1e-12
+
+
+# ---- committed fixtures of the hybrid smoothers on synthetic partitions (tests/golden/make_golden_hybrid.py) ---------------
+
+HYBRID_CASES = {"hybrid_poisson2d_2x2": dict(R=4, box=(9, 9), dim=2, dmin=30),
+                "hybrid_poisson3d_2x2x2": dict(R=8, box=(5, 5, 5), dim=3, dmin=20)}
+
+
+def _hybrid_fixture(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(HYBRID_CASES))
+@pytest.mark.parametrize("sm,tol", [("jacobi", 1e-12), ("gs", 1e-10), ("bgs", 1e-10)])
+def test_distributed_setup_and_cycle_reproduce_hybrid_fixture(name, sm, tol):
+    """partition, distributed coarsening, halo tables and the stage sequence are pinned: a fresh loopback run gives the
+    fixture's V-cycle vector"""
+    z = _hybrid_fixture(name)
+    c = HYBRID_CASES[name]
+    comm = D.LoopbackComm(c["R"])
+    pg = D.proc_grid(c["R"], c["dim"])
+    states = [D.assemble_poisson_owned(r, pg, c["box"]) for r in range(c["R"])]
+    assert np.array_equal([s.n for s in states], z["rank_sizes"])
+    amg = D.DistributedAMG(comm, states, dim=c["dim"], dist_min_rows=c["dmin"], backend=cpu_backend(sm_type=sm),
+                           max_coarse_size=10, sm_type=sm)
+    assert amg.k == int(z[f"{sm}_k"])
+    off = np.concatenate([[0], np.cumsum(z["rank_sizes"])])
+    bs = [torch.from_numpy(z["b"][off[r]:off[r + 1]].copy()) for r in range(c["R"])]
+    xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
+    amg.Mult(bs, xs)
+    got = np.concatenate([x.numpy() for x in xs])
+    ref = z[f"{sm}_V"]
+    assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("name", sorted(HYBRID_CASES))
+def test_serial_hybrid_gs_oracle_reproduces_fixture_from_stored_arrays(name):
+    """the oracle's serial hybrid Gauss-Seidel on the STORED global hierarchy (matrices, modified diagonals, rank of
+    every row, visiting order) -- no setup code involved"""
+    from types import SimpleNamespace
+    from ngsamg_amd._lib import Matrix
+    z = _hybrid_fixture(name)
+    nl, k = int(z["n_levels"]), int(z["gs_k"])
+
+    def mat(l, tag):
+        key = f"l{l}_{tag}_shape"
+        if key not in z:
+            return None
+        nr, nc, br, bc = (int(v) for v in z[key])
+        return Matrix(nr, nc, br, bc, z[f"l{l}_{tag}_rowptr"], z[f"l{l}_{tag}_col"], z[f"l{l}_{tag}_val"])
+
+    levels = []
+    for l in range(nl):
+        L = SimpleNamespace(A=mat(l, "A"), P=mat(l, "P"), PT=mat(l, "PT"), free=z[f"l{l}_free"], dinv=z[f"l{l}_dinv"],
+                            color=z[f"l{l}_color"], coords=None, agg=None)
+        if l < k:
+            L.dinv, L.gs_order, L.gs_block = z[f"gs_l{l}_dinv"], z[f"gs_l{l}_gs_order"], z[f"gs_l{l}_gs_block"]
+        levels.append(L)
+    # (the replicated tail levels carry the colours of the host setup: 'gs_mc' uses them)
+    got = Oracle(levels, sm_type=["gs_order"] * k + ["gs_mc"] * (nl - k)).apply(z["b"])
+    assert np.linalg.norm(got - z["gs_V"]) <= 1e-12 * np.linalg.norm(z["gs_V"])
