@@ -28,7 +28,8 @@ def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
 
 
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (12, 12, 12), 3, 100), (4, (10, 10, 10), 3, 50), (8, (8, 8, 8), 3, 20),
-                                            (4, (24, 24), 2, 50), (2, (12, 12, 12), 3, 10 ** 9)])
+                                            (4, (24, 24), 2, 50), (2, (12, 12, 12), 3, 10 ** 9),
+                                            (5, (6, 8, 8), 3, 50), (6, (7, 6, 8), 3, 50)])   # the reference runs NP = 2 and 5
 @pytest.mark.parametrize("fold", [True, False])
 def test_loopback_matches_serial_oracle(R, box, dim, dmin, fold):
     """fold = True: stages as the single-GPU cycle runs them (z = S(S0 b) on the way down, x = z + Q x_c on the way up);
