@@ -1,18 +1,22 @@
 // Hand-written HIP kernels (gfx950 / CDNA4, wave64) for the AMG apply path.
 //
-// Every kernel here is HBM-bound (arithmetic intensity <= 0.25 flop/B): the design rules are
-// coalesced 16-B/lane streaming of the matrix, gathers of x served by the XCD-local L2, and enough
-// independent loads in flight per wave.  No MFMA: SpMV with a single right-hand side is not a contraction.
+// Every kernel here is HBM-bound in the roofline sense (arithmetic intensity <= 0.25 flop/B).  Design
+// rules, in the order they turned out to matter on MI355X: coalesced 16-B/lane streaming of the matrix;
+// few, SMALL batches of loads in flight per wave with the next batch requested before the current one is consumed
+// (rows are short: a wave lives for only a few memory round trips, and bursts of gathers stall the CU's address path);
+// own-row epilogue operands requested ahead of the row product; gathers of x served by L2 / Infinity Cache.
+// No MFMA: SpMV with a single right-hand side is not a contraction.
 //
 // Matrix formats on the device (built once at amgx_create, see amgx.hip):
-//   SELL-64-pair ("sliced ELL"): slices of 64 consecutive rows = one wavefront; inside a slice the entries
-//       are stored column-major in PAIRS, so lane r reads a double2 (values j, j+1 of its row) and an int2
-//       (their columns): 16 B + 8 B per lane per step, perfectly coalesced (1 KiB + 512 B per wave
-//       instruction).  An odd trailing column is stored as singles.  Used for matrices with near-uniform
-//       row length (FEM level matrices, prolongations).
-//   CSR-vector: G = 2..64 lanes cooperate on one row, wave-level shuffle reduction.  Used for irregular /
-//       long rows (P^T, coarse level matrices) and for all block (3x3, 6x6, 3x6, 6x3) matrices.
-//   colour-major SELL copy of A for multicolour Gauss-Seidel (slices never cross a colour).
+//   SELL-64-pair ("sliced ELL"), G lanes per row: slices of 64/G consecutive rows = one wavefront; inside a slice the
+//       entries are stored column-major in PAIRS, so a lane reads a double2 (two values of its row) and their packed
+//       16-bit (or 32-bit) columns per step: perfectly coalesced 1 KiB + 256 B per wave instruction.  An odd trailing
+//       column is stored as singles.  Variants: diagonal-first rows, omega*Dinv in the diagonal slot of the
+//       pre-smoothing image, length-sorted 512-row windows for ragged rows (sell_win_spmv_kernel).
+//   BSELL: the same idea for square bs x bs block matrices, one lane per scalar row of a block row.
+//   CSR-vector / block CSR row-per-lane: irregular or long rows (P^T of block levels, rectangular transfer blocks).
+//   colour-major SELL copy of A for multicolour Gauss-Seidel (slices never cross a colour); aggregate blocks with dense
+//       inverses for block Gauss-Seidel (bgs_block_kernel).
 //
 // blockIdx -> row-block mapping: measured on MI355X (profiles/r01/spmv_lab_round*.log), an XCD-aware remap
 // (each XCD walking one contiguous eighth of the rows) is 5-6 % SLOWER than the natural round-robin order
