@@ -138,7 +138,14 @@ def main():
     if world > 1:
         # the host setup is OpenMP-parallel: share the box's cores between the ranks.  torch.distributed.run exports
         # OMP_NUM_THREADS=1 to its children, which would make the (untimed) setup of a 10M-DOF box take minutes.
-        os.environ["OMP_NUM_THREADS"] = os.environ.get("NGSAMG_OMP_THREADS", str(max(1, min(32, (os.cpu_count() or 8) // world))))
+        cpus = os.cpu_count() or 8
+        try:                                       # a container's CPU share (cgroup v2), if it is smaller than the box
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                cpus = max(1, min(cpus, int(q) // int(per)))
+        except (OSError, ValueError):
+            pass
+        os.environ["OMP_NUM_THREADS"] = os.environ.get("NGSAMG_OMP_THREADS", str(max(1, min(32, cpus // world))))
     import torch
     import __graft_entry__ as ge
     if local_rank == 0:
