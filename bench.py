@@ -135,16 +135,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        # the host setup is OpenMP-parallel: share the box's cores between the ranks.  torch.distributed.run exports
-        # OMP_NUM_THREADS=1 to its children, which would make the (untimed) setup of a 10M-DOF box take minutes.
-        cpus = os.cpu_count() or 8
-        try:                                       # a container's CPU share (cgroup v2), if it is smaller than the box
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if q != "max":
-                cpus = max(1, min(cpus, int(q) // int(per)))
-        except (OSError, ValueError):
-            pass
+    # the host setup is OpenMP-parallel: share the box's cores (or the container's CPU share, cgroup v2) between the ranks.
+    # torch.distributed.run exports OMP_NUM_THREADS=1 to its children, which would make the (untimed) setup of a 10M-DOF
+    # box take minutes; without any setting OpenMP would start one thread per visible core of the whole machine.
+    cpus = os.cpu_count() or 8
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cpus = max(1, min(cpus, int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    if world > 1 or "OMP_NUM_THREADS" not in os.environ:
         os.environ["OMP_NUM_THREADS"] = os.environ.get("NGSAMG_OMP_THREADS", str(max(1, min(32, cpus // world))))
     import torch
     import __graft_entry__ as ge
