@@ -107,3 +107,16 @@ def test_loopback_device_reproduces_hybrid_fixture(name, R, box, dim, dmin, sm, 
     got = np.concatenate([x.cpu().numpy() for x in xs])
     ref = z[f"{sm}_V"]
     assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref)
+
+
+def test_rccl_point_to_point_self_loop():
+    """the RCCL branch of TorchComm.halo (batch_isend_irecv on device tensors, stream-ordered wait) on ONE GPU: world size
+    1, the rank sends to and receives from itself; run in a child process (its own process group)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selfloop.py")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "correct = True" in r.stdout
