@@ -75,6 +75,11 @@ class LoopbackComm:
         pass
 
 
+def compaction_index(counts, m):
+    """positions of the valid entries in an all-gather of pieces padded to length m (piece r holds counts[r] entries)"""
+    return np.concatenate([r * m + np.arange(c) for r, c in enumerate(counts)]).astype(np.int64)
+
+
 class TorchComm:
     """One rank per process; host payloads travel over a gloo group, device halos over the default (nccl) group."""
 
@@ -164,10 +169,12 @@ class TorchComm:
             p = pad
         buf = torch.empty(m * self.size, dtype=p.dtype, device=p.device)
         dist.all_gather_into_tensor(buf, p, group=self.device_group)
-        off = 0
-        for r in range(self.size):
-            outs[0][off:off + counts[r]].copy_(buf[r * m:r * m + counts[r]])
-            off += counts[r]
+        # compact the padded pieces with ONE gather (index cached per layout) instead of one copy kernel per rank
+        key = (tuple(counts), str(p.device))
+        cache = self.__dict__.setdefault("_ag_index", {})
+        if key not in cache:
+            cache[key] = torch.from_numpy(compaction_index(counts, m)).to(p.device)
+        torch.index_select(buf, 0, cache[key], out=outs[0])
 
     def barrier(self):
         self.dist.barrier()

@@ -185,3 +185,14 @@ def test_serial_hybrid_gs_oracle_reproduces_fixture_from_stored_arrays(name):
     # (the replicated tail levels carry the colours of the host setup: 'gs_mc' uses them)
     got = Oracle(levels, sm_type=["gs_order"] * k + ["gs_mc"] * (nl - k)).apply(z["b"])
     assert np.linalg.norm(got - z["gs_V"]) <= 1e-12 * np.linalg.norm(z["gs_V"])
+
+
+def test_allgather_compaction_index():
+    """the RCCL all-gather works on pieces padded to the longest one; one gather with this index removes the padding"""
+    counts = [5, 3, 0, 4]
+    m = max(counts)
+    pieces = [np.arange(c) + 10 * r for r, c in enumerate(counts)]
+    buf = np.full(m * len(counts), -1.0)
+    for r, pc in enumerate(pieces):
+        buf[r * m:r * m + pc.size] = pc
+    assert np.array_equal(buf[D.compaction_index(counts, m)], np.concatenate(pieces))
