@@ -42,7 +42,10 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     from ngsamg_amd.device import matrix_bytes, vcycle_bytes
     t0 = time.time()
     comm = D.TorchComm()
-    pg = D.proc_grid(world, 3)
+    # slabs along the slowest axis: every rank keeps a full nv^3 box (weak scaling) and has at most 2 neighbours with one
+    # nv^2 face each, instead of up to 7 neighbours (3 faces + 3 edges + 1 corner) in a 2 x 2 x 2 arrangement: fewer and
+    # smaller point-to-point messages per halo exchange, fewer ghost columns
+    pg = (world, 1, 1)
     st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
     t1 = time.time()
     amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10)
@@ -103,7 +106,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cfg4-style weak scaling of cfg2: global grid {tuple(pg[d] * nv for d in range(3))} = "
                                    f"{world} x {nv}^3 vertices, hashed jitter (seed 1), Dirichlet right|top, jacobi omega=0.9, V(1,1)",
-                       "parallelism": f"{world} ranks, box partition {pg}, {amg.k} rank-partitioned levels with halo exchange "
+                       "parallelism": f"{world} ranks, slab partition {pg} (<= 2 neighbours per rank), {amg.k} rank-partitioned levels with halo exchange "
                                       f"(torch.distributed {dist.get_backend()}), coarse hierarchy replicated from n = {amg.tail_hier.levels[0].n}; "
                                       f"one apply = one V-cycle over one rank's share, value = ranks x steps / time",
                        "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(world * st.n)},
