@@ -927,18 +927,39 @@ __global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int
                                                        const double* __restrict__ dinv, const double* __restrict__ b, double* x) {
   __shared__ double hr[BGS_MAX_M];
   __shared__ double part[TH];
+  constexpr int DMAX = 16;                                  // entries of the inverse a thread keeps in registers
   const int k = blocklist[list_begin + blockIdx.x];
   const int p0 = block_ptr[k];
   const int M = (block_ptr[k + 1] - p0) * BS;
+  const double* __restrict__ D = dinv + dinv_ptr[k];
+  // A block is a chain of dependent round trips (block table -> rows -> row pointers -> entries -> gathers -> inverse ->
+  // x); everything that does not depend on the row products is requested up front: this thread's slice of the inverse
+  // and the old x value of its output row.
+  const bool fits = M <= TH;
+  const int S = fits ? TH / M : 1;                          // slices of the column range of the inverse
+  const int di = fits ? threadIdx.x % M : 0, dsl = fits ? threadIdx.x / M : S;
+  const bool dreg_ok = fits && (M + S - 1) / S <= DMAX;
+  double dreg[DMAX];
+  double xold = 0.0;
+  int64_t xrow = 0;
+  if (dreg_ok) {
+    if (dsl < S) {
+#pragma unroll
+      for (int q = 0; q < DMAX; ++q) { const int jj = dsl + q * S; dreg[q] = jj < M ? D[(int64_t)jj * M + di] : 0.0; }
+    }
+    if (threadIdx.x < M) {
+      xrow = (int64_t)block_rows[p0 + threadIdx.x / BS] * BS + threadIdx.x % BS;
+      xold = x[xrow];                                       // x_B is not written before the barrier below
+    }
+  }
   const int sub = threadIdx.x % G;
   for (int t0 = 0; t0 < M; t0 += TH / G) {             // trip count is workgroup-uniform: shuffles are safe
     const int t = t0 + threadIdx.x / G;
-    double acc = 0.0;
-    int64_t row = 0;
-    int rr = 0;
+    double acc = 0.0, bv = 0.0;
     if (t < M) {
-      row = block_rows[p0 + t / BS];
-      rr = t % BS;
+      const int64_t row = block_rows[p0 + t / BS];
+      const int rr = t % BS;
+      if (sub == 0) bv = b[row * BS + rr];
       const int e = rowptr[row + 1];
 #pragma unroll 4
       for (int p = rowptr[row] + sub; p < e; p += G) {
@@ -950,31 +971,36 @@ __global__ __launch_bounds__(TH) void bgs_block_kernel(int list_begin, const int
     }
 #pragma unroll
     for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
-    if (t < M && sub == 0) hr[t] = b[row * BS + rr] - acc;
+    if (t < M && sub == 0) hr[t] = bv - acc;
   }
   __syncthreads();
-  const double* __restrict__ D = dinv + dinv_ptr[k];
-  if (M <= TH) {
-    const int S = TH / M;                                   // slices of the column range
-    const int i = threadIdx.x % M, sl = threadIdx.x / M;
+  if (fits) {
     double u = 0.0;
-    if (sl < S) {
+    if (dsl < S) {
+      if (dreg_ok) {
+#pragma unroll
+        for (int q = 0; q < DMAX; ++q) { const int jj = dsl + q * S; if (jj < M) u += dreg[q] * hr[jj]; }
+      } else {
 #pragma unroll 8
-      for (int j = sl; j < M; j += S) u += D[(int64_t)j * M + i] * hr[j];
+        for (int jj = dsl; jj < M; jj += S) u += D[(int64_t)jj * M + di] * hr[jj];
+      }
     }
     part[threadIdx.x] = u;
     __syncthreads();
     if (threadIdx.x < M) {
       double tot = 0.0;
       for (int q = 0; q < S; ++q) tot += part[q * M + threadIdx.x];      // fixed order: deterministic
-      const int64_t row = block_rows[p0 + threadIdx.x / BS];
-      x[row * BS + threadIdx.x % BS] += tot;                // x_B is only read in the first phase, which is complete
+      if (dreg_ok) x[xrow] = xold + tot;
+      else {
+        const int64_t row = block_rows[p0 + threadIdx.x / BS];
+        x[row * BS + threadIdx.x % BS] += tot;              // x_B is only read in the first phase, which is complete
+      }
     }
   } else {
     for (int i = threadIdx.x; i < M; i += TH) {
       double u = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < M; ++j) u += D[(int64_t)j * M + i] * hr[j];
+      for (int jj = 0; jj < M; ++jj) u += D[(int64_t)jj * M + i] * hr[jj];
       const int64_t row = block_rows[p0 + i / BS];
       x[row * BS + i % BS] += u;
     }
