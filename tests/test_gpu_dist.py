@@ -120,3 +120,31 @@ def test_rccl_point_to_point_self_loop():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selfloop.py")], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "correct = True" in r.stdout
+
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (3, (20, 9, 9), 3, 100)])
+def test_loopback_device_fused_kernels_on_rank_partitioned_levels(R, box, dim, dmin, monkeypatch):
+    """the production shape of the multi-GPU run: level 0 in the one-thread-per-row form, i.e. the FUSED down kernel
+    (pre-smoothing + chunk-local restriction, omega*Dinv in the diagonal slot) and the windowed Q kernel on matrices WITH
+    ghost columns -- forced onto small levels"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_SELL_MAX_LANES", "1")
+    comm = D.LoopbackComm(R)
+    pg = (R, 1, 1) if R == 3 else D.proc_grid(R, dim)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10)
+    top = amg.ops[0].top
+    assert top.matrix_info(0, "Apre")["lanes"] == 1 and top.matrix_info(0, "Q")["fmt"] is not None
+    assert top.time_op(0, 7, reps=2) > 0            # the fused kernel exists on the rank-partitioned level 0
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    ref = Oracle(amg.global_levels(), sm_type="jacobi").apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
