@@ -170,8 +170,89 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *   op = 4: one whole cycle (amgx_apply on internal vectors)
  *   op = 5: pre-smoothing + restriction as the V-cycle runs it on this level (fused / folded where built)
  *   op = 6: coarse-grid correction + post-smoothing as the V-cycle runs it on this level
- *   op = 7: sell_pre_restrict_kernel alone (op 5 without the small restrict_sum_kernel); error if the level has none */
+ *   op = 7: sell_pre_restrict_kernel alone (op 5 without the small restrict_sum_kernel); error if the level has none
+ *   op = 8: the same kernel timed INSIDE the cycle: `reps` whole cycles are launched directly (no graph) with HIP events
+ *           around that one kernel; the average is what rocprofv3 --kernel-trace reports for it (roofline.achieved) */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Rank-partitioned hierarchies (one process per GPU; SURVEY.md 8b "halo tables + RCCL communicator", 8e).
+ *
+ * What the reference does with MPI -- every rank of the communicator calls AMGMatrix::Mult collectively
+ * (src/base/solve/amg_matrix.cpp:160-307), smoothers exchange halos through DCCMap (src/base/linalg/dcc_map.cpp:17-302)
+ * around their local stages (src/base/smoothers/hybrid_base_smoother.cpp:501-574) -- is one call here: amgx_dist_apply.
+ * Layout: a rank stores the rows of the vertices it owns, columns [owned | ghost], ghosts grouped by owning rank
+ * (ascending), owned rows ordered [interior | boundary] (interior = no ghost column).  Pack kernels + ncclSend / ncclRecv
+ * run on a communication stream while the interior rows are processed; nothing synchronises the host.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct amgx_comm_t* amgx_comm;
+typedef struct amgx_dist_t* amgx_dist;
+typedef struct amgx_halo_t* amgx_halo;
+enum {
+  AMGX_COMM_RCCL = 0,         /* one rank per process, ncclCommInitRank over xGMI (replaces the MPI communicator)          */
+  AMGX_COMM_LOCAL = 1         /* all n_ranks ranks live in this process on one GPU ("virtual ranks": tests, rehearsal);     */
+                              /*   same kernels, streams and events, device copies instead of ncclSend / ncclRecv           */
+};
+#define AMGX_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: called by rank 0, the caller distributes the 128 bytes (e.g. torch.distributed / MPI_Bcast) */
+int amgx_comm_unique_id(char* id128);
+/* RCCL: collective over all ranks (ncclCommInitRank); LOCAL: rank and id128 are ignored */
+int amgx_comm_create(int kind, int n_ranks, int rank, const char* id128, int device, amgx_comm* out);
+int amgx_comm_destroy(amgx_comm c);                      /* also destroys the hierarchies created on it */
+const char* amgx_comm_last_error(amgx_comm c);           /* c may be NULL for create-time errors        */
+/* compute stream of the communicator (and of every hierarchy on it); NULL = its own stream */
+int amgx_comm_set_stream(amgx_comm c, void* hip_stream);
+int amgx_comm_synchronize(amgx_comm c);
+int amgx_comm_info(amgx_comm c, int32_t* kind, int32_t* n_ranks, int32_t* rank, int64_t* n_exchanges);
+
+/* halo tables of one level = DCCMap's m_ex_dofs / g_ex_dofs (dcc_map.cpp:480-543) in owner-row form */
+typedef struct amgx_halo_desc {
+  int32_t n_peers;
+  const int32_t* peer_rank;   /* [n_peers] ascending (GetDistantProcs)                                              */
+  const int64_t* send_ptr;    /* [n_peers+1]                                                                        */
+  const int32_t* send_idx;    /* owned block rows whose values peer k ghosts (m_ex_dofs[k]), in the order of the     */
+                              /*   peer's ghost segment                                                              */
+  const int64_t* recv_ptr;    /* [n_peers+1] ghost block rows [recv_ptr[k], recv_ptr[k+1]) belong to peer k           */
+                              /*   (g_ex_dofs[k]; contiguous: ghosts are grouped by owner)                           */
+  int64_t n_interior;         /* owned rows [0, n_interior) have no ghost column (split_ind analogue,                 */
+                              /*   gssmoother.cpp:664-678); 0 = no overlap of communication and computation          */
+} amgx_halo_desc;
+
+typedef struct amgx_dist_desc {
+  amgx_hierarchy_desc top;    /* levels 0..k of this rank: A = owned rows x [owned | ghost]; P, PT rank-local; Jacobi   */
+                              /*   levels with fold: Q (columns = coarse [owned | ghost]); dinv / colours / blocks as    */
+                              /*   usual (dinv over n_cols entries for Jacobi); level k: only A (its shape is used)      */
+  const amgx_halo_desc* halo; /* [k] halo tables of the levels 0..k-1                                                    */
+  amgx_hierarchy_desc tail;   /* replicated coarse hierarchy; its level 0 = level k gathered in rank order (CtrMap,      */
+                              /*   src/base/coarsening/dof_contract.cpp:49-223, without the hop back)                    */
+  const int64_t* counts;      /* [n_ranks] owned block rows of level k per rank                                          */
+  const int64_t* kmap;        /* [kmap_len] level-k [owned | ghost] scalar entries -> scalar index in the gathered vector */
+  int64_t kmap_len;
+  int32_t rank;               /* this rank (LOCAL communicators: ranks are created in order 0, 1, ...)                   */
+  int32_t fold;               /* Jacobi: 1 = post-smoothing folded into the prolongation (2k-1 exchanges), 0 = literal   */
+  const int32_t* gs_stage;    /* optional [4*k]: colour ranges of the hybrid Gauss-Seidel stages per level,              */
+                              /*   [s0,s1) first local part, [s1,s2) rows that read ghosts ("EX"), [s2,s3) second local   */
+                              /*   part (gssmoother.cpp:721-782); NULL: one stage                                        */
+} amgx_dist_desc;
+
+int amgx_dist_create(amgx_comm c, const amgx_dist_desc* desc, amgx_dist* out);
+int amgx_dist_destroy(amgx_dist d);
+/* x = C b collectively.  b, x: one pointer per local rank (RCCL: one).  b_status 1 (CUMULATED): b holds the owned entries;
+ * 0 (DISTRIBUTED): b holds [owned | ghost] entries whose ghost part are contributions to the owners, added first
+ * (b.Distribute() state, amg_matrix.cpp:164; DCCMap DIS2CO).  x: owned entries (CUMULATED on the owners).
+ * flags: AMGX_HOST_PTR / AMGX_DEVICE_PTR. */
+int amgx_dist_apply(amgx_comm c, const double* const* b, double* const* x, int b_status, int flags);
+/* the level-0 right-hand-side buffer of a rank ([owned | ghost], device): filling it in place saves the copy of b */
+int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_ext);
+/* borrowed handles of the rank-partitioned levels and of the replicated tail, for queries / measurement only */
+int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail);
+
+/* stand-alone halo map = DCCMap (dcc_map.hpp:20-90): mode 0 owner -> ghost overwrite (StartCO2CU / ApplyCO2CU,
+ * dcc_map.cpp:138-178), mode 1 ghost -> owner add with the ghost entries zeroed (StartDIS2CO / ApplyDIS2CO, :76-136).
+ * vecs: device vectors of (n_owned + n_ghost) * bs entries, ordered on the communicator's stream. */
+int amgx_halo_create(amgx_comm c, const amgx_halo_desc* d, int64_t n_owned, int64_t n_ghost, int32_t bs, int32_t rank, amgx_halo* out);
+int amgx_halo_destroy(amgx_halo h);
+int amgx_halo_exchange(amgx_comm c, int n_local, const amgx_halo* halos, double* const* vecs, int mode);
 
 #ifdef __cplusplus
 }

@@ -197,7 +197,20 @@ class amgx_hierarchy_desc(C.Structure):
                 ("use_graph", C.c_int32)]
 
 
+class amgx_halo_desc(C.Structure):
+    _fields_ = [("n_peers", C.c_int32), ("peer_rank", c_i32p), ("send_ptr", c_i64p), ("send_idx", c_i32p),
+                ("recv_ptr", c_i64p), ("n_interior", C.c_int64)]
+
+
+class amgx_dist_desc(C.Structure):
+    _fields_ = [("top", amgx_hierarchy_desc), ("halo", C.POINTER(amgx_halo_desc)), ("tail", amgx_hierarchy_desc),
+                ("counts", c_i64p), ("kmap", c_i64p), ("kmap_len", C.c_int64), ("rank", C.c_int32), ("fold", C.c_int32),
+                ("gs_stage", c_i32p)]
+
+
 AMGX_SM_JACOBI, AMGX_SM_GS, AMGX_SM_BGS = 0, 1, 2
+AMGX_COMM_RCCL, AMGX_COMM_LOCAL = 0, 1
+AMGX_UNIQUE_ID_BYTES = 128
 AMGX_CYCLE = {"V": 0, "W": 1, "BS": 2}
 AMGX_CLEV_NONE, AMGX_CLEV_INV = 0, 1
 AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
@@ -209,6 +222,9 @@ AMGX_SYMBOLS = [
     "amgx_prolong", "amgx_matvec", "amgx_transfer_f2c",
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op",
+    "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
+    "amgx_comm_synchronize", "amgx_comm_info", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply",
+    "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
 ]
 
 AMGH_SYMBOLS = [
@@ -251,5 +267,22 @@ def hip():
     lib.amgx_matrix_info.argtypes = [vp, C.c_int, C.c_int, c_i32p, c_i64p, c_i32p]
     lib.amgx_matrix_stream_bytes.argtypes = [vp, C.c_int, C.c_int, c_i64p]
     lib.amgx_time_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
+    # rank-partitioned hierarchies
+    lib.amgx_comm_unique_id.argtypes = [C.c_char_p]
+    lib.amgx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.amgx_comm_destroy.argtypes = [vp]
+    lib.amgx_comm_last_error.argtypes = [vp]
+    lib.amgx_comm_last_error.restype = C.c_char_p
+    lib.amgx_comm_set_stream.argtypes = [vp, vp]
+    lib.amgx_comm_synchronize.argtypes = [vp]
+    lib.amgx_comm_info.argtypes = [vp, c_i32p, c_i32p, c_i32p, c_i64p]
+    lib.amgx_dist_create.argtypes = [vp, C.POINTER(amgx_dist_desc), C.POINTER(vp)]
+    lib.amgx_dist_destroy.argtypes = [vp]
+    lib.amgx_dist_apply.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_int, C.c_int]
+    lib.amgx_dist_rhs_buffer.argtypes = [vp, C.POINTER(dp), c_i64p, c_i64p]
+    lib.amgx_dist_handles.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.amgx_halo_create.argtypes = [vp, C.POINTER(amgx_halo_desc), C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.amgx_halo_destroy.argtypes = [vp]
+    lib.amgx_halo_exchange.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(dp), C.c_int]
     _hip = lib
     return lib

@@ -10,6 +10,7 @@
 #include "../../../include/amgx.h"
 #include "kernels.hpp"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <climits>
 #include <cstdint>
@@ -568,6 +569,9 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
 // the handle
 // ---------------------------------------------------------------------------------------------------
 
+enum { PART_ALL = 0, PART_INT = 1, PART_BND = 2 };
+struct Span { int part = PART_ALL; int64_t n_int = 0; };   // see Handle::spmv_ep
+
 struct Handle {
   int device = 0;
   std::vector<DevLevel> lev;
@@ -577,6 +581,9 @@ struct Handle {
   hipStream_t own_stream = nullptr, stream = nullptr;
   bool use_graph = true;
   bool skip_rsum = false;               // amgx_time_op(op 7): time sell_pre_restrict_kernel alone
+  // amgx_time_op(op 8): HIP events around the fused down kernel of `probe_level` INSIDE the cycle (direct launches)
+  int probe_level = -1;
+  hipEvent_t probe_e0 = nullptr, probe_e1 = nullptr;
   int ep_nt = 1;                        // non-temporal epilogue operands (AMGX_NO_EP_NT=1 disables)
   int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
   int tail_ops = 0;
@@ -614,16 +621,35 @@ struct Handle {
   // ------------------------------------------------------------------ primitive ops (all async on `stream`)
   static int grid_for(int64_t threads) { return (int)std::max<int64_t>(1, (threads + BLOCK - 1) / BLOCK); }
 
+  // Part of the rows a launch covers.  Rank-partitioned levels order their owned rows [interior | boundary] (interior =
+  // no ghost column; the analogue of the reference's split_ind stages, gssmoother.cpp:664-678): the interior part runs
+  // while the halo exchange is in flight, the boundary part after it (hybrid_base_smoother.cpp:501-574).  A kernel works
+  // in units of u rows (slice / window / chunk); units that straddle n_int belong to the boundary part.  Formats that
+  // cannot be split run completely in the boundary part (correct, no overlap).
+  using Span = ::amgx::Span;
+  enum { PART_ALL = ::amgx::PART_ALL, PART_INT = ::amgx::PART_INT, PART_BND = ::amgx::PART_BND };
+  static void unit_range(const Span& sp, int64_t u, int64_t n_units, int64_t& a, int64_t& b) {
+    const int64_t split = std::min<int64_t>(n_units, sp.n_int / u);
+    if (sp.part == PART_ALL) { a = 0; b = n_units; }
+    else if (sp.part == PART_INT) { a = 0; b = split; }
+    else { a = split; b = n_units; }
+  }
+
   template <int EP>
-  void spmv_ep(const DevMatrix& M, const double* x, double* y, const EpArgs& ep) {
+  void spmv_ep(const DevMatrix& M, const double* x, double* y, const EpArgs& ep, const Span sp = Span()) {
     if (M.n_rows == 0) return;
     if (M.fmt == FMT_SELL && M.sell.win) {
       if (M.sell.win != SELL_WIN) throw Err("windowed SELL: unexpected window size");
-      const int grid = (int)((M.n_rows + SELL_WIN - 1) / SELL_WIN);
-      hipLaunchKernelGGL((sell_win_spmv_kernel<SELL_WIN, EP>), dim3(grid), dim3(SELL_WIN), 0, stream, M.n_rows, M.sell.view(), M.sell.rowloc.p, x, y, ep);
+      int64_t a, b;
+      unit_range(sp, SELL_WIN, (M.n_rows + SELL_WIN - 1) / SELL_WIN, a, b);
+      if (b > a)
+        hipLaunchKernelGGL((sell_win_spmv_kernel<SELL_WIN, EP>), dim3((int)(b - a)), dim3(SELL_WIN), 0, stream, M.n_rows, (int)a, M.sell.view(), M.sell.rowloc.p, x, y, ep);
     } else if (M.fmt == FMT_SELL) {
-      const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-#define LAUNCH_SELL(G) hipLaunchKernelGGL((sell_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.sell.view(), x, y, ep)
+      int64_t a, b;
+      unit_range(sp, WAVE / M.lanes, M.n_slices, a, b);
+      if (b <= a) return;
+      const int grid = (int)((b - a + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+#define LAUNCH_SELL(G) hipLaunchKernelGGL((sell_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, (int)a, (int)b, M.sell.view(), x, y, ep)
       switch (M.lanes) {
         case 1: LAUNCH_SELL(1); break;
         case 2: LAUNCH_SELL(2); break;
@@ -633,8 +659,11 @@ struct Handle {
       }
 #undef LAUNCH_SELL
     } else if (M.br == 1 && M.bc == 1) {
-      const int grid = grid_for(M.n_rows * M.lanes);
-#define LAUNCH_CSR(G) hipLaunchKernelGGL((csrvec_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
+      int64_t a, b;
+      unit_range(sp, 1, M.n_rows, a, b);
+      if (b <= a) return;
+      const int grid = grid_for((b - a) * M.lanes);
+#define LAUNCH_CSR(G) hipLaunchKernelGGL((csrvec_spmv_kernel<G, EP>), dim3(grid), dim3(BLOCK), 0, stream, a, b, M.rowptr.p, M.col.p, M.val.p, x, y, ep)
       switch (M.lanes) {
         case 2: LAUNCH_CSR(2); break;
         case 4: LAUNCH_CSR(4); break;
@@ -646,6 +675,8 @@ struct Handle {
 #undef LAUNCH_CSR
     } else if constexpr (EP == EP_PRE) {
       throw Err("EP_PRE is only built for scalar matrices");
+    } else if (sp.part == PART_INT) {
+      return;                                   // block formats are not split: everything runs in the boundary part
     } else if (M.fmt == FMT_BSELL) {
       const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
       if (M.br == 6) hipLaunchKernelGGL((bsell_spmv_kernel<6, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
@@ -713,14 +744,14 @@ struct Handle {
     HIPCHK(hipGetLastError());
   }
 
-  void mult(const DevMatrix& M, const double* x, double* y) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr, 0}); }
-  void residual(const DevMatrix& M, const double* x, const double* b, double* r) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr, ep_nt & EPF_HOIST}); }
+  void mult(const DevMatrix& M, const double* x, double* y, const Span sp = Span()) { spmv_ep<EP_MULT>(M, x, y, EpArgs{nullptr, nullptr, nullptr, 0.0, nullptr, 0}, sp); }
+  void residual(const DevMatrix& M, const double* x, const double* b, double* r, const Span sp = Span()) { spmv_ep<EP_RES>(M, x, r, EpArgs{b, nullptr, nullptr, 0.0, nullptr, ep_nt & EPF_HOIST}, sp); }
   // y = yin + s * M x
-  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr, ep_nt & EPF_HOIST}); }
+  void mult_add(const DevMatrix& M, double s, const double* x, const double* yin, double* y, const Span sp = Span()) { spmv_ep<EP_AXPY>(M, x, y, EpArgs{nullptr, yin, nullptr, s, nullptr, ep_nt & EPF_HOIST}, sp); }
   // xout = xin + omega * dinv * (b - A xin)
-  void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout) {
+  void jacobi_fused(const DevLevel& L, const double* xin, const double* b, double* xout, const Span sp = Span()) {
     if (xin == xout) throw Err("jacobi_fused: in-place update is not allowed");
-    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr, ep_nt});
+    spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr, ep_nt}, sp);
   }
 
   void zero(double* v, int64_t n) { if (n) HIPCHK(hipMemsetAsync(v, 0, n * sizeof(double), stream)); }
@@ -751,12 +782,15 @@ struct Handle {
   }
 
   // one multicolour GS sweep (RHS form), forward: colours ascending, backward: descending
-  void gs_sweep(const DevLevel& L, int dir, double* x, const double* b, bool lower_only = false) {
+  // cbeg, cend: only the colours [cbeg, cend) (cend < 0: all) -- the stages of the hybrid smoother on rank-partitioned
+  // levels are colour ranges (dist.hpp)
+  void gs_sweep(const DevLevel& L, int dir, double* x, const double* b, bool lower_only = false, int cbeg = 0, int cend = -1) {
     const DevGS& g = L.gs;
     const DevMatrix::Sell& copy = (lower_only && g.has_split) ? g.lower : g.sell;
     if (g.n_colors == 0 && L.n > 0) throw Err("Gauss-Seidel requested but the level has no colouring");
-    for (int q = 0; q < g.n_colors; ++q) {
-      const int c = dir == 0 ? q : g.n_colors - 1 - q;
+    if (cend < 0 || cend > g.n_colors) cend = g.n_colors;
+    for (int q = cbeg; q < cend; ++q) {
+      const int c = dir == 0 ? q : cend - 1 - (q - cbeg);
       if (L.bs == 1) {
         const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
         if (s1 == s0) continue;
@@ -794,11 +828,12 @@ struct Handle {
   }
 
   // one block Gauss-Seidel sweep: colours of the block graph ascending (forward) or descending (backward)
-  void bgs_sweep(const DevLevel& L, int dir, double* x, const double* b) {
+  void bgs_sweep(const DevLevel& L, int dir, double* x, const double* b, int cbeg = 0, int cend = -1) {
     const DevBGS& g = L.bgs;
     if (g.n_colors == 0 && L.n > 0 && g.block_ptr.n > 1) throw Err("block Gauss-Seidel requested but the level has no block colouring");
-    for (int q = 0; q < g.n_colors; ++q) {
-      const int c = dir == 0 ? q : g.n_colors - 1 - q;
+    if (cend < 0 || cend > g.n_colors) cend = g.n_colors;
+    for (int q = cbeg; q < cend; ++q) {
+      const int c = dir == 0 ? q : cend - 1 - (q - cbeg);
       const int b0 = g.color_ptr[c], b1 = g.color_ptr[c + 1];
       if (b1 == b0) continue;
       // (TH, G): one pass over the block's rows where possible (M * G <= TH), G lanes per row ~ row length / 6
@@ -887,10 +922,12 @@ struct Handle {
 
   // pre-smoothing step of the cycles: x = 0; r = b; Smooth(x, b, r, 1, 1, 1)   (amg_matrix.cpp:193-206)
   // fold (only with folded(L)): x receives z = x + omega*Dinv*r, to be completed by post_smooth(..., fold = true)
-  void pre_smooth(DevLevel& L, double* x, const double* b, double* r, bool fold = false) {
+  void pre_smooth(DevLevel& L, double* x, const double* b, double* r, bool fold = false, const Span sp = Span()) {
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Apre.empty()) {
       // one pass: r = b - A' b, x = omega * Dinv * b   (A' = A * omega*Dinv built at create time)
-      spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x, ep_nt | (fold ? EPF_FOLD : 0)});
+      spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x, ep_nt | (fold ? EPF_FOLD : 0)}, sp);
+    } else if (sp.part == PART_INT) {
+      return;                                  // the other forms are not split: they run completely in the boundary part
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       if (fold && L.bs > 1) {
         // x_pre = omega * Dinv * b into tmp; then ONE pass: r = b - A x_pre and z = x_pre + omega * Dinv * r
@@ -931,40 +968,52 @@ struct Handle {
   }
 
   // pre-smoothing followed by the restriction of the residual (amg_matrix.cpp:193-212), fused where possible
-  void pre_smooth_restrict(int l, double* x, const double* b, double* r, double* b_coarse, bool fold = false) {
+  // sp: interior part = the row-parallel pass over the interior rows only; boundary part = the remaining rows plus
+  // everything that needs all rows (partial-sum reduction / P^T gather)
+  void pre_smooth_restrict(int l, double* x, const double* b, double* r, double* b_coarse, bool fold = false, const Span sp = Span()) {
     DevLevel& L = lev[l];
     if (fold && !folded(L)) throw Err("pre_smooth_restrict: level has no folded prolongation");
     const int epf = ep_nt | (fold ? EPF_FOLD : 0);
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty()) {
       const DevRestrict& R = L.RF;
       const int FB = L.fused_block;
-      const int grid = (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
-      if (grid != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
-      if (FB == 256)
-        hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-      else if (FB == 512)
-        hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-      else
-        hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, L.Apre.n_slices,
-                           L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-      if (!skip_rsum)
+      const int nch = (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
+      if (nch != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
+      int64_t ca, cb;
+      unit_range(sp, FB, nch, ca, cb);
+      const int grid = (int)(cb - ca), c0 = (int)ca;
+      const bool probe = probe_level == l && probe_e0;
+      if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
+      if (grid > 0) {
+        if (FB == 256)
+          hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+        else if (FB == 512)
+          hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+        else
+          hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+      }
+      if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
+      if (!skip_rsum && sp.part != PART_INT)
         hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                            R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
       return;
     }
-    pre_smooth(L, x, b, r, fold);
-    transfer_f2c(l, r, b_coarse);
+    pre_smooth(L, x, b, r, fold, sp);
+    if (sp.part != PART_INT) transfer_f2c(l, r, b_coarse);
   }
 
   // coarse-grid correction + post-smoothing: x += P x_c; SmoothBack(x, b, r, 0, 0, 0)   (amg_matrix.cpp:263-302)
   // fold: x holds z of the folded pre-smoothing pass; x' = z + Q x_c (see fold_prolongation)
-  void post_smooth(int l, double* x, const double* b, double* r, const double* xc, bool fold = false) {
+  void post_smooth(int l, double* x, const double* b, double* r, const double* xc, bool fold = false, const Span sp = Span()) {
     DevLevel& L = lev[l];
     if (fold) {
-      mult_add(L.Q, 1.0, xc, x, x);
+      mult_add(L.Q, 1.0, xc, x, x, sp);
+    } else if (sp.part == PART_INT) {
+      return;                                  // literal forms are driven stage by stage (Dist), not through this function
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
@@ -1975,6 +2024,33 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
         default: throw amgx::Err("amgx_time_op: unknown op");
       }
     };
+    if (op == 8) {
+      // the dominant kernel timed where it runs: inside the cycle, between the previous cycle's last kernel and the
+      // partial-sum reduction (cache state and clocks of the real application), averaged over `reps` cycles
+      if (L.RF.empty() || !(h.plain(L) && L.sm_type == AMGX_SM_JACOBI)) throw amgx::Err("amgx_time_op: level has no fused pre-smoothing + restriction kernel");
+      if (h.stream == nullptr) throw amgx::Err("amgx_time_op: op 8 needs a non-default stream");
+      HIPCHK(hipEventCreate(&h.probe_e0));
+      HIPCHK(hipEventCreate(&h.probe_e1));
+      double tot = 0.0;
+      if (h.lev[0].len()) hipLaunchKernelGGL(amgx::fill_kernel, dim3(amgx::Handle::grid_for(h.lev[0].len())), dim3(amgx::BLOCK), 0, h.stream, h.lev[0].len(), (uint64_t)2, h.lev[0].rhs.p);
+      try {
+        h.do_cycle(h.lev[0].x.p, h.lev[0].rhs.p);              // warm-up
+        h.probe_level = level;
+        for (int i = 0; i < reps; ++i) {
+          h.do_cycle(h.lev[0].x.p, h.lev[0].rhs.p);
+          HIPCHK(hipEventSynchronize(h.probe_e1));
+          float ms = 0;
+          HIPCHK(hipEventElapsedTime(&ms, h.probe_e0, h.probe_e1));
+          tot += ms;
+        }
+      } catch (...) { h.probe_level = -1; (void)hipEventDestroy(h.probe_e0); (void)hipEventDestroy(h.probe_e1); h.probe_e0 = h.probe_e1 = nullptr; throw; }
+      h.probe_level = -1;
+      HIPCHK(hipStreamSynchronize(h.stream));
+      (void)hipEventDestroy(h.probe_e0); (void)hipEventDestroy(h.probe_e1);
+      h.probe_e0 = h.probe_e1 = nullptr;
+      *avg_ms = tot / reps;
+      return;
+    }
     if (op != 4) {   // time on non-trivial data (the work vectors are otherwise zero in device-pointer mode)
       auto fill = [&](double* v, int64_t n, uint64_t seed) {
         if (n) hipLaunchKernelGGL(amgx::fill_kernel, dim3(amgx::Handle::grid_for(n)), dim3(amgx::BLOCK), 0, h.stream, n, seed, v);
@@ -2001,3 +2077,5 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
 }
 
 }  // extern "C"
+
+#include "dist.hpp"

@@ -1,0 +1,706 @@
+// Rank-partitioned levels: communicator, halo exchange and the collective V-cycle (included by amgx.hip).
+//
+// Reference counterparts (not its code):
+//   Comm        <-> the MPI communicator of the ParallelDofs                     (src/base/linalg/dcc_map.hpp:20-90)
+//   HaloTable   <-> DCCMap tables m_ex_dofs / g_ex_dofs + buffers                (dcc_map.cpp:17-65, 480-543)
+//   exchange()  <-> StartCO2CU / ApplyCO2CU (owner -> ghost, overwrite) and StartDIS2CO / ApplyDIS2CO (ghost -> owner,
+//                   add)                                                         (dcc_map.cpp:76-178, 249-302)
+//   Dist::apply <-> AMGMatrix::SmoothV called collectively by every rank        (src/base/solve/amg_matrix.cpp:160-307)
+//                   with HybridSmoother stages around the exchanges              (hybrid_base_smoother.cpp:501-574)
+//
+// MI355X design: one process per GPU; a rank stores the rows of the vertices it OWNS with columns [owned | ghost]
+// (DESIGN.md 5.4), ghosts grouped by owner, so a peer's message lands contiguously (no unpack kernel in the owner ->
+// ghost direction).  Owned rows are ordered [interior | boundary]: kernels on the interior rows run on the compute stream
+// while pack kernel + ncclSend/ncclRecv run on the communication stream; the boundary part waits for the exchange event.
+// Nothing here synchronises the host: one application is one burst of asynchronous launches.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace amgx {
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL entry points, resolved at run time: a process that already holds a copy of librccl (torch ships one)
+// must not get a second one through a link-time dependency.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+
+  static Rccl& get() {
+    static Rccl r;
+    if (r.lib) return r;
+    const char* names[] = {std::getenv("NGSAMG_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);       // the copy this process already uses, if any
+    for (int i = 0; i < 4 && !h; ++i) if (names[i] && *names[i]) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw Err(std::string("RCCL not found (librccl.so.1): ") + (dlerror() ? dlerror() : "?") + "; set NGSAMG_RCCL_LIB");
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw Err(std::string("librccl: missing symbol ") + n); return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.lib = h;
+    return r;
+  }
+};
+
+#define NCCLCHK(call)                                                                                              \
+  do {                                                                                                             \
+    ncclResult_t r_ = (call);                                                                                      \
+    if (r_ != ncclSuccess)                                                                                         \
+      throw ::amgx::Err(std::string(#call) + " failed: " + ::amgx::Rccl::get().GetErrorString(r_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+struct HaloTable {                       // one level of one rank
+  int bs = 1;
+  int64_t n = 0, n_ghost = 0, n_int = 0; // owned block rows, ghost block rows, interior rows (no ghost column)
+  std::vector<int> peers;                // ascending ranks
+  std::vector<int64_t> send_ptr, recv_ptr;   // [n_peers + 1] in block rows
+  DevBuf<int32_t> send_idx;              // owned block rows packed per peer (m_ex_dofs)
+  DevBuf<double> sendbuf;                // pack target / receive buffer of the add direction
+  int64_t n_send() const { return send_ptr.empty() ? 0 : send_ptr.back(); }
+
+  void build(const amgx_halo_desc& d, int64_t n_own, int64_t n_cols, int bsz, int nranks, int self) {
+    bs = bsz; n = n_own; n_ghost = n_cols - n_own;
+    if (d.n_peers < 0 || (d.n_peers > 0 && (!d.peer_rank || !d.send_ptr || !d.recv_ptr))) throw Err("halo table: missing arrays");
+    n_int = d.n_interior;
+    if (n_int < 0 || n_int > n) throw Err("halo table: n_interior out of range");
+    peers.assign(d.peer_rank, d.peer_rank + d.n_peers);
+    send_ptr.assign(d.n_peers + 1, 0); recv_ptr.assign(d.n_peers + 1, 0);
+    for (int k = 0; k <= d.n_peers; ++k) { send_ptr[k] = d.send_ptr[k]; recv_ptr[k] = d.recv_ptr[k]; }
+    for (int k = 0; k < d.n_peers; ++k) {
+      if (peers[k] < 0 || peers[k] >= nranks || (k && peers[k] <= peers[k - 1])) throw Err("halo table: peers must be ascending valid ranks");
+      if (peers[k] == self && nranks > 1) throw Err("halo table: a rank cannot be its own peer");
+      if (send_ptr[k + 1] < send_ptr[k] || recv_ptr[k + 1] < recv_ptr[k]) throw Err("halo table: pointers must be monotone");
+    }
+    if (send_ptr[0] != 0 || recv_ptr[0] != 0) throw Err("halo table: pointers must start at 0");
+    if (recv_ptr.back() != n_ghost) throw Err("halo table: the receive segments must cover the ghost block exactly");
+    const int64_t ns = n_send();
+    if (ns >= (int64_t)2147483647) throw Err("halo table: too many send entries");
+    if (ns > 0 && !d.send_idx) throw Err("halo table: send_idx missing");
+    for (int64_t i = 0; i < ns; ++i) if (d.send_idx[i] < 0 || d.send_idx[i] >= n) throw Err("halo table: send index out of the owned range");
+    // the boundary-row contract behind the overlap: a sent row may be interior or boundary, but a row that READS a ghost
+    // must not be interior -- that is a property of the matrix and is checked where the matrix is known (Dist::create)
+    if (ns) send_idx.upload(d.send_idx, (size_t)ns);
+    sendbuf.alloc((size_t)std::max<int64_t>(1, std::max<int64_t>(ns, 1) * bs));
+  }
+  int peer_pos(int q) const { for (size_t k = 0; k < peers.size(); ++k) if (peers[k] == q) return (int)k; return -1; }
+};
+
+struct Dist;
+
+struct Comm {
+  int kind = AMGX_COMM_LOCAL, nranks = 1, rank = 0, device = 0;
+  ncclComm_t nccl = nullptr;
+  hipStream_t own_compute = nullptr, compute = nullptr, comm_stream = nullptr;
+  static constexpr int NEV = 8;
+  hipEvent_t ev_ready[NEV], ev_done[NEV];
+  int ev_next = 0;
+  std::vector<Dist*> members;            // local ranks in creation order (RCCL: exactly one)
+  std::string err;
+  int64_t n_exchanges = 0;               // statistics: halo exchanges started
+
+  Comm() { for (int i = 0; i < NEV; ++i) { ev_ready[i] = nullptr; ev_done[i] = nullptr; } }
+  ~Comm() {
+    for (int i = 0; i < NEV; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
+    if (nccl) (void)Rccl::get().CommDestroy(nccl);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    if (own_compute) (void)hipStreamDestroy(own_compute);
+  }
+  void init_streams() {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&own_compute, hipStreamNonBlocking));
+    compute = own_compute;
+    // the communication stream gets the higher priority: its small pack kernels and the RCCL kernels must not queue
+    // behind the streaming kernels of the interior rows
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPCHK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, hi));
+    for (int i = 0; i < NEV; ++i) {
+      HIPCHK(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+    }
+  }
+
+  // ---- halo exchange.  items[i] = (table, vector) of local member i.  Returns a ticket for exchange_end. -------------
+  struct Item { HaloTable* t; double* vec; };
+
+  // owner -> ghost, overwrite (reference CO2CU: BufferM, send, ApplyG; dcc_map.cpp:138-178, 280-302)
+  int exchange_begin(const std::vector<Item>& items) {
+    const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
+    ++n_exchanges;
+    HIPCHK(hipEventRecord(ev_ready[tk], compute));                 // everything the vectors depend on is enqueued
+    HIPCHK(hipStreamWaitEvent(comm_stream, ev_ready[tk], 0));
+    for (const Item& it : items) {
+      const int64_t len = it.t->n_send() * it.t->bs;
+      if (len) hipLaunchKernelGGL(halo_pack_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, comm_stream, len, it.t->bs,
+                                  it.t->send_idx.p, it.vec, it.t->sendbuf.p);
+    }
+    HIPCHK(hipGetLastError());
+    if (kind == AMGX_COMM_RCCL) {
+      Rccl& R = Rccl::get();
+      const HaloTable& t = *items[0].t;
+      double* vec = items[0].vec;
+      if (!t.peers.empty()) {
+        NCCLCHK(R.GroupStart());
+        for (size_t k = 0; k < t.peers.size(); ++k) {
+          const int64_t ns = (t.send_ptr[k + 1] - t.send_ptr[k]) * t.bs, nr = (t.recv_ptr[k + 1] - t.recv_ptr[k]) * t.bs;
+          if (ns) NCCLCHK(R.Send(t.sendbuf.p + t.send_ptr[k] * t.bs, (size_t)ns, ncclDouble, t.peers[k], nccl, comm_stream));
+          if (nr) NCCLCHK(R.Recv(vec + (t.n + t.recv_ptr[k]) * t.bs, (size_t)nr, ncclDouble, t.peers[k], nccl, comm_stream));
+        }
+        NCCLCHK(R.GroupEnd());
+      }
+    } else {
+      for (size_t i = 0; i < items.size(); ++i) {
+        const HaloTable& t = *items[i].t;
+        for (size_t k = 0; k < t.peers.size(); ++k) {
+          const int q = t.peers[k];
+          const int64_t ns = (t.send_ptr[k + 1] - t.send_ptr[k]) * t.bs;
+          if (!ns) continue;
+          if (q < 0 || q >= (int)items.size()) throw Err("local exchange: peer out of range");
+          const HaloTable& tq = *items[q].t;
+          const int kq = tq.peer_pos((int)i);
+          if (kq < 0 || (tq.recv_ptr[kq + 1] - tq.recv_ptr[kq]) * tq.bs != ns) throw Err("local exchange: send / receive sizes do not match");
+          HIPCHK(hipMemcpyAsync(items[q].vec + (tq.n + tq.recv_ptr[kq]) * tq.bs, t.sendbuf.p + t.send_ptr[k] * t.bs, ns * sizeof(double),
+                                hipMemcpyDeviceToDevice, comm_stream));
+        }
+      }
+    }
+    HIPCHK(hipEventRecord(ev_done[tk], comm_stream));
+    return tk;
+  }
+  void exchange_end(int ticket) { HIPCHK(hipStreamWaitEvent(compute, ev_done[ticket], 0)); }
+
+  // ghost -> owner, add, ghost entries zeroed afterwards (reference DIS2CO: BufferG, send, ApplyM; dcc_map.cpp:76-136, 249-274)
+  void accumulate(const std::vector<Item>& items) {
+    const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
+    ++n_exchanges;
+    HIPCHK(hipEventRecord(ev_ready[tk], compute));
+    HIPCHK(hipStreamWaitEvent(comm_stream, ev_ready[tk], 0));
+    if (kind == AMGX_COMM_RCCL) {
+      Rccl& R = Rccl::get();
+      const HaloTable& t = *items[0].t;
+      double* vec = items[0].vec;
+      if (!t.peers.empty()) {
+        NCCLCHK(R.GroupStart());
+        for (size_t k = 0; k < t.peers.size(); ++k) {
+          const int64_t ns = (t.send_ptr[k + 1] - t.send_ptr[k]) * t.bs, nr = (t.recv_ptr[k + 1] - t.recv_ptr[k]) * t.bs;
+          if (nr) NCCLCHK(R.Send(vec + (t.n + t.recv_ptr[k]) * t.bs, (size_t)nr, ncclDouble, t.peers[k], nccl, comm_stream));
+          if (ns) NCCLCHK(R.Recv(t.sendbuf.p + t.send_ptr[k] * t.bs, (size_t)ns, ncclDouble, t.peers[k], nccl, comm_stream));
+        }
+        NCCLCHK(R.GroupEnd());
+      }
+    } else {
+      for (size_t i = 0; i < items.size(); ++i) {
+        const HaloTable& t = *items[i].t;
+        for (size_t k = 0; k < t.peers.size(); ++k) {
+          const int q = t.peers[k];
+          const int64_t nr = (t.recv_ptr[k + 1] - t.recv_ptr[k]) * t.bs;
+          if (!nr) continue;
+          if (q < 0 || q >= (int)items.size()) throw Err("local exchange: peer out of range");
+          const HaloTable& tq = *items[q].t;
+          const int kq = tq.peer_pos((int)i);
+          if (kq < 0 || (tq.send_ptr[kq + 1] - tq.send_ptr[kq]) * tq.bs != nr) throw Err("local exchange: send / receive sizes do not match");
+          HIPCHK(hipMemcpyAsync(tq.sendbuf.p + tq.send_ptr[kq] * tq.bs, items[i].vec + (t.n + t.recv_ptr[k]) * t.bs, nr * sizeof(double),
+                                hipMemcpyDeviceToDevice, comm_stream));
+        }
+      }
+    }
+    for (const Item& it : items) {
+      const HaloTable& t = *it.t;
+      const int64_t gl = t.n_ghost * t.bs;
+      if (gl) hipLaunchKernelGGL(halo_zero_kernel, dim3(Handle::grid_for(gl)), dim3(BLOCK), 0, comm_stream, gl, it.vec + t.n * t.bs);
+      for (size_t k = 0; k < t.peers.size(); ++k) {          // one launch per peer: two peers may both contribute to a row
+        const int64_t len = (t.send_ptr[k + 1] - t.send_ptr[k]) * t.bs;
+        if (len) hipLaunchKernelGGL(halo_unpack_add_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, comm_stream, len, t.bs,
+                                    t.send_idx.p + t.send_ptr[k], t.sendbuf.p + t.send_ptr[k] * t.bs, it.vec);
+      }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ev_done[tk], comm_stream));
+    HIPCHK(hipStreamWaitEvent(compute, ev_done[tk], 0));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// one rank's share of a rank-partitioned hierarchy + the replicated tail
+struct Dist {
+  Comm* comm = nullptr;
+  int index = 0;                         // position in comm->members
+  std::unique_ptr<Handle> top, tail;
+  int k = 0;                             // levels 0..k-1 smoothed in rank-partitioned form, level k gathered
+  int sm_type = AMGX_SM_JACOBI;
+  bool fold = true;
+  bool overlap = true;
+  std::vector<HaloTable> halo;           // [k]
+  std::vector<std::array<int, 4>> stage; // [k] colour ranges of the hybrid Gauss-Seidel stages: [s0,s1) first local part,
+                                         //     [s1,s2) boundary ("EX") rows, [s2,s3) second local part (gssmoother.cpp:721-782)
+  std::vector<DevBuf<double>> bext, xext, text, rl;
+  DevBuf<double> bk, bpad, bglob, xglob, xk_ext, x0;
+  DevBuf<int64_t> kmap, compact;
+  std::vector<int64_t> counts, offs;
+  int64_t mcount = 0;                    // longest level-k piece
+
+  int64_t n(int l) const { return top->lev[l].len(); }
+  int64_t next(int l) const { return top->lev[l].ext_len(); }
+};
+
+static void dist_check_interior(const amgx_matrix& A, int64_t n_int) {
+  for (int64_t i = 0; i < n_int; ++i)
+    for (int64_t e = A.rowptr[i]; e < A.rowptr[i + 1]; ++e)
+      if (A.col[e] >= A.n_rows) throw Err("rank-partitioned level: a row below n_interior has a ghost column");
+}
+
+static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
+  if (!c || !d) throw Err("amgx_dist_create: null argument");
+  if (c->kind == AMGX_COMM_RCCL && !c->members.empty()) throw Err("amgx_dist_create: an RCCL communicator carries one rank per process");
+  if (c->kind == AMGX_COMM_LOCAL && (int)c->members.size() >= c->nranks) throw Err("amgx_dist_create: all local ranks exist already");
+  const int self = c->kind == AMGX_COMM_RCCL ? c->rank : (int)c->members.size();
+  if (d->rank != self) throw Err("amgx_dist_create: descriptor rank does not match the communicator (local ranks are created in order)");
+  HIPCHK(hipSetDevice(c->device));
+  auto D = std::make_unique<Dist>();
+  D->comm = c;
+  D->index = (int)c->members.size();
+  D->k = d->top.n_levels - 1;
+  if (D->k < 1) throw Err("amgx_dist_create: need at least one rank-partitioned level and the gathered level");
+  if (!d->halo || !d->counts || !d->kmap) throw Err("amgx_dist_create: halo tables / level-k tables missing");
+  D->sm_type = d->top.levels[0].sm_type;
+  D->fold = d->fold != 0;
+  D->overlap = !std::getenv("AMGX_DIST_NO_OVERLAP");
+  amgx_hierarchy_desc td = d->top;
+  td.device = c->device; td.use_graph = 0; td.clev = AMGX_CLEV_NONE; td.coarse_n = 0; td.coarse_inv = nullptr;
+  D->top.reset(create(&td));
+  amgx_hierarchy_desc ld = d->tail;
+  ld.device = c->device;
+  D->tail.reset(create(&ld));
+  // both handles work on the communicator's compute stream
+  for (Handle* h : {D->top.get(), D->tail.get()}) { HIPCHK(hipStreamSynchronize(h->stream)); h->stream = c->compute; }
+  const int k = D->k;
+  D->halo.resize(k);
+  D->stage.resize(k);
+  for (int l = 0; l < k; ++l) {
+    const amgx_level_desc& s = d->top.levels[l];
+    if (s.sm_type != D->sm_type) throw Err("amgx_dist_create: all rank-partitioned levels must use the same smoother");
+    if (s.sm_steps > 1 || s.sm_symm) throw Err("amgx_dist_create: sm_steps / sm_symm are not supported on rank-partitioned levels");
+    D->halo[l].build(d->halo[l], s.A.n_rows, s.A.n_cols, s.A.br, c->nranks, self);
+    dist_check_interior(s.A, D->halo[l].n_int);
+    if (D->fold && s.Q.rowptr) {           // the way up splits the same way: interior rows of Q must not read coarse ghosts
+      const int64_t nco = d->top.levels[l + 1].A.n_rows;
+      for (int64_t i = 0; i < D->halo[l].n_int; ++i)
+        for (int64_t e = s.Q.rowptr[i]; e < s.Q.rowptr[i + 1]; ++e)
+          if (s.Q.col[e] >= nco) throw Err("rank-partitioned level: a row of Q below n_interior reads a coarse ghost");
+    }
+    const int nc = s.sm_type == AMGX_SM_GS ? s.n_colors : (s.sm_type == AMGX_SM_BGS ? s.bgs_n_colors : 0);
+    D->stage[l] = {0, 0, nc, nc};
+    if (d->gs_stage && s.sm_type == AMGX_SM_GS) {
+      const int32_t* g = d->gs_stage + 4 * l;
+      if (!(g[0] == 0 && g[0] <= g[1] && g[1] <= g[2] && g[2] <= g[3] && g[3] == nc)) throw Err("amgx_dist_create: gs_stage must be 0 <= s1 <= s2 <= n_colors");
+      D->stage[l] = {g[0], g[1], g[2], g[3]};
+      // rows of the first and third stage must not read ghosts (they run while the exchange is in flight)
+      for (int64_t i = 0; i < s.A.n_rows; ++i) {
+        const int ci = s.color[i];
+        if (ci < 0 || (ci >= g[1] && ci < g[2])) continue;
+        for (int64_t e = s.A.rowptr[i]; e < s.A.rowptr[i + 1]; ++e)
+          if (s.A.col[e] >= s.A.n_rows) throw Err("amgx_dist_create: a row of a local Gauss-Seidel stage has a ghost column");
+      }
+    }
+  }
+  if (D->fold) {
+    if (D->sm_type != AMGX_SM_JACOBI) throw Err("amgx_dist_create: fold needs Jacobi levels");
+    for (int l = 0; l < k; ++l) if (!D->top->folded(D->top->lev[l])) throw Err("amgx_dist_create: fold requested but level " + std::to_string(l) + " has no Q");
+  }
+  D->bext.resize(k); D->xext.resize(k); D->text.resize(k); D->rl.resize(k);
+  auto zalloc = [&](DevBuf<double>& b, int64_t len) { b.alloc((size_t)std::max<int64_t>(1, len)); HIPCHK(hipMemset(b.p, 0, std::max<int64_t>(1, len) * sizeof(double))); };
+  for (int l = 0; l < k; ++l) {
+    zalloc(D->bext[l], D->next(l)); zalloc(D->xext[l], D->next(l)); zalloc(D->rl[l], D->n(l));
+    if (!D->fold && D->sm_type == AMGX_SM_JACOBI) zalloc(D->text[l], D->next(l));
+  }
+  // level k: gathered in rank order
+  D->counts.assign(d->counts, d->counts + c->nranks);
+  D->offs.assign(c->nranks + 1, 0);
+  for (int r = 0; r < c->nranks; ++r) { if (D->counts[r] < 0) throw Err("amgx_dist_create: negative count"); D->offs[r + 1] = D->offs[r] + D->counts[r]; D->mcount = std::max(D->mcount, D->counts[r]); }
+  const int bsk = D->top->lev[k].bs;
+  if (D->counts[self] * bsk != D->n(k)) throw Err("amgx_dist_create: counts[rank] does not match level k");
+  if (D->offs.back() * bsk != D->tail->lev[0].len()) throw Err("amgx_dist_create: the replicated tail does not match the gathered level");
+  if (d->kmap_len != D->next(k)) throw Err("amgx_dist_create: kmap must cover level k [owned | ghost]");
+  for (int64_t i = 0; i < d->kmap_len; ++i) if (d->kmap[i] < 0 || d->kmap[i] >= D->offs.back() * bsk) throw Err("amgx_dist_create: kmap out of range");
+  D->kmap.upload(d->kmap, (size_t)d->kmap_len);
+  zalloc(D->bk, D->mcount * bsk); zalloc(D->bglob, D->offs.back() * bsk); zalloc(D->xglob, D->offs.back() * bsk);
+  zalloc(D->xk_ext, D->next(k)); zalloc(D->x0, D->n(0));
+  bool equal = true;
+  for (int r = 0; r < c->nranks; ++r) equal = equal && D->counts[r] == D->mcount;
+  if (!equal && c->kind == AMGX_COMM_RCCL) {
+    // ncclAllGather moves pieces of one size: pad to the longest piece, then drop the padding with one gather
+    zalloc(D->bpad, D->mcount * bsk * c->nranks);
+    std::vector<int64_t> ci((size_t)(D->offs.back() * bsk));
+    for (int r = 0; r < c->nranks; ++r)
+      for (int64_t i = 0; i < D->counts[r] * bsk; ++i) ci[D->offs[r] * bsk + i] = (int64_t)r * D->mcount * bsk + i;
+    D->compact.upload(ci);
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return D.release();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the collective cycle.  All members of the communicator advance stage by stage (one member under RCCL).
+struct DistCycle {
+  Comm& c;
+  std::vector<Dist*>& M;
+  std::vector<double*> x;                // level-0 solution vectors (device)
+  using Span = Handle::Span;
+
+  std::vector<Comm::Item> items(int l, int which) {      // which: 0 bext, 1 xext, 2 text
+    std::vector<Comm::Item> it;
+    for (Dist* d : M) it.push_back({&d->halo[l], which == 0 ? d->bext[l].p : which == 1 ? d->xext[l].p : d->text[l].p});
+    return it;
+  }
+  double* xl(Dist* d, int i, int l) { return l == 0 ? x[i] : d->xext[l].p; }
+  double* bnext(Dist* d, int l) { return l + 1 < d->k ? d->bext[l + 1].p : d->bk.p; }
+
+  void gather_level_k() {
+    for (size_t i = 0; i < M.size(); ++i) {
+      Dist* d = M[i];
+      const int bsk = d->top->lev[d->k].bs;
+      if (c.kind == AMGX_COMM_RCCL) {
+        Rccl& R = Rccl::get();
+        if (c.nranks == 1) d->top->copy(d->bglob.p, d->bk.p, d->n(d->k));
+        else if (d->compact.n == 0) NCCLCHK(R.AllGather(d->bk.p, d->bglob.p, (size_t)(d->mcount * bsk), ncclDouble, c.nccl, c.compute));
+        else {
+          NCCLCHK(R.AllGather(d->bk.p, d->bpad.p, (size_t)(d->mcount * bsk), ncclDouble, c.nccl, c.compute));
+          const int64_t len = d->offs.back() * bsk;
+          hipLaunchKernelGGL(index_gather_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, c.compute, len, d->compact.p, d->bpad.p, d->bglob.p);
+          HIPCHK(hipGetLastError());
+        }
+      } else {
+        for (size_t q = 0; q < M.size(); ++q)
+          if (d->counts[i]) HIPCHK(hipMemcpyAsync(M[q]->bglob.p + d->offs[i] * bsk, d->bk.p, d->counts[i] * bsk * sizeof(double), hipMemcpyDeviceToDevice, c.compute));
+      }
+    }
+  }
+
+  void tail_and_pick() {
+    for (Dist* d : M) {
+      d->tail->run_cycle(d->xglob.p, d->bglob.p, true);
+      const int64_t len = d->next(d->k);
+      if (len) hipLaunchKernelGGL(index_gather_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, c.compute, len, d->kmap.p, d->xglob.p, d->xk_ext.p);
+      HIPCHK(hipGetLastError());
+    }
+  }
+
+  // ---- Jacobi, post-smoothing folded into the prolongation: 2k - 1 exchanges ------------------------
+  void jacobi_folded() {
+    const int k = M[0]->k;
+    for (int l = 0; l < k; ++l) {
+      const int tk = c.exchange_begin(items(l, 0));
+      if (M[0]->overlap)
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, Span{Handle::PART_INT, d->halo[l].n_int}); }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+      }
+    }
+    gather_level_k();
+    tail_and_pick();
+    int tk = -1;
+    for (int l = k - 1; l >= 0; --l) {
+      if (tk >= 0 && M[0]->overlap)
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, d->xext[l + 1].p, true, Span{Handle::PART_INT, d->halo[l].n_int}); }
+      const bool split = tk >= 0 && M[0]->overlap;
+      if (tk >= 0) c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        const double* xc = l + 1 < k ? d->xext[l + 1].p : d->xk_ext.p;
+        d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, xc, true, split ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+      }
+      tk = l > 0 ? c.exchange_begin(items(l, 1)) : -1;
+    }
+  }
+
+  // ---- Jacobi, literal stage order (base_smoother.cpp:61-74 around dof_map.cpp:636-709): 2k exchanges ----------------
+  void jacobi_literal() {
+    const int k = M[0]->k;
+    for (int l = 0; l < k; ++l) {
+      const int tk = c.exchange_begin(items(l, 0));
+      if (M[0]->overlap)
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, Span{Handle::PART_INT, d->halo[l].n_int}); }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+        d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l));
+      }
+    }
+    gather_level_k();
+    tail_and_pick();
+    for (int l = k - 1; l >= 0; --l) {
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        const double* xc = l + 1 < k ? d->xext[l + 1].p : d->xk_ext.p;       // owned part first in both
+        d->top->mult_add(d->top->lev[l].P, 1.0, xc, xl(d, i, l), d->text[l].p);
+      }
+      const int tk = c.exchange_begin(items(l, 2));
+      if (M[0]->overlap)
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), Span{Handle::PART_INT, d->halo[l].n_int}); }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+      }
+    }
+  }
+
+  // ---- hybrid (block) Gauss-Seidel: local sweeps with the off-rank values frozen at their sweep-start values
+  //      (HybridGSSmoother, gssmoother.cpp:709-861; stages LOC_1 / EX / LOC_2 = colour ranges, :721-782) ---------------
+  void sweep(Dist* d, int l, int dir, double* xv, const double* b, int c0, int c1) {
+    if (c1 <= c0) return;
+    DevLevel& L = d->top->lev[l];
+    if (d->sm_type == AMGX_SM_BGS) d->top->bgs_sweep(L, dir, xv, b, c0, c1);
+    else d->top->gs_sweep(L, dir, xv, b, false, c0, c1);
+  }
+  void hybrid_gs(const std::vector<const double*>& b0) {
+    const int k = M[0]->k;
+    auto bl = [&](Dist* d, size_t i, int l) { return l == 0 ? b0[i] : (const double*)d->bext[l].p; };
+    for (int l = 0; l < k; ++l) {
+      // pre: x = 0; forward sweep (all off-rank values are 0, no exchange needed before it); the owner -> ghost exchange
+      // of x starts as soon as the boundary stage is done and hides behind the second local stage
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        d->top->zero(d->xext[l].p, d->next(l));
+        sweep(d, l, 0, d->xext[l].p, bl(d, i, l), d->stage[l][0], d->stage[l][2]);
+      }
+      const int tk = c.exchange_begin(items(l, 1));
+      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep(d, l, 0, d->xext[l].p, bl(d, i, l), d->stage[l][2], d->stage[l][3]); }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        d->top->residual(d->top->lev[l].A, d->xext[l].p, bl(d, i, l), d->rl[l].p);
+        d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l));
+      }
+    }
+    gather_level_k();
+    tail_and_pick();
+    for (int l = k - 1; l >= 0; --l) {
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        const double* xc = l + 1 < k ? d->xext[l + 1].p : d->xk_ext.p;
+        d->top->mult_add(d->top->lev[l].P, 1.0, xc, d->xext[l].p, d->xext[l].p);
+      }
+      // post: backward sweep = the stages in reverse order; the exchange hides behind the (reversed) second local stage
+      const int tk = c.exchange_begin(items(l, 1));
+      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep(d, l, 1, d->xext[l].p, bl(d, i, l), d->stage[l][2], d->stage[l][3]); }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        sweep(d, l, 1, d->xext[l].p, bl(d, i, l), d->stage[l][0], d->stage[l][2]);
+        if (l == 0) d->top->copy(x[i], d->xext[0].p, d->n(0));
+      }
+    }
+  }
+};
+
+// b_status 0 (DISTRIBUTED): b carries [owned | ghost] entries and the ghost entries are contributions to their owners
+// (b.Distribute() state of the reference, amg_matrix.cpp:164); 1 (CUMULATED): the owned entries are complete.
+static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_status, int flags) {
+  std::vector<Dist*>& M = c.members;
+  if (M.empty()) throw Err("amgx_dist_apply: the communicator has no rank-partitioned hierarchy");
+  if (c.kind == AMGX_COMM_LOCAL && (int)M.size() != c.nranks) throw Err("amgx_dist_apply: not all local ranks have been created");
+  if (!b || !x) throw Err("amgx_dist_apply: null vector list");
+  const bool host = !(flags & AMGX_DEVICE_PTR);
+  DistCycle cy{c, M, {}};
+  std::vector<const double*> b0(M.size());
+  for (size_t i = 0; i < M.size(); ++i) {
+    Dist* d = M[i];
+    if (!b[i] || !x[i]) throw Err("amgx_dist_apply: null vector");
+    const int64_t nb = b_status == 0 ? d->next(0) : d->n(0);
+    if (host) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyHostToDevice, c.compute));
+    else if (b[i] != d->bext[0].p) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyDeviceToDevice, c.compute));
+    b0[i] = d->bext[0].p;
+    cy.x.push_back(host ? d->x0.p : x[i]);
+  }
+  if (b_status == 0) {
+    std::vector<Comm::Item> it;
+    for (Dist* d : M) it.push_back({&d->halo[0], d->bext[0].p});
+    c.accumulate(it);
+  }
+  if (M[0]->sm_type == AMGX_SM_JACOBI) { if (M[0]->fold) cy.jacobi_folded(); else cy.jacobi_literal(); }
+  else cy.hybrid_gs(b0);
+  if (host) {
+    for (size_t i = 0; i < M.size(); ++i) HIPCHK(hipMemcpyAsync(x[i], M[i]->x0.p, M[i]->n(0) * sizeof(double), hipMemcpyDeviceToHost, c.compute));
+    HIPCHK(hipStreamSynchronize(c.compute));
+  }
+}
+
+}  // namespace amgx
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI (include/amgx.h, "rank-partitioned hierarchies")
+// ---------------------------------------------------------------------------------------------------
+struct amgx_comm_t { amgx::Comm* c; };
+struct amgx_dist_t { amgx::Dist* d; };
+struct amgx_halo_t { amgx::Comm* c; amgx::HaloTable t; };
+
+namespace {
+template <class F>
+int cguard(amgx_comm cc, F&& f) {
+  try {
+    if (!cc || !cc->c) throw amgx::Err("null communicator");
+    HIPCHK(hipSetDevice(cc->c->device));
+    f(*cc->c);
+    return 0;
+  } catch (const std::exception& e) {
+    if (cc && cc->c) cc->c->err = e.what(); else g_create_err = e.what();
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* amgx_comm_last_error(amgx_comm c) { return (c && c->c) ? c->c->err.c_str() : g_create_err.c_str(); }
+
+int amgx_comm_unique_id(char* id128) {
+  try {
+    if (!id128) throw amgx::Err("amgx_comm_unique_id: null buffer");
+    static_assert(sizeof(ncclUniqueId) == AMGX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCLCHK(amgx::Rccl::get().GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
+}
+
+int amgx_comm_create(int kind, int n_ranks, int rank, const char* id128, int device, amgx_comm* out) {
+  try {
+    if (!out) throw amgx::Err("amgx_comm_create: null output");
+    if (kind != AMGX_COMM_RCCL && kind != AMGX_COMM_LOCAL) throw amgx::Err("amgx_comm_create: unknown kind");
+    if (n_ranks < 1) throw amgx::Err("amgx_comm_create: n_ranks must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw amgx::Err("amgx_comm_create: no HIP device available (the apply path has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw amgx::Err("amgx_comm_create: device ordinal out of range");
+    auto c = std::make_unique<amgx::Comm>();
+    c->kind = kind; c->nranks = n_ranks; c->device = device;
+    c->rank = kind == AMGX_COMM_RCCL ? rank : 0;
+    c->init_streams();
+    if (kind == AMGX_COMM_RCCL) {
+      if (rank < 0 || rank >= n_ranks || !id128) throw amgx::Err("amgx_comm_create: RCCL needs rank in [0, n_ranks) and the unique id of rank 0");
+      ncclUniqueId id;
+      std::memcpy(&id, id128, sizeof(id));
+      NCCLCHK(amgx::Rccl::get().CommInitRank(&c->nccl, n_ranks, id, rank));     // collective over all ranks
+    }
+    *out = new amgx_comm_t{c.release()};
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
+}
+
+int amgx_comm_destroy(amgx_comm c) {
+  if (!c) return 0;
+  if (c->c) {
+    (void)hipSetDevice(c->c->device);
+    (void)hipDeviceSynchronize();
+    for (amgx::Dist* d : c->c->members) delete d;
+    delete c->c;
+  }
+  delete c;
+  return 0;
+}
+
+int amgx_comm_set_stream(amgx_comm cc, void* s) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    hipStream_t ns = s ? (hipStream_t)s : c.own_compute;       // NULL: back to the communicator's own stream
+    if (ns == c.compute) return;
+    HIPCHK(hipStreamSynchronize(c.compute));
+    HIPCHK(hipStreamSynchronize(c.comm_stream));
+    c.compute = ns;
+    for (amgx::Dist* d : c.members) { d->top->drop_graphs(); d->tail->drop_graphs(); d->top->stream = ns; d->tail->stream = ns; }
+  });
+}
+
+int amgx_comm_synchronize(amgx_comm cc) {
+  return cguard(cc, [&](amgx::Comm& c) { HIPCHK(hipStreamSynchronize(c.comm_stream)); HIPCHK(hipStreamSynchronize(c.compute)); });
+}
+
+int amgx_comm_info(amgx_comm cc, int32_t* kind, int32_t* n_ranks, int32_t* rank, int64_t* n_exchanges) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (kind) *kind = c.kind;
+    if (n_ranks) *n_ranks = c.nranks;
+    if (rank) *rank = c.rank;
+    if (n_exchanges) *n_exchanges = c.n_exchanges;
+  });
+}
+
+int amgx_dist_create(amgx_comm cc, const amgx_dist_desc* desc, amgx_dist* out) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (!out) throw amgx::Err("amgx_dist_create: null output");
+    amgx::Dist* d = amgx::dist_create(&c, desc);
+    c.members.push_back(d);
+    *out = new amgx_dist_t{d};
+  });
+}
+
+int amgx_dist_destroy(amgx_dist d) { delete d; return 0; }     // the communicator owns the rank objects
+
+int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_ext) {
+  if (!d || !d->d) return 1;
+  if (b) *b = d->d->bext[0].p;
+  if (n_owned) *n_owned = d->d->n(0);
+  if (n_ext) *n_ext = d->d->next(0);
+  return 0;
+}
+
+int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail) {
+  // borrowed views for queries / measurement (amgx_matrix_info, amgx_time_op); destroyed with the communicator
+  if (!d || !d->d) return 1;
+  static thread_local std::vector<std::unique_ptr<amgx_handle_t>> views;
+  if (top) { views.emplace_back(new amgx_handle_t{d->d->top.get()}); *top = views.back().get(); }
+  if (tail) { views.emplace_back(new amgx_handle_t{d->d->tail.get()}); *tail = views.back().get(); }
+  return 0;
+}
+
+int amgx_dist_apply(amgx_comm cc, const double* const* b, double* const* x, int b_status, int flags) {
+  return cguard(cc, [&](amgx::Comm& c) { amgx::dist_apply(c, b, x, b_status, flags); });
+}
+
+// ---- stand-alone halo maps (the DCCMap surface: python_smoothers / tests use it without a hierarchy) -----------------
+int amgx_halo_create(amgx_comm cc, const amgx_halo_desc* d, int64_t n_owned, int64_t n_ghost, int32_t bs, int32_t rank, amgx_halo* out) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (!d || !out) throw amgx::Err("amgx_halo_create: null argument");
+    if (bs < 1 || bs > 6) throw amgx::Err("amgx_halo_create: block size must be in 1..6");
+    auto h = std::make_unique<amgx_halo_t>();
+    h->c = &c;
+    // world size 1 over RCCL: a rank may list itself as peer (self send / receive) -- used to exercise the wire on one GPU
+    h->t.build(*d, n_owned, n_owned + n_ghost, bs, c.nranks, c.nranks > 1 ? (c.kind == AMGX_COMM_RCCL ? c.rank : rank) : -1);
+    *out = h.release();
+  });
+}
+int amgx_halo_destroy(amgx_halo h) { delete h; return 0; }
+
+// mode 0: owner -> ghost, overwrite (CO2CU); mode 1: ghost -> owner, add, ghosts zeroed (DIS2CO).
+// halos / vecs: one per local rank (RCCL: one); device vectors of (n_owned + n_ghost) * bs entries on the communicator's stream
+int amgx_halo_exchange(amgx_comm cc, int n_local, const amgx_halo* halos, double* const* vecs, int mode) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (n_local < 1 || !halos || !vecs) throw amgx::Err("amgx_halo_exchange: bad arguments");
+    if (c.kind == AMGX_COMM_RCCL && n_local != 1) throw amgx::Err("amgx_halo_exchange: one rank per process under RCCL");
+    if (c.kind == AMGX_COMM_LOCAL && n_local != c.nranks) throw amgx::Err("amgx_halo_exchange: pass all local ranks");
+    std::vector<amgx::Comm::Item> it;
+    for (int i = 0; i < n_local; ++i) { if (!halos[i] || halos[i]->c != &c || !vecs[i]) throw amgx::Err("amgx_halo_exchange: bad halo / vector"); it.push_back({&halos[i]->t, vecs[i]}); }
+    if (mode == 0) c.exchange_end(c.exchange_begin(it));
+    else if (mode == 1) c.accumulate(it);
+    else throw amgx::Err("amgx_halo_exchange: mode must be 0 or 1");
+  });
+}
+
+}  // extern "C"

@@ -272,11 +272,12 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
 
 // SELL-64-pair, scalar, G lanes per row (G = 1: one thread per row), one wave per slice of 64/G rows
 template <int G, int EP>
-__global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_slices, SellMat M,
+__global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int slice0, int n_slices, SellMat M,
                                                           const double* __restrict__ x, double* y, EpArgs ep) {
   const int lane = threadIdx.x & (WAVE - 1);
   // the slice index is wave-uniform: tell the compiler, so slice pointers and column bases use scalar loads
-  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  // (slice0 .. n_slices: the launch covers a range of slices -- interior / boundary rows of a rank-partitioned level)
+  const int s = __builtin_amdgcn_readfirstlane(slice0 + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
   const int row = s * (WAVE / G) + lane / G;
   double xd[2] = {0.0, 0.0};
@@ -309,13 +310,14 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int n_
 #endif
 constexpr int SELL_WIN = SELL_WIN_SIZE;
 template <int WB, int EP>
-__global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, SellMat M, const uint16_t* __restrict__ rowloc,
+__global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, int win0, SellMat M, const uint16_t* __restrict__ rowloc,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
   __shared__ double buf[WB];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (WB / WAVE) + (threadIdx.x >> 6));
+  const int wb = win0 + blockIdx.x;            // window index (win0: first window of the launch, see sell_spmv_kernel)
+  const int s = __builtin_amdgcn_readfirstlane(wb * (WB / WAVE) + (threadIdx.x >> 6));
   const int64_t slot = (int64_t)s * WAVE + lane;
-  const int64_t row = (int64_t)blockIdx.x * WB + threadIdx.x;
+  const int64_t row = (int64_t)wb * WB + threadIdx.x;
   const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
   EpOps ops{0.0, 0.0, 0.0};
   if (hoist && row < n_rows) ops = ep_operands<EP>(row, ep, false);
@@ -330,12 +332,12 @@ __global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, SellM
 // ---------------------------------------------------------------------------------------------------
 // CSR-vector, scalar: G lanes per row
 template <int G, int EP>
-__global__ __launch_bounds__(BLOCK) void csrvec_spmv_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(BLOCK) void csrvec_spmv_kernel(int64_t row0, int64_t n_rows, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ cols,
                                                             const double* __restrict__ vals,
                                                             const double* __restrict__ x, double* y, EpArgs ep) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t row = t / G;
+  const int64_t row = row0 + t / G;            // rows [row0, n_rows)
   const int sub = (int)(t % G);
   double acc = 0.0;
   if (row < n_rows) {
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 // order.  Replaces: 80 MB write of r + the P^T gather kernel (134 us at cfg 2, TA/L2-bound).
 // FB = workgroup size = rows per chunk (1024 or 512); 4 entries of P per row at most
 template <int FUSED_BLOCK>
-__global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int n_slices, SellMat M,
+__global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
                                                                         double omega, int nt, double* __restrict__ x, double* r_out,
                                                                         const int32_t* __restrict__ chunk_slot,
@@ -693,11 +695,11 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   __shared__ double rl[FUSED_BLOCK];
   __shared__ double pr[FUSED_MAX_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));
+  const int c = chunk0 + blockIdx.x;           // chunk0: first chunk of the launch (interior / boundary chunks of a rank-partitioned level)
+  const int s = __builtin_amdgcn_readfirstlane(c * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));
   const int row = s * WAVE + lane;
   // the chunk-local restriction data of this thread is requested FIRST, so that it arrives while the row product
   // streams A'; the epilogue after the barriers then touches LDS only
-  const int c = blockIdx.x;
   const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
   const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
   double wq[FUSED_MAX_ENTRIES / FUSED_BLOCK];
@@ -1024,6 +1026,41 @@ __global__ __launch_bounds__(BLOCK) void perm_scatter_kernel(int64_t len, int bs
   const int64_t i = t / bs;
   const int c = (int)(t - i * bs);
   dst[(int64_t)perm[i] * bs + c] = src[t];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Halo exchange buffers (reference DCCMap, src/base/linalg/dcc_map.cpp:249-302).  Block vectors are AoS (entry =
+// bs*dof + comp, dcc_map.cpp:237-243); `idx` lists block rows, one thread moves one scalar entry, so consecutive
+// threads write (pack) / read (unpack) consecutive buffer entries: the buffer side is always coalesced.
+//   halo_pack_kernel      : buf[t] = vec[idx[t / bs] * bs + t % bs]           BufferM (:280-288): owner entries -> send buffer
+//   halo_unpack_add_kernel: vec[idx[t / bs] * bs + t % bs] += buf[t]          ApplyM  (:266-274): vec += received
+//   ghost segments are contiguous per peer in this layout, so BufferG (:252-260, copy ghost entries and ZERO them) is a
+//   plain device copy + halo_zero_kernel, and ApplyG (:294-302, vec = received) is the receive itself (no kernel).
+// An index list never repeats a row inside one call (a peer's list is a set; lists of different peers are unpacked by
+// separate launches), so the += is race-free.
+__global__ __launch_bounds__(BLOCK) void halo_pack_kernel(int64_t len, int bs, const int32_t* __restrict__ idx,
+                                                          const double* __restrict__ vec, double* __restrict__ buf) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= len) return;
+  const int64_t i = t / bs;
+  buf[t] = vec[(int64_t)idx[i] * bs + (t - i * bs)];
+}
+__global__ __launch_bounds__(BLOCK) void halo_unpack_add_kernel(int64_t len, int bs, const int32_t* __restrict__ idx,
+                                                                const double* __restrict__ buf, double* __restrict__ vec) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= len) return;
+  const int64_t i = t / bs;
+  vec[(int64_t)idx[i] * bs + (t - i * bs)] += buf[t];
+}
+__global__ __launch_bounds__(BLOCK) void halo_zero_kernel(int64_t len, double* __restrict__ v) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t < len) v[t] = 0.0;
+}
+// 64-bit index gather (all-gather compaction, level-k [owned | ghost] pick from the replicated tail solution)
+__global__ __launch_bounds__(BLOCK) void index_gather_kernel(int64_t len, const int64_t* __restrict__ idx,
+                                                             const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (t < len) dst[t] = src[idx[t]];
 }
 
 // dense y = M x, one wave per row (coarsest-level inverse, n <= a few hundred)

@@ -49,6 +49,62 @@ class _Vec:
             self.addr = a.ctypes.data
 
 
+def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False, mg_cycle="V", clev="inv", device=0,
+                   use_graph=True):
+    """amgx_hierarchy_desc over the host arrays of a hierarchy.  Returns (desc, keep): `keep` holds everything the
+    descriptor points to and must outlive the amgx_create / amgx_dist_create call."""
+    levels = hierarchy.levels
+    n = len(levels)
+    types = sm_type if isinstance(sm_type, (list, tuple)) else [sm_type] * n
+    if len(types) != n:
+        raise NgsAMGError("sm_type list must have one entry per level")
+    arr = (_lib.amgx_level_desc * n)()
+    keep = [arr, hierarchy]
+    for i, lv in enumerate(levels):
+        d = arr[i]
+        d.A = lv.A.desc(_lib.amgx_matrix)
+        if lv.P is not None:
+            d.P = lv.P.desc(_lib.amgx_matrix)
+            d.PT = lv.PT.desc(_lib.amgx_matrix)
+        d.dinv = _lib.ptr(lv.dinv, C.c_double)
+        d.free_dofs = _lib.ptr(lv.free, C.c_uint8)
+        if types[i] not in _SM:
+            raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs | bgs)")
+        d.sm_type = _SM[types[i]]
+        d.omega = float(omega)
+        d.sm_steps = int(sm_steps[i] if isinstance(sm_steps, (list, tuple)) else sm_steps)      # per level: ..._spec flags
+        d.sm_symm = int(bool(sm_symm[i] if isinstance(sm_symm, (list, tuple)) else sm_symm))
+        d.color = _lib.ptr(lv.color, C.c_int32)
+        d.n_colors = int(lv.n_colors)
+        g = getattr(lv, "bgs", None)
+        if types[i] == "bgs" and g is None and i + 1 < n:
+            raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")
+        if types[i] == "bgs" and g is not None:
+            keep.append(g)
+            d.bgs_n_blocks = int(g.n_blocks)
+            d.bgs_block_ptr, d.bgs_block_rows = _lib.ptr(g.block_ptr, C.c_int32), _lib.ptr(g.block_rows, C.c_int32)
+            d.bgs_dinv_ptr, d.bgs_dinv = _lib.ptr(g.dinv_ptr, C.c_int64), _lib.ptr(g.dinv, C.c_double)
+            d.bgs_color, d.bgs_n_colors = _lib.ptr(g.color, C.c_int32), int(g.n_colors)
+        q = getattr(lv, "Q", None)        # caller-supplied folded prolongation (rank-partitioned levels, dist.py)
+        if q is not None:
+            d.Q = q.desc(_lib.amgx_matrix)
+    desc = _lib.amgx_hierarchy_desc()
+    desc.n_levels = n
+    desc.levels = arr
+    if mg_cycle not in _lib.AMGX_CYCLE:
+        raise NgsAMGError(f"unknown mg_cycle '{mg_cycle}' (V | W | BS)")
+    desc.cycle = _lib.AMGX_CYCLE[mg_cycle]
+    if clev == "inv" and hierarchy.coarse_n == 0:
+        raise NgsAMGError("clev = inv but the hierarchy has no coarse inverse (coarsest level too large to invert densely: "
+                          "raise ngs_amg_max_levels or lower ngs_amg_max_coarse_size, or use ngs_amg_clev='none')")
+    desc.clev = _lib.AMGX_CLEV_INV if clev == "inv" else _lib.AMGX_CLEV_NONE
+    desc.coarse_n = hierarchy.coarse_n if clev == "inv" else 0
+    desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
+    desc.device = int(device)
+    desc.use_graph = int(bool(use_graph))
+    return desc, keep
+
+
 class DeviceAMGMatrix:
     def __init__(self, hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False, mg_cycle="V",
                  clev="inv", device=0, use_graph=True):
@@ -57,67 +113,38 @@ class DeviceAMGMatrix:
         self._cfg = dict(sm_type=sm_type, omega=omega, sm_steps=sm_steps, sm_symm=sm_symm, mg_cycle=mg_cycle, clev=clev,
                          device=device, use_graph=use_graph)
         self.hierarchy = hierarchy
-        levels = hierarchy.levels
-        n = len(levels)
-        types = sm_type if isinstance(sm_type, (list, tuple)) else [sm_type] * n
-        if len(types) != n:
-            raise NgsAMGError("sm_type list must have one entry per level")
-        arr = (_lib.amgx_level_desc * n)()
-        self._keep = [arr]
-        for i, lv in enumerate(levels):
-            d = arr[i]
-            d.A = lv.A.desc(_lib.amgx_matrix)
-            if lv.P is not None:
-                d.P = lv.P.desc(_lib.amgx_matrix)
-                d.PT = lv.PT.desc(_lib.amgx_matrix)
-            d.dinv = _lib.ptr(lv.dinv, C.c_double)
-            d.free_dofs = _lib.ptr(lv.free, C.c_uint8)
-            if types[i] not in _SM:
-                raise NgsAMGError(f"unknown smoother type '{types[i]}' (jacobi | gs | bgs)")
-            d.sm_type = _SM[types[i]]
-            d.omega = float(omega)
-            d.sm_steps = int(sm_steps[i] if isinstance(sm_steps, (list, tuple)) else sm_steps)      # per level: ..._spec flags
-            d.sm_symm = int(bool(sm_symm[i] if isinstance(sm_symm, (list, tuple)) else sm_symm))
-            d.color = _lib.ptr(lv.color, C.c_int32)
-            d.n_colors = int(lv.n_colors)
-            g = getattr(lv, "bgs", None)
-            if types[i] == "bgs" and g is None and i + 1 < n:
-                raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")
-            if types[i] == "bgs" and g is not None:
-                self._keep.append(g)
-                d.bgs_n_blocks = int(g.n_blocks)
-                d.bgs_block_ptr, d.bgs_block_rows = _lib.ptr(g.block_ptr, C.c_int32), _lib.ptr(g.block_rows, C.c_int32)
-                d.bgs_dinv_ptr, d.bgs_dinv = _lib.ptr(g.dinv_ptr, C.c_int64), _lib.ptr(g.dinv, C.c_double)
-                d.bgs_color, d.bgs_n_colors = _lib.ptr(g.color, C.c_int32), int(g.n_colors)
-            q = getattr(lv, "Q", None)        # caller-supplied folded prolongation (rank-partitioned levels, dist.py)
-            if q is not None:
-                d.Q = q.desc(_lib.amgx_matrix)
-        desc = _lib.amgx_hierarchy_desc()
-        desc.n_levels = n
-        desc.levels = arr
-        if mg_cycle not in _lib.AMGX_CYCLE:
-            raise NgsAMGError(f"unknown mg_cycle '{mg_cycle}' (V | W | BS)")
-        desc.cycle = _lib.AMGX_CYCLE[mg_cycle]
-        if clev == "inv" and hierarchy.coarse_n == 0:
-            raise NgsAMGError("clev = inv but the hierarchy has no coarse inverse")
-        desc.clev = _lib.AMGX_CLEV_INV if clev == "inv" else _lib.AMGX_CLEV_NONE
-        desc.coarse_n = hierarchy.coarse_n if clev == "inv" else 0
-        desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
-        desc.device = int(device)
-        desc.use_graph = int(bool(use_graph))
+        desc, self._keep = hierarchy_desc(hierarchy, sm_type, omega, sm_steps, sm_symm, mg_cycle, clev, device, use_graph)
         self._h = C.c_void_p()
+        self._owned = True
         if lib.amgx_create(C.byref(desc), C.byref(self._h)) != 0:
             raise NgsAMGError(lib.amgx_last_error(None).decode())
+        self._set_sizes()
+
+    def _set_sizes(self):
+        levels = self.hierarchy.levels
         self.sizes = [lv.A.n_rows * lv.A.br for lv in levels]
         self.ext_sizes = [lv.A.n_cols * lv.A.bc for lv in levels]      # > sizes on rank-partitioned levels (ghost columns)
-        self.n_levels = n
+        self.n_levels = len(levels)
         self._stream = None
+
+    @classmethod
+    def view(cls, handle, hierarchy):
+        """borrowed handle (amgx_dist_handles): queries and measurement hooks of a hierarchy owned by a communicator"""
+        self = cls.__new__(cls)
+        self._lib = _lib.hip()
+        self.hierarchy = hierarchy
+        self._h = handle
+        self._owned = False
+        self._keep = []
+        self._cfg = {}
+        self._set_sizes()
+        return self
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and getattr(self, "_owned", True):
             self._lib.amgx_destroy(h)
-            self._h = None
+        self._h = None
 
     # ------------------------------------------------------------------------------------------
     def _ck(self, rc):

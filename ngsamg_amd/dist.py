@@ -331,8 +331,36 @@ def _peer_segments(owner):
     return seg
 
 
-def _send_lists(comm, states):
-    """every rank tells the owners which of their vertices it ghosts -> owners' send lists (symmetric peers)"""
+def interior_first(s):
+    """Renumber the owned vertices of a rank: [interior | boundary], interior = the row has no ghost column.  Kernels on
+    the interior rows then run while the halo exchange is in flight (the reference splits its local rows for the same
+    purpose: split_ind, gssmoother.cpp:664-678; stages in hybrid_base_smoother.cpp:501-574).  The peers still address
+    this rank's vertices by the old numbers; _send_lists(..., translate=True) settles that."""
+    A = sp.csr_matrix(s.A)
+    n = s.n
+    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    has_ghost = np.zeros(n, dtype=bool)
+    has_ghost[rows[A.indices >= n]] = True
+    perm = np.concatenate([np.nonzero(~has_ghost)[0], np.nonzero(has_ghost)[0]])        # new -> old
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[perm] = np.arange(n)
+    colmap = np.concatenate([iperm, n + np.arange(A.shape[1] - n)])
+    A2 = sp.csr_matrix(A[perm])
+    A2 = sp.csr_matrix((A2.data, colmap[A2.indices], A2.indptr), shape=A.shape)
+    A2.sort_indices()
+    s.A = A2
+    s.free = np.ascontiguousarray(s.free[perm])
+    if getattr(s, "coords", None) is not None:
+        s.coords = np.ascontiguousarray(s.coords[perm])
+    s.n_interior = int((~has_ghost).sum())
+    s.iperm = iperm
+    return s
+
+
+def _send_lists(comm, states, translate=False):
+    """every rank tells the owners which of their vertices it ghosts -> owners' send lists (symmetric peers).
+    translate: the owners were renumbered after the ghost tables were made (interior_first): the requests arrive in the
+    owners' old numbers, the owners answer with the new ones"""
     sends = []
     for s in states:
         d = {q: s.ghost_rindex[a:b].astype(np.int64) for q, (a, b) in _peer_segments(s.ghost_owner).items()}
@@ -340,8 +368,20 @@ def _send_lists(comm, states):
     # make the exchange symmetric: a peer I need nothing from may still need something from me
     recvs = comm.exchange(_symmetrise(comm, states, sends, np.int64))
     for s, r in zip(states, recvs):
-        s.send = {q: v for q, v in r.items() if v.size}
+        ip = getattr(s, "iperm", None) if translate else None
+        s.send = {q: (ip[v] if ip is not None else v) for q, v in r.items() if v.size}
         s.recv_seg = _peer_segments(s.ghost_owner)
+    if translate:
+        back = comm.exchange(_symmetrise(comm, states, [dict(s.send) for s in states], np.int64))
+        for s, r in zip(states, back):
+            for q, (a, b) in s.recv_seg.items():
+                if r[q].size != b - a:
+                    raise NgsAMGError("renumbered ghost table: size mismatch")
+                s.ghost_rindex[a:b] = r[q]
+            s.iperm = None
+    for s in states:
+        if not hasattr(s, "n_interior"):
+            s.n_interior = 0
 
 
 def _symmetrise(comm, states, sends, dtype):
@@ -381,6 +421,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
     o = dict(opts)
     nxt = []
     P_owns = []
+    stuck = False
     for s in states:
         A_oo = sp.csr_matrix(s.A[:, :s.n])
         kw = dict(o)
@@ -389,16 +430,37 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         kw["max_coarse_size"] = 1
         H = Hierarchy(_mat(A_oo), s.free, s.coords, dim=dim, energy=0, **{k: v for k, v in kw.items() if k not in ("dist_min_rows",)})
         if H.n_levels < 2:
-            raise NgsAMGError("distributed coarsening got stuck on a rank")
-        P = H.levels[0].P.to_scipy()
-        P_owns.append(P)
-        s.agg = np.array(H.levels[0].agg, copy=True)      # blocks of the block smoother (never cross ranks)
+            stuck = True
+            H = None
+            break
+        P = sp.csr_matrix(H.levels[0].P.to_scipy())
+        agg = np.array(H.levels[0].agg, copy=True)        # blocks of the block smoother (never cross ranks)
         c = RankState()
         c.rank = s.rank
         c.n = P.shape[1]
         c.coords = H.levels[1].coords.copy() if H.levels[1].coords is not None else None
+        # coarse numbering [interior | boundary]: a coarse row can only reach a coarse ghost through a fine row that has a
+        # ghost column, so "some fine vertex of my prolongation column is a boundary row" is a safe boundary test
+        Af = sp.csr_matrix(s.A)
+        frows = np.repeat(np.arange(s.n), np.diff(Af.indptr))
+        bnd_f = np.zeros(s.n, dtype=np.float64)
+        bnd_f[frows[Af.indices >= s.n]] = 1.0
+        bnd_c = (abs(P).T @ bnd_f) > 0
+        permc = np.concatenate([np.nonzero(~bnd_c)[0], np.nonzero(bnd_c)[0]])
+        ipermc = np.empty(c.n, dtype=np.int64)
+        ipermc[permc] = np.arange(c.n)
+        P = sp.csr_matrix((P.data, ipermc[P.indices], P.indptr), shape=P.shape)
+        P.sort_indices()
+        if c.coords is not None:
+            c.coords = np.ascontiguousarray(c.coords[permc])
+        c.n_interior = int((~bnd_c).sum())
+        s.agg = np.where(agg >= 0, ipermc[np.maximum(agg, 0)], -1).astype(np.int32)
+        P_owns.append(P)
         c.free = np.ones(c.n, dtype=np.uint8)
         nxt.append(c)
+    # a rank whose local coarsening made no progress must not leave the others waiting in the next collective: agree first
+    if any(comm.allgather([stuck for _ in states])[0]):
+        raise NgsAMGError("distributed coarsening got stuck on a rank (raise dist_min_rows or lower max_dist_levels)")
     # P rows of the ghost vertices: owners send (row lengths, coarse ids at the owner, weights) for their send lists
     cnt_s, col_s, val_s = [], [], []
     for s, P in zip(states, P_owns):
@@ -550,7 +612,9 @@ class DistributedAMG:
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
         self.fold = bool(fold) and sm_type == "jacobi"
-        _send_lists(comm, states0)
+        for s in states0:
+            interior_first(s)
+        _send_lists(comm, states0, translate=True)
         levels = [states0]
         while len(levels) <= max_dist_levels:
             cur = levels[-1]
@@ -565,6 +629,9 @@ class DistributedAMG:
         if sm_type in ("gs", "bgs"):
             for lv in levels[:-1]:
                 _hybrid_gs_data(comm, lv)
+        if sm_type == "gs":
+            for lv in levels[:-1]:
+                _gs_stages(comm, lv, opts.get("gs_stage_min_rows", 65536))
         if sm_type == "bgs":
             for lv in levels[:-1]:
                 _hybrid_bgs_data(lv)
@@ -599,10 +666,21 @@ class DistributedAMG:
         # ---- per-rank execution objects --------------------------------------------------------------------
         self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type in ("gs", "bgs")), fold=self.fold, bgs=(sm_type == "bgs"))
                      for i in range(len(states0))]
+        self._dev = None
         if backend is None:
-            backend = _device_backend(device, omega, sm_type)
+            # the product path: the whole collective cycle behind the C ABI (amgx_dist_apply): pack kernels, RCCL (or
+            # device copies between virtual ranks), stream overlap -- no Python between the stages
+            self._dev = _DeviceDist(self, device)
+            self.ops = self._dev.ops
+            return
+        # stage-by-stage driver for test backends (tests/dist_cpu_backend.py): same tables, same stage order
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
         self._alloc()
+
+    def level_k_map(self, i):
+        """level k of local rank i in its [owned | ghost] layout -> index in the gathered (replicated) vector"""
+        sk = self.dist_levels[self.k][i]
+        return np.concatenate([self.offs[sk.rank] + np.arange(sk.n), self.offs[sk.ghost_owner] + sk.ghost_rindex]).astype(np.int64)
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc(self):
@@ -635,7 +713,7 @@ class DistributedAMG:
             b["nk"] = sk.n
             if self.fold:
                 # level k in the [owned | ghost] layout of this rank, picked from the replicated tail solution
-                gmap = np.concatenate([self.offs[sk.rank] + np.arange(sk.n), self.offs[sk.ghost_owner] + sk.ghost_rindex])
+                gmap = self.level_k_map(i)
                 b["kmap"] = ops.index(gmap)
                 b["xk_ext"] = ops.zeros(gmap.size)
             self.buf.append(b)
@@ -655,10 +733,16 @@ class DistributedAMG:
     def rhs_buffer(self, i=0):
         """owned part of the level-0 right-hand-side buffer of local rank i: fill THIS tensor and pass it to Mult to
         save the copy of b into the [owned | ghost] layout (Jacobi path)"""
+        if self._dev is not None:
+            return self._dev.rhs_buffer(i)
         return self.buf[i]["bext"][0][:self.dist_levels[0][i].n]
 
-    def Mult(self, bs, xs):
-        """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind)"""
+    def Mult(self, bs, xs, b_status=1):
+        """bs[i], xs[i]: owned level-0 vectors of local rank i (tensors of the backend's kind).  Collective: every rank of
+        the communicator calls it (AMGMatrix::Mult, amg_matrix.cpp:160-307).  b_status 0 (device path only): bs[i] has
+        [owned | ghost] entries, the ghost entries are added to their owners first (DISTRIBUTED vector)"""
+        if self._dev is not None:
+            return self._dev.Mult(bs, xs, b_status)
         if self.sm_type in ("gs", "bgs"):
             return self._mult_gs(bs, xs)
         if self.fold:
@@ -837,69 +921,177 @@ class DistributedAMG:
             out.append(L)
         return out + list(self.tail_hier.levels)
 
-    def oracle_sm_types(self):
-        """per-level smoother names for oracle.pyoracle.Oracle over global_levels()"""
-        if self.sm_type == "jacobi":
-            return ["jacobi"] * (self.k + self.tail_hier.n_levels)
-        if self.sm_type == "bgs":
-            return ["bgs_mc"] * (self.k + self.tail_hier.n_levels)
-        return ["gs_order"] * self.k + ["gs_mc"] * self.tail_hier.n_levels
 
-    def oracle_bgs(self, levels):
-        """bgs=... argument for the oracle over global_levels() (block smoother only)"""
-        return [getattr(L, "bgs", None) for L in levels] if self.sm_type == "bgs" else None
+def _gs_stages(comm, states, min_rows):
+    """Stages of the hybrid Gauss-Seidel sweep as colour ranges (reference: LOC_1 = rows [0, split), EX = rows shared with
+    other ranks, LOC_2 = rows [split, N), split_ind = N/2, gssmoother.cpp:664-678, 721-782): colours are re-indexed so that
+    the first half of the interior rows comes first, then the boundary rows, then the second half of the interior rows.  The
+    exchange of x is hidden behind a local stage in both sweep directions.  Small levels keep one stage (three times the
+    colours would be three times the dependent launches)."""
+    big = min(min(x) for x in comm.allgather([s.n for s in states])) >= min_rows
+    for s in states:
+        nc = int(s.n_colors)
+        if not big or s.n_interior < 2:
+            s.gs_stage = np.array([0, 0, nc, nc], dtype=np.int32)
+            continue
+        half = s.n_interior // 2
+        grp = np.ones(s.n, dtype=np.int64)
+        grp[:half] = 0
+        grp[half:s.n_interior] = 2
+        col = np.asarray(s.color, dtype=np.int64)
+        act = col >= 0
+        key = grp[act] * (nc + 1) + col[act]
+        uniq, inv = np.unique(key, return_inverse=True)
+        newc = np.full(s.n, -1, dtype=np.int32)
+        newc[act] = inv.astype(np.int32)
+        g_of = uniq // (nc + 1)
+        s1, s2 = int((g_of == 0).sum()), int((g_of <= 1).sum())
+        s.color, s.n_colors = newc, int(uniq.size)
+        s.gs_stage = np.array([0, s1, s2, int(uniq.size)], dtype=np.int32)
 
 
-def _device_backend(device, omega, sm_type="jacobi"):
-    """execution on the GPU through the C ABI (include/amgx.h); vectors are torch CUDA tensors"""
-    import torch
-    from .device import DeviceAMGMatrix
+class _CudaBuffer:
+    """device memory owned by the native library, exposed through __cuda_array_interface__ (torch.as_tensor)"""
 
-    tails = {}
+    def __init__(self, addr, n, owner):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(addr), False), "version": 2, "strides": None}
+        self._owner = owner
 
-    class Ops:
-        def __init__(self, top, tail_hier, i):
-            types = [sm_type] * (top.n_levels - 1) + ["jacobi"]
-            self.top = DeviceAMGMatrix(top, sm_type=types, omega=omega, clev="none", device=device, use_graph=False)
-            if id(tail_hier) not in tails:
-                tails[id(tail_hier)] = DeviceAMGMatrix(tail_hier, sm_type=sm_type, omega=omega, device=device)
-            self.tail = tails[id(tail_hier)]
-            self.dev = torch.device("cuda", device)
 
-        def zeros(self, n):
-            return torch.zeros(int(n), dtype=torch.float64, device=self.dev)
+class _DeviceDist:
+    """Rank-partitioned hierarchy on the GPU(s) behind the C ABI (include/amgx.h: amgx_comm_*, amgx_dist_*).
+    LoopbackComm -> AMGX_COMM_LOCAL (all ranks in this process on one GPU), TorchComm -> AMGX_COMM_RCCL (one rank per
+    process; torch.distributed only carries the 128-byte RCCL id and the host-side setup messages)."""
 
-        def index(self, idx):
-            return torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(self.dev)
+    def __init__(self, amg, device):
+        import torch
+        from .device import DeviceAMGMatrix, hierarchy_desc
+        lib = _lib.hip()
+        self._lib, self.amg, self.device = lib, amg, int(device)
+        comm = amg.comm
+        self._comm = C.c_void_p()
+        if isinstance(comm, LoopbackComm):
+            rc = lib.amgx_comm_create(_lib.AMGX_COMM_LOCAL, comm.size, 0, None, self.device, C.byref(self._comm))
+        else:
+            uid = C.create_string_buffer(_lib.AMGX_UNIQUE_ID_BYTES)
+            if comm.rank == 0 and lib.amgx_comm_unique_id(uid) != 0:
+                raise NgsAMGError(lib.amgx_comm_last_error(None).decode())
+            ids = comm.allgather([uid.raw])[0]
+            torch.cuda.set_device(self.device)
+            rc = lib.amgx_comm_create(_lib.AMGX_COMM_RCCL, comm.size, comm.rank, ids[0], self.device, C.byref(self._comm))
+        if rc != 0:
+            raise NgsAMGError(lib.amgx_comm_last_error(None).decode())
+        k = amg.k
+        sm = amg.sm_type
+        self._dists, self.ops, self._keep = [], [], []
 
-        def gather(self, vec, idx, out):
-            torch.index_select(vec, 0, idx, out=out)
+        class _Ops:
+            pass
+        for i, top in enumerate(amg.tops):
+            types = [sm] * (top.n_levels - 1) + ["jacobi"]
+            tdesc, tkeep = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
+            ldesc, lkeep = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
+            halos = (_lib.amgx_halo_desc * k)()
+            keep = [tkeep, lkeep, halos]
+            for l in range(k):
+                s = amg.dist_levels[l][i]
+                peers = sorted(set(s.send) | set(s.recv_seg))
+                send_ptr = np.zeros(len(peers) + 1, dtype=np.int64)
+                recv_ptr = np.zeros(len(peers) + 1, dtype=np.int64)
+                idx = []
+                pos = 0
+                for j, q in enumerate(peers):
+                    v = s.send.get(q, np.empty(0, dtype=np.int64))
+                    idx.append(np.asarray(v, dtype=np.int32))
+                    send_ptr[j + 1] = send_ptr[j] + v.size
+                    a, b = s.recv_seg.get(q, (pos, pos))
+                    if a != pos:
+                        raise NgsAMGError("halo tables: ghost segments are not in peer order")
+                    pos = b
+                    recv_ptr[j + 1] = b
+                pr = np.asarray(peers, dtype=np.int32)
+                si = np.ascontiguousarray(np.concatenate(idx) if idx else np.empty(0, dtype=np.int32), dtype=np.int32)
+                h = halos[l]
+                h.n_peers = len(peers)
+                h.peer_rank, h.send_ptr, h.send_idx, h.recv_ptr = _lib.ptr(pr, C.c_int32), _lib.ptr(send_ptr, C.c_int64), _lib.ptr(si, C.c_int32), _lib.ptr(recv_ptr, C.c_int64)
+                h.n_interior = int(getattr(s, "n_interior", 0))
+                keep += [pr, send_ptr, si, recv_ptr]
+            counts = np.asarray(amg.counts, dtype=np.int64)
+            kmap = np.ascontiguousarray(amg.level_k_map(i), dtype=np.int64)
+            d = _lib.amgx_dist_desc()
+            d.top, d.tail, d.halo = tdesc, ldesc, halos
+            d.counts, d.kmap, d.kmap_len = _lib.ptr(counts, C.c_int64), _lib.ptr(kmap, C.c_int64), kmap.size
+            d.rank = int(amg.dist_levels[0][i].rank)
+            d.fold = int(amg.fold)
+            if sm == "gs":
+                st = np.ascontiguousarray(np.concatenate([amg.dist_levels[l][i].gs_stage for l in range(k)]), dtype=np.int32)
+                d.gs_stage = _lib.ptr(st, C.c_int32)
+                keep.append(st)
+            keep += [counts, kmap]
+            hd = C.c_void_p()
+            if lib.amgx_dist_create(self._comm, C.byref(d), C.byref(hd)) != 0:
+                raise NgsAMGError(lib.amgx_comm_last_error(self._comm).decode())
+            self._dists.append(hd)
+            self._keep.append(keep)
+            ht, hl = C.c_void_p(), C.c_void_p()
+            lib.amgx_dist_handles(hd, C.byref(ht), C.byref(hl))
+            o = _Ops()
+            o.top, o.tail = DeviceAMGMatrix.view(ht, top), DeviceAMGMatrix.view(hl, amg.tail_hier)
+            self.ops.append(o)
+        self._keep = []           # the native side copied everything
+        self._stream = None
+        self._rhs = {}
 
-        def jacobi_pre(self, l, bext, x, r):
-            self.top.JacobiPre(l, bext, x, r)
+    def __del__(self):
+        c = getattr(self, "_comm", None)
+        if c:
+            for o in getattr(self, "ops", []):
+                o.top._h = o.tail._h = None
+            self._lib.amgx_comm_destroy(c)
+            self._comm = None
 
-        def cycle_down(self, l, bext, x, bc):
-            self.top.CycleDown(l, bext, x, bc)
+    def _ck(self, rc):
+        if rc != 0:
+            raise NgsAMGError(self._lib.amgx_comm_last_error(self._comm).decode())
 
-        def cycle_up(self, l, x, xc_ext):
-            self.top.CycleUp(l, x, xc_ext)
+    def rhs_buffer(self, i=0):
+        import torch
+        if i not in self._rhs:
+            p, n, ne = C.c_void_p(), C.c_int64(), C.c_int64()
+            self._lib.amgx_dist_rhs_buffer(self._dists[i], C.byref(p), C.byref(n), C.byref(ne))
+            t = torch.as_tensor(_CudaBuffer(p.value, ne.value, self), device=torch.device("cuda", self.device))
+            self._rhs[i] = (t, n.value)
+        t, n = self._rhs[i]
+        return t[:n]
 
-        def restrict(self, l, r, bc):
-            self.top.TransferF2C(l, r, bc)
+    def rhs_buffer_ext(self, i=0):
+        self.rhs_buffer(i)
+        return self._rhs[i][0]
 
-        def prolong(self, l, x, xc, out):
-            self.top.Prolong(l, 1.0, x, xc, out)
+    def Mult(self, bs, xs, b_status=1):
+        import torch
+        st = int(torch.cuda.current_stream().cuda_stream)
+        if st != self._stream:
+            self._ck(self._lib.amgx_comm_set_stream(self._comm, C.c_void_p(st)))
+            self._stream = st
+        n = len(self._dists)
+        if len(bs) != n or len(xs) != n:
+            raise NgsAMGError("Mult: one b and one x per local rank")
+        for i, (b, x) in enumerate(zip(bs, xs)):
+            s = self.amg.dist_levels[0][i]
+            nb = s.n if b_status else s.n + s.ghost_owner.size
+            for v, m, nm in ((b, nb, "b"), (x, s.n, "x")):
+                if not (v.is_cuda and v.dtype == torch.float64 and v.is_contiguous() and v.numel() == m):
+                    raise NgsAMGError(f"{nm}[{i}]: need a contiguous float64 CUDA tensor with {m} entries")
+        pb = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        self._ck(self._lib.amgx_dist_apply(self._comm, pb, px, int(b_status), _lib.AMGX_DEVICE_PTR))
+        return xs
 
-        def jacobi_post(self, l, text, b, x):
-            self.top.JacobiPost(l, text, b, x)
+    def n_exchanges(self):
+        ne = C.c_int64()
+        self._ck(self._lib.amgx_comm_info(self._comm, None, None, None, C.byref(ne)))
+        return ne.value
 
-        def tail_apply(self, b, x):
-            self.tail.Mult(b, x)
-
-        def gs_sweep(self, l, back, xext, b, scratch):
-            self.top.Smooth(l, xext, b, scratch, False, False, False, back=bool(back))
-
-        def residual(self, l, xext, b, r):
-            self.top.Residual(l, xext, b, r)
-
-    return lambda top, tail_hier, i: Ops(top, tail_hier, i)
+    def synchronize(self):
+        self._ck(self._lib.amgx_comm_synchronize(self._comm))

@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 from ngsamg_amd import dist as D                      # noqa: E402
 from oracle.pyoracle import Oracle                    # noqa: E402
 from tests.dist_cpu_backend import cpu_backend        # noqa: E402
+from tests.dist_oracle import oracle_bgs, oracle_sm_types   # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 CASES = {"hybrid_poisson2d_2x2": dict(R=4, box=(9, 9), dim=2, dmin=30),
@@ -44,7 +45,7 @@ def main():
         for sm in ("jacobi", "gs", "bgs"):
             amg, b, x = run(case, sm)
             glv = amg.global_levels()
-            ref = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv)).apply(b)
+            ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(b)
             assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.norm(ref)
             d[f"{sm}_V"] = ref
             d[f"{sm}_k"] = np.int64(amg.k)

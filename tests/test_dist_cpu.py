@@ -9,6 +9,7 @@ import torch
 from ngsamg_amd import dist as D
 from oracle.pyoracle import Oracle
 from tests.dist_cpu_backend import cpu_backend
+from tests.dist_oracle import oracle_bgs, oracle_sm_types
 
 
 def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
@@ -22,7 +23,7 @@ def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
     xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
     amg.Mult(bs, xs)
     glv = amg.global_levels()
-    ref = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv)).apply(np.concatenate([b.numpy() for b in bs]))
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate([b.numpy() for b in bs]))
     got = np.concatenate([x.numpy() for x in xs])
     return amg, got, ref
 
@@ -46,7 +47,7 @@ def test_loopback_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin):
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
     # and the hybrid smoother still gives a convergent preconditioner: PCG on the global system
     glv = amg.global_levels()
-    orc = Oracle(glv, sm_type=amg.oracle_sm_types())
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg))
     rng = np.random.default_rng(5)
     b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
     _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)
@@ -60,7 +61,7 @@ def test_loopback_hybrid_block_gs_matches_serial_hybrid_oracle(R, box, dim, dmin
     amg, got, ref = _run_loopback(R, box, dim, dmin, "bgs")
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
     glv = amg.global_levels()
-    orc = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv))
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
     rng = np.random.default_rng(5)
     b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
     _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)

@@ -70,6 +70,7 @@ def test_loopback_device_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmi
     import torch
     from ngsamg_amd import dist as D
     from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
@@ -82,7 +83,7 @@ def test_loopback_device_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmi
         amg.Mult(bs, xs)
     torch.cuda.synchronize()
     glv = amg.global_levels()
-    ref = Oracle(glv, sm_type=amg.oracle_sm_types(), bgs=amg.oracle_bgs(glv)).apply(np.concatenate(bh))
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
 
@@ -109,17 +110,134 @@ def test_loopback_device_reproduces_hybrid_fixture(name, R, box, dim, dmin, sm, 
     assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref)
 
 
-def test_rccl_point_to_point_self_loop():
-    """the RCCL branch of TorchComm.halo (batch_isend_irecv on device tensors, stream-ordered wait) on ONE GPU: world size
-    1, the rank sends to and receives from itself; run in a child process (its own process group)"""
+def _run_check(*argv, timeout=600):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selfloop.py")], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "correct = True" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "RCCL CHECK PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("sm", ["jacobi", "gs"])
+def test_rccl_world_size_one(sm):
+    """The native driver over a real RCCL communicator on ONE GPU (child process): ncclCommInitRank, the all-gather of
+    level k, and -- through a halo map whose only peer is the rank itself -- pack kernel + ncclSend / ncclRecv in one group
+    straight into the ghost segment, and the add direction.  More ranks need more GPUs: tests/test_gpu_multi.py."""
+    out = _run_check("--world", "1", "--box", "20", "--sm", sm)
+    assert "self-loop halo ok = True" in out
+
+
+def _halo_tables(R, n, rng):
+    """random symmetric exchange pattern between R virtual ranks: rank p ghosts a random subset of every other rank's rows"""
+    want = {(p, q): np.sort(rng.choice(n[q], size=int(rng.integers(0, max(1, n[q] // 3))), replace=False)).astype(np.int32)
+            for p in range(R) for q in range(R) if p != q}
+    return want
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_halo_exchange_local_ranks(bs):
+    """amgx_halo_exchange = DCCMap: owner -> ghost overwrite (CO2CU) and ghost -> owner add with zeroed ghosts (DIS2CO),
+    hand-written pack / unpack kernels, R virtual ranks on one GPU; checked against numpy"""
+    import ctypes as C
+    import torch
+    from ngsamg_amd import _lib
+    lib = _lib.hip()
+    rng = np.random.default_rng(7)
+    R = 4
+    n = [int(v) for v in rng.integers(50, 400, size=R)]
+    want = _halo_tables(R, n, rng)
+    comm = C.c_void_p()
+    assert lib.amgx_comm_create(_lib.AMGX_COMM_LOCAL, R, 0, None, 0, C.byref(comm)) == 0
+    halos, keep, vecs, host = [], [], [], []
+    for p in range(R):
+        peers = np.array([q for q in range(R) if q != p], dtype=np.int32)
+        send = [want[(q, p)] for q in peers]            # rows of mine that q ghosts
+        recv = [want[(p, q)].size for q in peers]
+        sp = np.concatenate([[0], np.cumsum([v.size for v in send])]).astype(np.int64)
+        rp = np.concatenate([[0], np.cumsum(recv)]).astype(np.int64)
+        si = np.ascontiguousarray(np.concatenate(send), dtype=np.int32)
+        d = _lib.amgx_halo_desc()
+        d.n_peers = peers.size
+        d.peer_rank, d.send_ptr, d.send_idx, d.recv_ptr = _lib.ptr(peers, C.c_int32), _lib.ptr(sp, C.c_int64), _lib.ptr(si, C.c_int32), _lib.ptr(rp, C.c_int64)
+        h = C.c_void_p()
+        assert lib.amgx_halo_create(comm, C.byref(d), n[p], int(rp[-1]), bs, p, C.byref(h)) == 0, lib.amgx_comm_last_error(comm)
+        halos.append(h)
+        keep += [peers, sp, rp, si]
+        v = rng.standard_normal((n[p] + int(rp[-1])) * bs)
+        host.append(v.reshape(-1, bs).copy())
+        vecs.append(torch.from_numpy(v).cuda())
+    hp = (C.c_void_p * R)(*halos)
+    vp = (C.c_void_p * R)(*[v.data_ptr() for v in vecs])
+    assert lib.amgx_halo_exchange(comm, R, hp, vp, 0) == 0, lib.amgx_comm_last_error(comm)
+    lib.amgx_comm_synchronize(comm)
+    exp = [h.copy() for h in host]
+    for p in range(R):
+        off = n[p]
+        for q in range(R):
+            if q == p:
+                continue
+            w = want[(p, q)]
+            exp[p][off:off + w.size] = host[q][w]
+            off += w.size
+    for p in range(R):
+        assert np.array_equal(vecs[p].cpu().numpy().reshape(-1, bs), exp[p])
+    assert lib.amgx_halo_exchange(comm, R, hp, vp, 1) == 0, lib.amgx_comm_last_error(comm)
+    lib.amgx_comm_synchronize(comm)
+    exp2 = [h.copy() for h in exp]
+    for p in range(R):
+        off = n[p]
+        for q in range(R):
+            if q == p:
+                continue
+            w = want[(p, q)]
+            np.add.at(exp2[q], w, exp[p][off:off + w.size])
+            off += w.size
+        exp2[p][n[p]:] = 0.0
+    for p in range(R):
+        assert np.allclose(vecs[p].cpu().numpy().reshape(-1, bs), exp2[p], rtol=1e-15, atol=0)
+    for h in halos:
+        lib.amgx_halo_destroy(h)
+    lib.amgx_comm_destroy(comm)
+
+
+def test_overlap_split_equals_unsplit(monkeypatch):
+    """interior rows processed while the exchange is in flight + boundary rows afterwards == one pass over all rows; also
+    b_status = 0 (DISTRIBUTED right-hand side: ghost entries are contributions to the owners, added first)"""
+    import torch
+    from ngsamg_amd import dist as D
+    R, box = 4, (14, 14, 14)
+    res = []
+    for no_overlap in (False, True):
+        if no_overlap:
+            monkeypatch.setenv("AMGX_DIST_NO_OVERLAP", "1")
+        comm = D.LoopbackComm(R)
+        states = [D.assemble_poisson_owned(r, D.proc_grid(R, 3), box) for r in range(R)]
+        amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=100, device=0, max_coarse_size=10)
+        assert all(s.n_interior > 0 for s in states)
+        rng = np.random.default_rng(2)
+        bh = [rng.standard_normal(s.n) * s.free for s in states]
+        xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in states]
+        amg.Mult([torch.from_numpy(b).cuda() for b in bh], xs)
+        torch.cuda.synchronize()
+        res.append(np.concatenate([x.cpu().numpy() for x in xs]))
+        if not no_overlap:
+            # the same right-hand side handed over in DISTRIBUTED form: every owner keeps a random share of its entries that
+            # a peer ghosts, the rest sits in the peers' ghost entries
+            ext = [np.concatenate([b, np.zeros(s.ghost_owner.size)]) for b, s in zip(bh, states)]
+            for p, s in enumerate(states):
+                for q, (a, e) in s.recv_seg.items():
+                    rows = states[q].send[p]
+                    share = rng.uniform(0.1, 0.9, size=rows.size)
+                    ext[p][s.n + a:s.n + e] = share * bh[q][rows]
+                    ext[q][rows] -= share * bh[q][rows]
+            xd = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in states]
+            amg.Mult([torch.from_numpy(v).cuda() for v in ext], xd, b_status=0)
+            torch.cuda.synchronize()
+            got = np.concatenate([x.cpu().numpy() for x in xd])
+            assert np.linalg.norm(got - res[0]) <= 1e-12 * np.linalg.norm(res[0])
+    assert np.linalg.norm(res[0] - res[1]) <= 1e-14 * np.linalg.norm(res[1])
 
 
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (3, (20, 9, 9), 3, 100)])

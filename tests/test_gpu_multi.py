@@ -1,0 +1,38 @@
+"""Rank-partitioned V-cycle on SEVERAL GPUs: one process per GPU, RCCL over xGMI through the C ABI (amgx_comm_create /
+amgx_dist_apply), against the serial CPU oracle on the assembled global hierarchy.  Skipped on boxes with fewer GPUs than
+ranks (counting devices does not initialise the GPU, so the child ranks start from a clean process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _run(*argv, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and "RCCL CHECK PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("sm,extra", [("jacobi", []), ("jacobi", ["--no-fold"]), ("gs", []), ("bgs", [])])
+def test_rccl_ranks_match_serial_oracle(world, sm, extra):
+    """cfg 4's arrangement (2 x 2 x 2 boxes at world 8; 2 x 1 x 1, 2 x 2 x 1 below) at a size the oracle finishes in seconds"""
+    if _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run("--world", str(world), "--box", "28", "--sm", sm, *extra)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_rccl_slab_partition_as_in_bench(world):
+    """bench.py --gpus N stacks the ranks as slabs (N, 1, 1)"""
+    if _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run("--world", str(world), "--box", "24", "--pgrid", "slab")
