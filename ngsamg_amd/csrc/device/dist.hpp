@@ -112,10 +112,17 @@ struct Comm {
   std::vector<Dist*> members;            // local ranks in creation order (RCCL: exactly one)
   std::string err;
   int64_t n_exchanges = 0;               // statistics: halo exchanges started
+  // Cross-stream ordering.  Measured on MI355X (tools/sync_lab.hip, profiles/r02/sync_lab.txt): one exchange-shaped
+  // dependency pair costs 15 us of stream time with hipEventRecord / hipStreamWaitEvent and 9 us with
+  // hipStreamWriteValue64 / hipStreamWaitValue64 on a device flag; the latter is used where the device supports it.
+  uint64_t* flags = nullptr;             // 2 * NEV counters, one cache line each
+  uint64_t epoch = 0;
+  bool use_values = false;
 
   Comm() { for (int i = 0; i < NEV; ++i) { ev_ready[i] = nullptr; ev_done[i] = nullptr; } }
   ~Comm() {
     for (int i = 0; i < NEV; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
+    if (flags) (void)hipFree(flags);
     if (nccl) (void)Rccl::get().CommDestroy(nccl);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     if (own_compute) (void)hipStreamDestroy(own_compute);
@@ -133,7 +140,37 @@ struct Comm {
       HIPCHK(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
     }
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
+    use_values = can && !std::getenv("AMGX_DIST_EVENTS");
+    if (use_values) {
+      HIPCHK(hipMalloc((void**)&flags, 2 * NEV * 64));
+      HIPCHK(hipMemset(flags, 0, 2 * NEV * 64));
+    }
   }
+  // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+  void order(hipStream_t from, hipStream_t to, int slot, hipEvent_t ev) {
+    if (use_values) {
+      uint64_t* f = flags + slot * 8;
+      ++epoch;
+      HIPCHK(hipStreamWriteValue64(from, f, epoch, 0));
+      HIPCHK(hipStreamWaitValue64(to, f, epoch, hipStreamWaitValueGte, 0xffffffffffffffffull));
+    } else {
+      HIPCHK(hipEventRecord(ev, from));
+      HIPCHK(hipStreamWaitEvent(to, ev, 0));
+    }
+  }
+  // split form: the signal is enqueued now, the wait later (exchange_end)
+  uint64_t signal(hipStream_t from, int slot, hipEvent_t ev) {
+    if (use_values) { ++epoch; HIPCHK(hipStreamWriteValue64(from, flags + slot * 8, epoch, 0)); return epoch; }
+    HIPCHK(hipEventRecord(ev, from));
+    return 0;
+  }
+  void wait(hipStream_t to, int slot, hipEvent_t ev, uint64_t value) {
+    if (use_values) HIPCHK(hipStreamWaitValue64(to, flags + slot * 8, value, hipStreamWaitValueGte, 0xffffffffffffffffull));
+    else HIPCHK(hipStreamWaitEvent(to, ev, 0));
+  }
+  uint64_t done_value[NEV] = {0};
 
   // ---- halo exchange.  items[i] = (table, vector) of local member i.  Returns a ticket for exchange_end. -------------
   struct Item { HaloTable* t; double* vec; };
@@ -142,8 +179,7 @@ struct Comm {
   int exchange_begin(const std::vector<Item>& items) {
     const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
     ++n_exchanges;
-    HIPCHK(hipEventRecord(ev_ready[tk], compute));                 // everything the vectors depend on is enqueued
-    HIPCHK(hipStreamWaitEvent(comm_stream, ev_ready[tk], 0));
+    order(compute, comm_stream, tk, ev_ready[tk]);                 // everything the vectors depend on is enqueued
     for (const Item& it : items) {
       const int64_t len = it.t->n_send() * it.t->bs;
       if (len) hipLaunchKernelGGL(halo_pack_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, comm_stream, len, it.t->bs,
@@ -179,17 +215,16 @@ struct Comm {
         }
       }
     }
-    HIPCHK(hipEventRecord(ev_done[tk], comm_stream));
+    done_value[tk] = signal(comm_stream, NEV + tk, ev_done[tk]);
     return tk;
   }
-  void exchange_end(int ticket) { HIPCHK(hipStreamWaitEvent(compute, ev_done[ticket], 0)); }
+  void exchange_end(int ticket) { wait(compute, NEV + ticket, ev_done[ticket], done_value[ticket]); }
 
   // ghost -> owner, add, ghost entries zeroed afterwards (reference DIS2CO: BufferG, send, ApplyM; dcc_map.cpp:76-136, 249-274)
   void accumulate(const std::vector<Item>& items) {
     const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
     ++n_exchanges;
-    HIPCHK(hipEventRecord(ev_ready[tk], compute));
-    HIPCHK(hipStreamWaitEvent(comm_stream, ev_ready[tk], 0));
+    order(compute, comm_stream, tk, ev_ready[tk]);
     if (kind == AMGX_COMM_RCCL) {
       Rccl& R = Rccl::get();
       const HaloTable& t = *items[0].t;
@@ -230,8 +265,7 @@ struct Comm {
       }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ev_done[tk], comm_stream));
-    HIPCHK(hipStreamWaitEvent(compute, ev_done[tk], 0));
+    order(comm_stream, compute, NEV + tk, ev_done[tk]);
   }
 };
 
@@ -361,6 +395,9 @@ struct DistCycle {
   std::vector<Dist*>& M;
   std::vector<double*> x;                // level-0 solution vectors (device)
   using Span = Handle::Span;
+  // replicated tail: direct launches by default -- a graph launch between directly launched kernels costs ~10 us of
+  // stream time (profiles/r02/trace_dist_world1.txt), the tail's handful of kernels do not pay that back
+  bool tail_graph = std::getenv("AMGX_DIST_TAIL_GRAPH") != nullptr;
 
   std::vector<Comm::Item> items(int l, int which) {      // which: 0 bext, 1 xext, 2 text
     std::vector<Comm::Item> it;
@@ -393,7 +430,7 @@ struct DistCycle {
 
   void tail_and_pick() {
     for (Dist* d : M) {
-      d->tail->run_cycle(d->xglob.p, d->bglob.p, true);
+      d->tail->run_cycle(d->xglob.p, d->bglob.p, tail_graph);
       const int64_t len = d->next(d->k);
       if (len) hipLaunchKernelGGL(index_gather_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, c.compute, len, d->kmap.p, d->xglob.p, d->xk_ext.p);
       HIPCHK(hipGetLastError());

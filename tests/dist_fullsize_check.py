@@ -15,7 +15,9 @@ def main():
     import torch
     from ngsamg_amd import dist as D
     from oracle.pyoracle import Oracle
-    R, box = 2, (108, 215, 215)
+    R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    box = tuple(int(v) for v in sys.argv[2].split("x")) if len(sys.argv) > 2 else (108, 215, 215)
+    check = (sys.argv[3] != "nocheck") if len(sys.argv) > 3 else True
     comm = D.LoopbackComm(R)
     t0 = time.time()
     states = [D.assemble_poisson_owned(r, (R, 1, 1), box) for r in range(R)]
@@ -36,7 +38,10 @@ def main():
     for _ in range(20):
         amg.Mult(bs, xs)
     torch.cuda.synchronize()
-    print(f"cycle of both ranks: {(time.perf_counter() - t) / 20 * 1e3:.3f} ms", flush=True)
+    dt = (time.perf_counter() - t) / 20 * 1e3
+    print(f"cycle of all {R} virtual ranks (box {box}): {dt:.3f} ms = {dt / R:.3f} ms per rank; exchanges per cycle {amg._dev.n_exchanges() // 23}", flush=True)
+    if not check:
+        return
     glv = amg.global_levels()
     ref = Oracle(glv, sm_type="jacobi", threads=16).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
