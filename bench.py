@@ -32,8 +32,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+_RESULT_FD = None
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def emit(line):
+    """the one result line, on the process's original stdout"""
+    data = (line.rstrip("\n") + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
 
 
 def run_distributed(args, torch, dist, world, rank, device, nv):
@@ -50,7 +63,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
     t1 = time.time()
     amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10,
-                           sm_type=args.smoother)
+                           sm_type="jacobi" if args.smoother == "jacobi" else "gs")
     t2 = time.time()
     lib = _lib.hip()
     kind, nr, rk = C.c_int32(), C.c_int32(), C.c_int32()
@@ -140,7 +153,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
                          "algorithmic_bytes": int(spmv_bytes), "cycle_algorithmic_bytes_per_rank": int(per_rank),
                          "algorithmic_model_GBs_per_gpu": round(per_rank / (ms_per_step * 1e-3) / 1e9, 1)},
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     dist.destroy_process_group()
 
 
@@ -180,7 +193,7 @@ def self_launch(args):
     if res.get("n_gpus") != args.gpus or res.get("rccl_ranks") != args.gpus:
         log(f"only {res.get('rccl_ranks')} of {args.gpus} ranks joined the RCCL communicator")
         raise SystemExit(1)
-    print(line, flush=True)
+    emit(line)
 
 
 def main():
@@ -189,12 +202,20 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nv", type=int, default=215, help="vertices per direction (215 = cfg 2)")
-    ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "gs"])
+    ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "gs", "gs_mc"],
+                    help="gs = Gauss-Seidel in the block-hybrid form (one launch per sweep); gs_mc = multicolour Gauss-Seidel (one launch per colour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ops", action="store_true", help="print HIP-event timings of the individual kernels per level")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the result): everything libraries print (RCCL / gloo banners) goes to stderr
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -259,7 +280,8 @@ def main():
     t1 = time.time()
     H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
     t2 = time.time()
-    amg = DeviceAMGMatrix(H, sm_type=args.smoother, omega=0.9, mg_cycle="V", clev="inv", device=device,
+    dev_sm = {"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother]
+    amg = DeviceAMGMatrix(H, sm_type=dev_sm, omega=0.9, mg_cycle="V", clev="inv", device=device,
                           use_graph=not args.no_graph)
     t3 = time.time()
     if rank == 0:
@@ -395,6 +417,8 @@ def main():
                 cores = max(1, min(cores, int(int(q) // int(per))))
         except (OSError, ValueError):
             pass
+        # Gauss-Seidel: the CPU baseline is the reference's sequential sweep; parity of the GPU result is checked against
+        # the oracle run in the GPU's own order (block-hybrid: tests/hgs_oracle.py, multicolour: gs_mc)
         orc = Oracle(H.levels, sm_type="jacobi" if args.smoother == "jacobi" else "gs", omega=0.9, threads=cores)
         if cores > 1:
             orc.first_touch()                    # NUMA placement: every thread first-writes the rows it streams
@@ -408,7 +432,15 @@ def main():
         for _ in range(reps):
             orc.apply(b_host, xo)
         cpu_t = (time.perf_counter() - tc0) / reps
-        parity = float(np.linalg.norm(x.cpu().numpy() - xo) / np.linalg.norm(xo))
+        if args.smoother == "gs":
+            from tests.hgs_oracle import hgs_levels
+            plv, ptypes = hgs_levels(H.levels, amg.hgs)
+            xp = Oracle(plv, sm_type=ptypes, omega=0.9, threads=cores).apply(b_host)
+        elif args.smoother == "gs_mc":
+            xp = Oracle(H.levels, sm_type="gs_mc", omega=0.9, threads=cores).apply(b_host)
+        else:
+            xp = xo
+        parity = float(np.linalg.norm(x.cpu().numpy() - xp) / np.linalg.norm(xp))
         # north_star: "iteration count and residual norm" of the Krylov solve the preconditioner sits in, GPU and CPU:
         # PCG to 1e-8 on A x = b, both with the criterion of the reference's drivers (err_k = sqrt(<C r_k, r_k>))
         pcg = None
@@ -465,10 +497,13 @@ def main():
 
     # Gauss-Seidel: iteration counts of PCG (1e-8) with the GPU's sweep order and with the reference's sequential order
     gs_its = None
-    if args.smoother == "gs" and rank == 0 and not args.no_cpu_baseline:
+    if args.smoother in ("gs", "gs_mc") and rank == 0 and not args.no_cpu_baseline:
         try:
             from oracle.pyoracle import Oracle as _O
-            it_gpu = _O(H.levels, sm_type="gs_mc", threads=cores).pcg(b_host, tol=1e-8, maxit=200)[1]
+            if args.smoother == "gs":
+                it_gpu = _O(plv, sm_type=ptypes, threads=cores).pcg(b_host, tol=1e-8, maxit=200)[1]
+            else:
+                it_gpu = _O(H.levels, sm_type="gs_mc", threads=cores).pcg(b_host, tol=1e-8, maxit=200)[1]
             it_seq = _O(H.levels, sm_type="gs", threads=cores).pcg(b_host, tol=1e-8, maxit=200)[1]
             gs_its = {"tol": 1e-8, "gpu_order_iterations": int(it_gpu), "sequential_order_iterations": int(it_seq)}
         except Exception as e:
@@ -495,7 +530,7 @@ def main():
             out["gs_iterations"] = gs_its
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -74,6 +74,13 @@ void amgh_destroy(amgh_hierarchy* h);
  * reference src/base/smoothers/python_smoothers.cpp:144-387) */
 int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, double* dinv_out);
 int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors);
+/* Block-hybrid Gauss-Seidel (amgx_level_desc.gs_block_rows): blocks of block_rows consecutive rows are swept like the
+ * ranks of the reference's HybridGSSmoother (gssmoother.cpp:709-861) -- Gauss-Seidel inside a block, couplings that leave
+ * the block frozen at their sweep-start values.  amgh_coloring_blocked: greedy colouring that only sees couplings inside a
+ * block; amgh_hybrid_dinv: inverse of the l1-type modified diagonal md = max(1, 0.51 (1 + ad)) d with ad_k = sum over the
+ * couplings leaving the block of |a_kj| / sqrt(d_k d_j)  (CalcModDiag, hybrid_smoother_utils.hpp:35-142); scalar matrices */
+int amgh_coloring_blocked(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int32_t* color_out, int32_t* n_colors);
+int amgh_hybrid_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, double* dinv_out);
 
 /* Block Gauss-Seidel data (reference BSmoother, src/base/smoothers/block_gssmoother.cpp:17-150).  Blocks are sets of
  * block rows -- the aggregates of the level, as GetGSBlocks builds them (amg_pc_vertex_impl.hpp:1171-1269); block k owns

@@ -76,6 +76,13 @@ typedef struct amgx_level_desc {
                               /*   Square levels: the library builds it itself.  Rank-partitioned levels (A has ghost  */
                               /*   columns): the caller, who holds the P rows of the ghost vertices, supplies it; its    */
                               /*   columns index the coarse level's [owned | ghost] vector (see amgx_cycle_up).          */
+  int32_t gs_block_rows;      /* AMGX_SM_GS, scalar levels: 0 = multicolour Gauss-Seidel over the whole level (one launch per  */
+                              /*   colour); B > 0 = BLOCK-HYBRID Gauss-Seidel, one launch per sweep: blocks of B consecutive  */
+                              /*   rows (B = 1024, 512, ..., 64) are swept like the ranks of the reference's hybrid smoother   */
+                              /*   (gssmoother.cpp:709-861): GS inside a block in colour order, couplings that leave the block */
+                              /*   frozen at their sweep-start values.  `color` then only has to separate coupled rows of the  */
+                              /*   SAME block (amgh_coloring_blocked) and `dinv` should be the inverse of the l1-modified      */
+                              /*   diagonal (amgh_hybrid_dinv).  Rows may have at most 16 * (1024 / B) + 1 entries.            */
 } amgx_level_desc;
 
 typedef struct amgx_hierarchy_desc {

@@ -111,6 +111,19 @@ struct DevGS {                          // colour-major data for multicolour Gau
   DevBuf<int32_t> rowlist;
 };
 
+struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_kernel): blocks of B consecutive rows
+  int B = 0, G = 1, TH = 1024;          // rows per block, lanes per row, workgroup size (B * G == TH)
+  int n_blocks = 0, n_colors = 0;
+  DevMatrix::Sell full, lowin;          // block-local SELL-G copies (slots colour-sorted inside a block): all entries /
+                                        //   only the in-block couplings to LOWER colours (forward sweep from x = 0)
+  DevBuf<int32_t> rowid;
+  DevBuf<uint8_t> slotcolor;
+  DevMatrix rest;                       // natural-order copy of everything `lowin` leaves out, without the diagonal
+  DevBuf<double> cvec;                  // 1 / dinv - a_kk: r = c .* x - rest x right after the sweep from zero
+  bool has_split = false;
+  bool on() const { return B > 0; }
+};
+
 struct DevBGS {                         // block Gauss-Seidel over aggregate blocks (bgs_block_kernel)
   int n_colors = 0;
   int max_m = 0;                        // largest block (scalar dofs)
@@ -155,6 +168,8 @@ struct DevLevel {
   DevMatrix Q;                          // scalar Jacobi levels of the V-cycle: (I - omega*Dinv*A) P, see fold_prolongation()
   DevBuf<double> dinv;
   DevGS gs;
+  DevGSB gsb;
+  DevRestrict RG;                       // chunk-local P^T for the fused residual + restriction after a block-hybrid sweep
   DevBGS bgs;
   int sm_type = AMGX_SM_JACOBI;
   double omega = 0.9;
@@ -787,6 +802,7 @@ struct Handle {
   void gs_sweep(const DevLevel& L, int dir, double* x, const double* b, bool lower_only = false, int cbeg = 0, int cend = -1) {
     const DevGS& g = L.gs;
     const DevMatrix::Sell& copy = (lower_only && g.has_split) ? g.lower : g.sell;
+    if (L.gsb.on()) throw Err("gs_sweep: the level uses the block-hybrid form");
     if (g.n_colors == 0 && L.n > 0) throw Err("Gauss-Seidel requested but the level has no colouring");
     if (cend < 0 || cend > g.n_colors) cend = g.n_colors;
     for (int q = cbeg; q < cend; ++q) {
@@ -825,6 +841,25 @@ struct Handle {
       }
       HIPCHK(hipGetLastError());
     }
+  }
+
+  // one block-hybrid Gauss-Seidel sweep (gsb_sweep_kernel): ONE launch; xin == nullptr: sweep from x = 0
+  void gsb_sweep(const DevLevel& L, int dir, const DevMatrix::Sell& copy, const double* xin, double* xout, const double* b) {
+    const DevGSB& g = L.gsb;
+    if (g.n_blocks == 0) return;
+    if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
+    GsbArgs a{g.rowid.p, g.slotcolor.p, L.dinv.p, b, g.n_colors, dir};
+    const SellMat M = copy.view();
+    const bool fz = xin == nullptr;
+#define LAUNCH_GSB3(TT, GG, ZZ) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ>), dim3(g.n_blocks), dim3(TT), 0, stream, L.n, 0, M, a, xin, xout)
+#define LAUNCH_GSB2(TT, GG) { if (fz) LAUNCH_GSB3(TT, GG, true); else LAUNCH_GSB3(TT, GG, false); }
+#define LAUNCH_GSB(TT) switch (g.G) { case 1: LAUNCH_GSB2(TT, 1); break; case 2: LAUNCH_GSB2(TT, 2); break; case 4: LAUNCH_GSB2(TT, 4); break; \
+                                      case 8: LAUNCH_GSB2(TT, 8); break; default: LAUNCH_GSB2(TT, 16); break; }
+    if (g.TH == 256) LAUNCH_GSB(256) else if (g.TH == 512) LAUNCH_GSB(512) else LAUNCH_GSB(1024)
+#undef LAUNCH_GSB
+#undef LAUNCH_GSB2
+#undef LAUNCH_GSB3
+    HIPCHK(hipGetLastError());
   }
 
   // one block Gauss-Seidel sweep: colours of the block graph ascending (forward) or descending (backward)
@@ -890,6 +925,11 @@ struct Handle {
       // row-transpose scatters when asked for it; here: gather (RHS) form + one residual SpMV, same x and res
       bgs_sweep(L, dir, x, b);
       if (update_res) residual(L.A, x, b, res);
+    } else if (L.gsb.on()) {
+      // block-hybrid sweep (out of place: the off-block values are those from the start of the sweep)
+      copy(L.tmp.p, x, L.ext_len());
+      gsb_sweep(L, dir, L.gsb.full, L.tmp.p, x, b);
+      if (update_res) residual(L.A, x, b, res);
     } else {
       // GSS3::Smooth / SmoothBack (gssmoother.cpp:350-398).  The reference keeps the residual current with
       // row-transpose scatters (RES form); for symmetric A the gather (RHS) form followed by one residual
@@ -937,6 +977,17 @@ struct Handle {
         diag_apply(L, b, x, false);          // x = omega * Dinv * b      (x was zero, res == b)
         residual(L.A, x, b, r);              // r = b - A x
         if (fold) diag_apply(L, r, x, true); // z = x + omega * Dinv * r  (folded post-smoothing, see fold_prolongation)
+      }
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on()) {
+      // forward block-hybrid sweep from x = 0: inside a block only couplings to lower colours contribute (all other
+      // values are still 0); afterwards (b - L_in x)_k = x_k / dinv_k on every swept row, hence
+      // r = b - A x = (1/dinv - a_kk) .* x - (A - L_in - D) x = c .* x - rest x
+      if (L.gsb.has_split) {
+        gsb_sweep(L, 0, L.gsb.lowin, nullptr, x, b);
+        spmv_ep<EP_CRES>(L.gsb.rest, x, r, EpArgs{x, nullptr, L.gsb.cvec.p, 0.0, nullptr, ep_nt & EPF_HOIST});
+      } else {
+        gsb_sweep(L, 0, L.gsb.full, nullptr, x, b);
+        residual(L.A, x, b, r);
       }
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gs.has_split && L.bs == 1) {
       // forward sweep from x = 0: only couplings to lower colours contribute; afterwards b - L x - D x = 0 on every
@@ -1002,6 +1053,24 @@ struct Handle {
       HIPCHK(hipGetLastError());
       return;
     }
+    if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.gsb.has_split && !L.RG.empty() && sp.part == PART_ALL) {
+      // sweep from zero, then residual of the untouched part + chunk-local restriction in one pass (r stays in LDS)
+      gsb_sweep(L, 0, L.gsb.lowin, nullptr, x, b);
+      const DevRestrict& R = L.RG;
+      const DevMatrix& M = L.gsb.rest;
+      const int nch = (M.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
+      if (nch != R.n_chunks) throw Err("fused Gauss-Seidel residual: chunk / slice mismatch");
+      if (M.sell.win)
+        hipLaunchKernelGGL((sell_win_cres_restrict_kernel<SELL_WIN>), dim3(nch), dim3(SELL_WIN), 0, stream, M.n_rows, M.sell.view(), M.sell.rowloc.p,
+                           (const double*)x, (const double*)L.gsb.cvec.p, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+      else
+      hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 1>), dim3(nch), dim3(512), 0, stream, M.n_rows, 0, M.n_slices, M.sell.view(), (const double*)x,
+                         (const double*)L.gsb.cvec.p, 0.0, 0, (double*)nullptr, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                         R.oidx.p, R.part.p, b_coarse);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     pre_smooth(L, x, b, r, fold, sp);
     if (sp.part != PART_INT) transfer_f2c(l, r, b_coarse);
   }
@@ -1017,6 +1086,9 @@ struct Handle {
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols) {
+      mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
+      gsb_sweep(L, 1, L.gsb.full, L.tmp.p, x, b);   // backward block-hybrid sweep, tmp -> x
     } else {
       add_c2f(l, 1.0, x, xc);
       level_smooth(L, 1, x, b, r, false, false, false);
@@ -1226,6 +1298,108 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     std::vector<int> pos(g.color_row_ptr.begin(), g.color_row_ptr.end() - 1);
     for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
     g.rowlist.upload(rows);
+  }
+}
+
+// Block-hybrid Gauss-Seidel data (gsb_sweep_kernel).  Validated like the colourings above: two coupled rows of one block
+// sharing a colour would be a data race.
+static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* P) {
+  const int64_t n = d.A.n_rows;
+  DevGSB& g = L.gsb;
+  const int B = d.gs_block_rows;
+  // lanes per row from the longest row (a lane holds <= 16 entries, + 1 when G = 1); workgroup size TH = B * G
+  int64_t mx = 0;
+  for (int64_t i = 0; i < n; ++i) mx = std::max<int64_t>(mx, d.A.rowptr[i + 1] - d.A.rowptr[i]);
+  int G = 1;
+  while (G < 16 && mx > 16 * G + (G == 1 ? 1 : 0)) G <<= 1;
+  const int TH = B * G;
+  if (B < 16 || (TH != 256 && TH != 512 && TH != 1024))
+    throw Err("gs_block_rows = " + std::to_string(B) + " with " + std::to_string(G) + " lanes per row (longest row: " + std::to_string(mx) +
+              " entries) does not give a workgroup of 256, 512 or 1024 lanes");
+  if (d.A.br != 1 || d.A.bc != 1) throw Err("block-hybrid Gauss-Seidel: scalar levels only");
+  if (!d.color || d.n_colors <= 0 || d.n_colors > 254) { if (n > 0) throw Err("block-hybrid Gauss-Seidel needs a blocked colouring with at most 254 colours"); return; }
+  if (!d.dinv) throw Err("dinv missing");
+  const int nc = d.n_colors;
+  for (int64_t i = 0; i < n; ++i) {
+    const int ci = d.color[i];
+    if (ci >= nc) throw Err("colour index out of range");
+    if (ci < 0) continue;
+    const int64_t b0 = (i / B) * B, b1 = b0 + B;
+    for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+      const int64_t j = d.A.col[k];
+      if (j != i && j >= b0 && j < b1 && j < n && d.color[j] == ci) throw Err("invalid blocked colouring: two coupled rows of one block share a colour");
+    }
+  }
+  g.B = B; g.G = G; g.TH = TH; g.n_colors = nc;
+  g.n_blocks = (int)((n + B - 1) / B);
+  const int64_t slots = (int64_t)g.n_blocks * B;
+  std::vector<int32_t> rows((size_t)slots, -1);
+  std::vector<uint8_t> sc((size_t)slots, 255);
+  for (int64_t b0 = 0; b0 < n; b0 += B) {
+    const int64_t b1 = std::min<int64_t>(n, b0 + B);
+    for (int64_t i = b0; i < b1; ++i) rows[i] = (int32_t)i;
+    std::stable_sort(rows.begin() + b0, rows.begin() + b1, [&](int32_t a, int32_t c) {
+      return (d.color[a] < 0 ? 255 : d.color[a]) < (d.color[c] < 0 ? 255 : d.color[c]); });
+    for (int64_t q = b0; q < b1; ++q) sc[q] = d.color[rows[q]] < 0 ? 255 : (uint8_t)d.color[rows[q]];
+  }
+  auto check_width = [&](const HostSell& S, const char* what) {
+    const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
+    for (int64_t q = 0; q < ns; ++q) {
+      const int w = (int)(((S.slice_ptr[q + 1] & ~(int64_t)63) - (S.slice_ptr[q] & ~(int64_t)63)) / WAVE);
+      if (w > 2 * GSB_WP + 1) throw Err(std::string("block-hybrid Gauss-Seidel (") + what + "): a row has more than " + std::to_string((2 * GSB_WP) * G + 1) +
+                                        " entries for gs_block_rows = " + std::to_string(B) + " (use smaller blocks)");
+    }
+  };
+  {
+    HostSell S;
+    build_sell(d.A, rows.data(), slots, false, G, S);
+    check_width(S, "A");
+    upload_sell(S, g.full);
+  }
+  g.rowid.upload(rows);
+  g.slotcolor.upload(sc);
+  // split for the pre-smoothing from zero: lowin = in-block couplings to lower colours, rest = everything else but the
+  // diagonal; couplings to non-free columns are dropped (x is 0 there), non-free rows are empty (their residual is not
+  // needed: their prolongation rows are empty)
+  const int64_t nnz = d.A.rowptr[n];
+  std::vector<double> cv((size_t)n, 0.0);
+  std::vector<int64_t> rp[2];
+  std::vector<int32_t> cc[2];
+  std::vector<double> vv[2];
+  for (int part = 0; part < 2; ++part) { rp[part].assign(n + 1, 0); cc[part].reserve(nnz / 2 + 16); vv[part].reserve(nnz / 2 + 16); }
+  bool ok = true;
+  for (int64_t i = 0; i < n; ++i) {
+    const int ci = d.color[i];
+    if (ci >= 0) {
+      const int64_t b0 = (i / B) * B, b1 = b0 + B;
+      double aii = 0.0;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+        const int64_t j = d.A.col[k];
+        if (j == i) { aii = d.A.val[k]; continue; }
+        const int cj = j < n ? d.color[j] : 0;            // ghost columns count as live
+        if (cj < 0) continue;
+        const int part = (j >= b0 && j < b1 && j < n && cj < ci) ? 0 : 1;
+        cc[part].push_back((int32_t)j); vv[part].push_back(d.A.val[k]);
+      }
+      if (d.dinv[i] != 0.0) cv[i] = 1.0 / d.dinv[i] - aii; else ok = false;     // a swept row without a diagonal inverse
+    }
+    rp[0][i + 1] = (int64_t)cc[0].size();
+    rp[1][i + 1] = (int64_t)cc[1].size();
+  }
+  if (ok && !std::getenv("AMGX_GSB_NO_SPLIT")) {
+    amgx_matrix F = d.A;
+    F.rowptr = rp[0].data(); F.col = cc[0].data(); F.val = vv[0].data();
+    HostSell S;
+    build_sell(F, rows.data(), slots, false, G, S);
+    check_width(S, "lower part");
+    upload_sell(S, g.lowin);
+    F.rowptr = rp[1].data(); F.col = cc[1].data(); F.val = vv[1].data();
+    upload_matrix(F, g.rest, "A (block-hybrid Gauss-Seidel: rest)", true, false, false, 1.6, SELL_WIN);
+    g.cvec.upload(cv);
+    g.has_split = true;
+    if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
+        P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
+      build_restrict(*P, L.RG, 512, 4 * 512);
   }
 }
 
@@ -1478,7 +1652,8 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       }
       if (!s.dinv) throw Err("dinv missing");
       L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
-      if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
+      if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
+      else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
         // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
@@ -1561,7 +1736,8 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
-      if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
+      if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0) build_gsb(s, L, nullptr);
+      else if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
     const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
@@ -1587,7 +1763,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         const amgx_level_desc& s = levels[T - 1];
         const int64_t cap = s.sm_type == AMGX_SM_GS ? TAIL_MAX_ROWS_GS : TAIL_MAX_ROWS;
         const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= cap &&
-                        (s.sm_type == AMGX_SM_JACOBI || (s.sm_type == AMGX_SM_GS && s.color && s.n_colors > 0)) &&
+                        (s.sm_type == AMGX_SM_JACOBI || (s.sm_type == AMGX_SM_GS && s.color && s.n_colors > 0 && s.gs_block_rows == 0)) &&
                         s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= 512;
         if (!ok) break;
         --T;
@@ -1598,11 +1774,17 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       std::vector<TailOp> prog;
       const EpArgs none{nullptr, nullptr, nullptr, 0.0, nullptr, 0};
       auto spmv = [&](int ep, const DevCsr& M, int n, const double* x, double* y, EpArgs a) {
-        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0});
+        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0, 0});
       };
-      auto gs = [&](DevLevel& V, int nc, int backward) {
+      auto gs = [&](DevLevel& V, int nc, int backward, int lds_ok) {
         prog.push_back(TailOp{T_GS, 0, (int)V.n, V.tA.rowptr.p, V.tA.col.p, V.tA.val.p, nullptr, V.x.p,
-                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward});
+                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward, lds_ok});
+      };
+      auto gs_lds_ok = [&](int l) {
+        const amgx_matrix& A = levels[l].A;
+        if (A.n_rows > TAIL_BLOCK / TAIL_G || std::getenv("AMGX_NO_TAIL_LDS")) return 0;
+        for (int64_t i = 0; i < A.n_rows; ++i) if (A.rowptr[i + 1] - A.rowptr[i] > TAIL_G * TAIL_GS_K) return 0;
+        return 1;
       };
       for (int l = T; l + 1 < L; ++l) {
         const amgx_level_desc& s = levels[l];
@@ -1628,14 +1810,14 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         if (V.sm_type == AMGX_SM_JACOBI) {     // r = b - A'b, x = omega*Dinv*b
           spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p, 0});
         } else {                               // x = 0; forward sweep; r = b - A x
-          prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0});
-          gs(V, levels[l].n_colors, 0);
+          prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0, 0});
+          gs(V, levels[l].n_colors, 0, gs_lds_ok(l));
           spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr, 0});
         }
         spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, none);   // b_{l+1} = P^T r
       }
       prog.push_back(TailOp{T_DENSE, 0, (int)h->coarse_n, nullptr, nullptr, h->coarse_inv.p, h->lev[L - 1].rhs.p, h->lev[L - 1].x.p,
-                            none, nullptr, nullptr, 0, 0});
+                            none, nullptr, nullptr, 0, 0, 0});
       for (int l = L - 2; l >= T; --l) {      // up
         DevLevel& V = h->lev[l];
         if (V.sm_type == AMGX_SM_JACOBI) {     // tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)
@@ -1643,7 +1825,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
           spmv(EP_JAC, V.tA, (int)V.n, V.tmp.p, V.x.p, EpArgs{V.rhs.p, V.tmp.p, V.dinv.p, V.omega, nullptr, 0});
         } else {                               // x += P x_{l+1} ; backward sweep
           spmv(EP_AXPY, V.tP, (int)V.n, h->lev[l + 1].x.p, V.x.p, EpArgs{nullptr, V.x.p, nullptr, 1.0, nullptr, 0});
-          gs(V, levels[l].n_colors, 1);
+          gs(V, levels[l].n_colors, 1, gs_lds_ok(l));
         }
       }
       h->tail_prog.upload(prog);

@@ -40,8 +40,10 @@ enum Epilogue : int {
   EP_RES = 1,    // y = b - A x
   EP_AXPY = 2,   // y = yin + s * A x        (yin may alias y)
   EP_JAC = 3,    // y = yin + omega * dinv * (b - A yin)   with x == yin gathered, y != yin
-  EP_PRE = 4     // Jacobi pre-smoothing from x = 0 in one pass over the column-scaled image A' = A * omega*Dinv:
+  EP_PRE = 4,    // Jacobi pre-smoothing from x = 0 in one pass over the column-scaled image A' = A * omega*Dinv:
                  //   y = b - A' b  (= b - A x with x = omega*Dinv*b),  y2 = omega * dinv * b  (= x)
+  EP_CRES = 5    // y = c .* v - A x  with c = ep.dinv, v = ep.b (own-row entries): residual right after a block-hybrid
+                 //   Gauss-Seidel sweep from zero, A = the part of the matrix the sweep did not use (see gsb_sweep_kernel)
 };
 
 struct EpArgs {
@@ -75,6 +77,7 @@ __device__ __forceinline__ void store_scalar(int64_t row, double acc, double* y,
   if (EP == EP_MULT) y[row] = acc;
   else if (EP == EP_RES) y[row] = ep.b[row] - acc;
   else if (EP == EP_AXPY) y[row] = ep.yin[row] + ep.s * acc;
+  else if (EP == EP_CRES) y[row] = ep.dinv[row] * ep.b[row] - acc;
   else if (EP == EP_JAC) {
     if (ep.nt & EPF_NT) __builtin_nontemporal_store((have_xd ? xd : ep.yin[row]) + ep.s * (ld_nt(ep.dinv + row) * (ld_nt(ep.b + row) - acc)), y + row);
     else y[row] = (have_xd ? xd : ep.yin[row]) + ep.s * (ep.dinv[row] * (ep.b[row] - acc));
@@ -97,6 +100,7 @@ __device__ __forceinline__ EpOps ep_operands(int64_t row, const EpArgs& ep, bool
   EpOps o{0.0, 0.0, 0.0};
   const bool nt = ep.nt & EPF_NT;
   if (EP == EP_RES) o.b = ep.b[row];
+  else if (EP == EP_CRES) { o.b = ep.b[row]; o.d = ep.dinv[row]; }
   else if (EP == EP_AXPY) o.yin = ep.yin[row];
   else if (EP == EP_JAC) {
     o.d = nt ? ld_nt(ep.dinv + row) : ep.dinv[row];
@@ -113,6 +117,7 @@ __device__ __forceinline__ void store_scalar_ops(int64_t row, double acc, double
   const bool nt = ep.nt & EPF_NT;
   if (EP == EP_MULT) y[row] = acc;
   else if (EP == EP_RES) y[row] = o.b - acc;
+  else if (EP == EP_CRES) y[row] = o.d * o.b - acc;
   else if (EP == EP_AXPY) y[row] = o.yin + ep.s * acc;
   else if (EP == EP_JAC) {
     const double v = (have_xd ? xd : o.yin) + ep.s * (o.d * (o.b - acc));
@@ -578,6 +583,106 @@ __global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int sl
   if (writer) x[row] = xv + dv * (bv - acc);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Block-hybrid Gauss-Seidel: ONE launch per sweep.  A workgroup owns B = TH / G consecutive rows (G lanes per row) and
+// sweeps them like one rank of the reference's hybrid smoother (HybridGSSmoother, gssmoother.cpp:709-861, with
+// workgroups in the role of the ranks): Gauss-Seidel inside the block in colour order, couplings that leave the block use
+// the values from the START of the sweep (xin); the diagonal is the l1-modified one where the off-block weight is large
+// (hybrid_smoother_utils.hpp:111-142, applied on the host: amgh_hybrid_dinv).
+//   * the block's own x lives in LDS (natural order: coalesced load and store); every lane loads its share of its row
+//     (<= 2*GSB_WP + 1 entries, block-local SELL-G slices whose slots are sorted by colour) into REGISTERS up front, so the
+//     matrix streams from HBM exactly like in the SpMV kernels while nothing depends on the sweep yet;
+//   * off-block entries are gathered from xin (L2 / Infinity Cache) and summed immediately; in-block entries keep
+//     (value, LDS slot); the colour phases then touch LDS only: acc = sum v * xs[slot], x_k += dinv_k (b_k - acc),
+//     one workgroup barrier per colour;
+//   * out of place (xin != xout) unless FROM_ZERO (x = 0 everywhere: no global gathers at all).
+// Replaces 8...30 dependent colour launches per sweep whose colour-major slices touched ~8x the cache lines per gather.
+constexpr int GSB_WP = 8;                    // pair-steps per lane held in registers (<= 16 entries + one odd trailing)
+struct GsbArgs {
+  const int32_t* rowid;                      // [n_blocks * B] slot -> row, -1 = padding
+  const uint8_t* slotcolor;                  // [n_blocks * B] colour of the slot's row, 255 = not swept (non-free / padding)
+  const double* dinv;
+  const double* b;
+  int n_colors;
+  int backward;
+};
+
+template <int TH, int G, bool FROM_ZERO>
+__global__ __launch_bounds__(TH) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
+                                                        const double* __restrict__ xin, double* xout) {
+  constexpr int B = TH / G;                  // rows per block
+  constexpr int RPS = WAVE / G;              // rows per slice
+  __shared__ double xs[B];
+  const int blk = block0 + blockIdx.x;
+  const int64_t r0 = (int64_t)blk * B;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blk * (TH / WAVE) + (tid >> 6));
+  if (tid < B) { const int64_t r = r0 + tid; xs[tid] = (!FROM_ZERO && r < n_rows) ? xin[r] : 0.0; }
+  const int slot = s * RPS + lane / G;
+  const int row = a.rowid[slot];
+  const int mycol = row >= 0 ? (int)a.slotcolor[slot] : 255;
+  const bool writer = mycol != 255 && (lane % G) == 0;
+  double dv = 0.0, bv = 0.0;
+  if (writer) { dv = a.dinv[row]; bv = a.b[row]; }
+  // ---- this lane's entries: values + decoded columns
+  const int64_t sp0 = M.slice_ptr[s];
+  const int64_t base = sp0 & ~(int64_t)63;
+  const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
+  const int np = w >> 1;
+  const bool c16 = sp0 & 1;
+  const double* __restrict__ vb = M.val + base;
+  const int32_t* __restrict__ cb = M.cbase + (base >> 6);
+  double v[2 * GSB_WP + 1];
+  int cl[2 * GSB_WP + 1];
+#pragma unroll
+  for (int p = 0; p < GSB_WP; ++p) {
+    if (p < np) {                                            // wave-uniform
+      v[2 * p] = ld_nt(vb + (p * WAVE + lane) * 2);
+      v[2 * p + 1] = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
+      if (c16) {
+        const uint32_t pk = ld_nt(reinterpret_cast<const uint32_t*>(M.col16 + base) + p * WAVE + lane);
+        cl[2 * p] = cb[2 * p] + (int)(pk & 0xffffu);
+        cl[2 * p + 1] = cb[2 * p + 1] + (int)(pk >> 16);
+      } else {
+        cl[2 * p] = ld_nt(M.col32 + base + (p * WAVE + lane) * 2);
+        cl[2 * p + 1] = ld_nt(M.col32 + base + (p * WAVE + lane) * 2 + 1);
+      }
+    } else { v[2 * p] = 0.0; v[2 * p + 1] = 0.0; cl[2 * p] = (int)r0; cl[2 * p + 1] = (int)r0; }
+  }
+  if (w & 1) {
+    const int64_t o = (int64_t)(w - 1) * WAVE + lane;
+    v[2 * GSB_WP] = ld_nt(vb + o);
+    cl[2 * GSB_WP] = c16 ? cb[w - 1] + (int)ld_nt(M.col16 + base + o) : ld_nt(M.col32 + base + o);
+  } else { v[2 * GSB_WP] = 0.0; cl[2 * GSB_WP] = (int)r0; }
+  // ---- off-block part now (frozen values), in-block part as (value, LDS slot)
+  double acc_off = 0.0;
+#pragma unroll
+  for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
+    const int loc = cl[j] - (int)r0;
+    const bool inb = loc >= 0 && loc < B;
+    if (!FROM_ZERO) { if (!inb && v[j] != 0.0) acc_off += v[j] * xin[cl[j]]; }
+    if (!inb) v[j] = 0.0;
+    cl[j] = inb ? loc : 0;
+  }
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) acc_off += __shfl_xor(acc_off, o, G);
+  const int own = row >= 0 ? row - (int)r0 : 0;
+  __syncthreads();                                           // xs is loaded
+  for (int q = 0; q < a.n_colors; ++q) {
+    const int c = a.backward ? a.n_colors - 1 - q : q;
+    if (__any(mycol == c)) {                                 // slices hold one or two colours (slots are colour-sorted)
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 2 * GSB_WP + 1; ++j) acc += v[j] * xs[cl[j]];
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+      if (writer && mycol == c) xs[own] = xs[own] + dv * (bv - acc_off - acc);
+    }
+    __syncthreads();
+  }
+  if (tid < B && r0 + tid < n_rows) xout[r0 + tid] = xs[tid];
+}
+
 // r = -(U x) on the colour-major rows: the residual right after a forward sweep from x = 0, where
 // (b - L x - D x)_k = 0 holds for every swept row (see Handle::pre_smooth), so only the entries coupling to HIGHER
 // colours are needed.  One launch over all colours (no ordering required).
@@ -682,7 +787,9 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 // (chunk, coarse column) slot; restrict_sum_kernel then adds the ~10 partial sums of every coarse row in a fixed
 // order.  Replaces: 80 MB write of r + the P^T gather kernel (134 us at cfg 2, TA/L2-bound).
 // FB = workgroup size = rows per chunk (1024 or 512); 4 entries of P per row at most
-template <int FUSED_BLOCK>
+// MODE 0: Jacobi pre-smoothing as described above.  MODE 1: residual after a block-hybrid Gauss-Seidel sweep from zero,
+// r = c .* x - A_rest x (EP_CRES; b = the swept x, dinv = c, nothing written to x), with the same chunk-local restriction.
+template <int FUSED_BLOCK, int MODE = 0>
 __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
                                                                         double omega, int nt, double* __restrict__ x, double* r_out,
@@ -717,7 +824,14 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
   const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
   double r = 0.0;
-  if (s < n_slices) {
+  if (MODE == 1) {
+    if (s < n_slices) {
+      double ci = 0.0, xi = 0.0;
+      if (row < n_rows) { ci = dinv[row]; xi = b[row]; }
+      const double acc = sell_row_dot(M, s, lane, row, b);
+      if (row < n_rows) { r = ci * xi - acc; if (r_out) r_out[row] = r; }
+    }
+  } else if (s < n_slices) {
     double bi = 0.0, di = 0.0;
     double xd[2] = {0.0, 0.0};
     const bool wdiag = M.wdiag && M.diag_first;
@@ -757,6 +871,63 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     double acc = 0.0;
     for (int k = a; k < bnd; ++k) acc += pr[k];
     part[dest ? dest[slot] : slot] = acc;
+  }
+}
+
+// The residual after a block-hybrid Gauss-Seidel sweep from zero, r = c .* x - A_rest x, fused with the chunk-local
+// restriction like sell_pre_restrict_kernel<.., 1>, for the WINDOWED SELL form (rows of a 512-row window stored by
+// decreasing length): A_rest has ragged rows (each row lost its in-block lower-colour couplings), plain slices pad ~27 %.
+template <int WB>
+__global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_rows, SellMat M, const uint16_t* __restrict__ rowloc,
+                                                                    const double* __restrict__ x, const double* __restrict__ cvec,
+                                                                    const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ slot_ptr,
+                                                                    const double* __restrict__ w, const uint16_t* __restrict__ fi,
+                                                                    double* __restrict__ part, const int32_t* __restrict__ dest) {
+  constexpr int MAXE = 4 * WB;
+  __shared__ double buf[WB];
+  __shared__ double pr[MAXE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int c = blockIdx.x;
+  const int s = __builtin_amdgcn_readfirstlane(c * (WB / WAVE) + (threadIdx.x >> 6));
+  const int64_t slot = (int64_t)s * WAVE + lane;
+  const int64_t row = (int64_t)c * WB + threadIdx.x;
+  const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
+  const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
+  double wq[MAXE / WB];
+  int fq[MAXE / WB];
+#pragma unroll
+  for (int q = 0; q < MAXE / WB; ++q) {
+    const int e = e0 + threadIdx.x + q * WB;
+    wq[q] = e < e1 ? ld_nt(w + e) : 0.0;
+    fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
+  }
+  const int myslot = s0 + threadIdx.x;
+  const int mydest = (dest && myslot < s1) ? dest[myslot] : myslot;
+  const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
+  const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
+  double ci = 0.0, xi = 0.0;
+  if (row < n_rows) { ci = cvec[row]; xi = x[row]; }
+  if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, x);
+  __syncthreads();
+  const double r = row < n_rows ? ci * xi - buf[threadIdx.x] : 0.0;
+  buf[threadIdx.x] = r;                      // (same thread, same entry: the residuals replace the row sums in place)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXE / WB; ++q) {
+    const int e = threadIdx.x + q * WB;
+    if (e0 + e < e1) pr[e] = wq[q] * buf[fq[q]];
+  }
+  __syncthreads();
+  if (myslot < s1) {
+    double acc = 0.0;
+    for (int k = pa; k < pb; ++k) acc += pr[k];
+    part[mydest] = acc;
+  }
+  for (int sl = myslot + WB; sl < s1; sl += WB) {
+    const int a = slot_ptr[sl] - e0, bnd = slot_ptr[sl + 1] - e0;
+    double acc = 0.0;
+    for (int k = a; k < bnd; ++k) acc += pr[k];
+    part[dest ? dest[sl] : sl] = acc;
   }
 }
 
@@ -849,7 +1020,9 @@ struct TailOp {
   const int32_t* cptr;   // [n_colors+1] ranges of rowlist
   int n_colors;
   int backward;
+  int lds_ok;            // T_GS: n <= TAIL_BLOCK / TAIL_G rows of <= TAIL_G * TAIL_GS_K entries: x in LDS, rows in registers
 };
+constexpr int TAIL_GS_K = 8;
 
 __device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, double* y, const EpArgs& a) {
   switch (ep) {
@@ -857,16 +1030,57 @@ __device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, doub
     case EP_RES: store_scalar<EP_RES>(row, acc, y, a); break;
     case EP_AXPY: store_scalar<EP_AXPY>(row, acc, y, a); break;
     case EP_JAC: store_scalar<EP_JAC>(row, acc, y, a); break;
+    case EP_CRES: store_scalar<EP_CRES>(row, acc, y, a); break;
     default: store_scalar<EP_PRE>(row, acc, y, a); break;
   }
 }
 
 __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailOp* __restrict__ ops) {
+  __shared__ double xs[TAIL_BLOCK / TAIL_G];
+  __shared__ int rc[TAIL_BLOCK / TAIL_G];
   const int tid = threadIdx.x;
   for (int i = 0; i < n_ops; ++i) {
     const TailOp op = ops[i];
     if (op.type == T_ZERO) {
       for (int k = tid; k < op.n; k += TAIL_BLOCK) op.y[k] = 0.0;
+    } else if (op.type == T_GS && op.lds_ok) {
+      // small level: every lane group owns ONE row for the whole sweep, its entries sit in registers and x in LDS, so a
+      // colour phase is LDS reads + one barrier instead of a chain of dependent global loads (2 us per colour)
+      const int row = tid / TAIL_G, sub = tid % TAIL_G;
+      const bool act = row < op.n;
+      if (tid < TAIL_BLOCK / TAIL_G) rc[tid] = -1;
+      __syncthreads();
+      for (int p = tid; p < op.cptr[op.n_colors]; p += TAIL_BLOCK) {
+        int c = 0;
+        while (op.cptr[c + 1] <= p) ++c;
+        rc[op.rowlist[p]] = c;
+      }
+      double v[TAIL_GS_K];
+      int cl[TAIL_GS_K];
+      const int e0 = act ? op.rowptr[row] : 0, e1 = act ? op.rowptr[row + 1] : 0;
+#pragma unroll
+      for (int k = 0; k < TAIL_GS_K; ++k) {
+        const int e = e0 + sub + k * TAIL_G;
+        v[k] = e < e1 ? op.val[e] : 0.0;
+        cl[k] = e < e1 ? op.col[e] : 0;
+      }
+      double dv = 0.0, bv = 0.0;
+      if (act && sub == 0) { dv = op.args.dinv[row]; bv = op.args.b[row]; xs[row] = op.y[row]; }
+      __syncthreads();
+      const int mycol = act ? rc[row] : -1;
+      for (int q = 0; q < op.n_colors; ++q) {
+        const int c = op.backward ? op.n_colors - 1 - q : q;
+        if (mycol == c) {                                   // uniform inside a lane group: the shuffles are safe
+          double acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < TAIL_GS_K; ++k) acc += v[k] * xs[cl[k]];
+#pragma unroll
+          for (int o = TAIL_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, TAIL_G);
+          if (sub == 0) xs[row] += dv * (bv - acc);
+        }
+        __syncthreads();
+      }
+      if (act && sub == 0) op.y[row] = xs[row];
     } else if (op.type == T_GS) {
       const int sub = tid % TAIL_G;
       for (int q = 0; q < op.n_colors; ++q) {

@@ -138,6 +138,25 @@ int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* co
   });
 }
 
+int amgh_coloring_blocked(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int32_t* color_out, int32_t* n_colors) {
+  return guard([&] {
+    check_matrix(A);
+    if (block_rows < 1 || !color_out || !n_colors) throw amgh::Error("amgh_coloring_blocked: bad arguments");
+    amgh::BCSR M = to_bcsr(A);
+    *n_colors = amgh::greedy_coloring_blocked(M, free_or_null, block_rows, color_out);
+  });
+}
+
+int amgh_hybrid_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, double* dinv_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->br != 1 || A->bc != 1) throw amgh::Error("amgh_hybrid_dinv: scalar matrices only");
+    if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv: bad arguments");
+    amgh::BCSR M = to_bcsr(A);
+    amgh::hybrid_mod_dinv(M, free_or_null, block_rows, dinv_out);
+  });
+}
+
 int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows, int pinv,
                   const int64_t* dinv_ptr, double* dinv_out) {
   return guard([&] {

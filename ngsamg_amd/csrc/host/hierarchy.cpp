@@ -371,6 +371,65 @@ int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color) {
   return ncol;
 }
 
+// greedy colouring that only sees couplings INSIDE blocks of `block_rows` consecutive rows (block-hybrid Gauss-Seidel:
+// couplings that cross a block boundary are frozen during a sweep, so they put no constraint on the order)
+int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color) {
+  const int64_t n = A.n_rows;
+  int ncol = 0;
+#pragma omp parallel
+  {
+    std::vector<int64_t> mark(64, -1);
+    int loc = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t b0 = 0; b0 < n; b0 += block_rows) {
+      const int64_t b1 = std::min<int64_t>(n, b0 + block_rows);
+      for (int64_t i = b0; i < b1; i++) {
+        color[i] = -1;
+        if (free && !free[i]) continue;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+          const int64_t j = A.col[k];
+          if (j >= i || j < b0) continue;
+          const int32_t c = color[j];
+          if (c >= 0) { if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1); mark[c] = i; }
+        }
+        int c = 0;
+        while (c < (int)mark.size() && mark[c] == i) c++;
+        if (c >= (int)mark.size()) mark.resize(2 * c + 2, -1);
+        color[i] = c;
+        loc = std::max(loc, c + 1);
+      }
+    }
+#pragma omp critical
+    ncol = std::max(ncol, loc);
+  }
+  return ncol;
+}
+
+// inverse of the l1-type modified diagonal of the hybrid smoother (reference CalcModDiag, hybrid_smoother_utils.hpp:35-142):
+//   ad_k = sum over the couplings of row k that leave its block of |a_kj| / sqrt(a_kk a_jj);  md_k = max(1, 0.51 (1 + ad_k)) a_kk
+// scalar matrices; non-free rows get 0
+void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv) {
+  const int64_t n = A.n_rows;
+  std::vector<double> d((size_t)A.n_cols, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { d[i] = A.val[k]; break; }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    dinv[i] = 0.0;
+    if ((free && !free[i]) || d[i] == 0.0) continue;
+    const int64_t b0 = (i / block_rows) * block_rows, b1 = b0 + block_rows;
+    double ad = 0.0;
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+      const int64_t j = A.col[k];
+      if (j >= b0 && j < b1) continue;
+      const double dj = j < n ? d[j] : 0.0;
+      if (d[i] > 0.0 && dj > 0.0) ad += std::fabs(A.val[k]) / std::sqrt(d[i] * dj);
+    }
+    dinv[i] = 1.0 / (std::max(1.0, 0.51 * (1.0 + ad)) * d[i]);
+  }
+}
+
 Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coords0, const Options& o) {
   auto H = new Hierarchy();
   H->opts = o;

@@ -52,5 +52,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
 // smoother data for one matrix (also used stand-alone by CreateJacobiSmoother / CreateHybridGSS mirrors)
 void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv);
 int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color);
+int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color);
+void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv);
 
 }  // namespace amgh

@@ -17,7 +17,39 @@ import numpy as np
 from . import _lib
 from ._lib import NgsAMGError
 
-_SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS, "bgs": _lib.AMGX_SM_BGS}
+# "hgs" = Gauss-Seidel in the block-hybrid form (one launch per sweep, amgx_level_desc.gs_block_rows); "gs" = multicolour
+_SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS, "hgs": _lib.AMGX_SM_GS, "bgs": _lib.AMGX_SM_BGS}
+
+
+def gs_block_rows(A):
+    """rows per block of the block-hybrid Gauss-Seidel kernel for a scalar level matrix.  G lanes share a row, each holds
+    at most 16 entries (+1 when G = 1) in registers; the workgroup has B * G lanes.  Measured at cfg 2:
+    one-lane rows run fastest in 256-row blocks (more workgroups per CU hide the colour phases of their neighbours); rows
+    that need several lanes get 1024-lane workgroups, so the blocks stay as large as possible (fewer frozen couplings).
+    0: the level keeps the multicolour form (rows too long, or a level small enough for the single-workgroup tail)."""
+    import os
+    if A.br != 1 or A.bc != 1 or A.n_rows <= 256:
+        return 0
+    mx = int(np.diff(A.rowptr).max()) if A.n_rows else 0
+    for G in (1, 2, 4, 8, 16):
+        if mx <= 16 * G + (1 if G == 1 else 0):
+            threads = int(os.environ.get("AMGX_GSB_THREADS", "256" if G == 1 else "1024"))
+            threads = threads if threads in (256, 512, 1024) else 1024
+            return max(16, threads // G)
+    return 0
+
+
+def hybrid_gs_data(A, free, B):
+    """blocked colouring + inverse of the l1-modified diagonal for blocks of B consecutive rows (host library)"""
+    lib = _lib.host()
+    d = A.desc()
+    fr = None if free is None else np.ascontiguousarray(free, dtype=np.uint8)
+    color = np.full(A.n_rows, -1, dtype=np.int32)
+    nc = C.c_int32()
+    _lib.hcheck(lib.amgh_coloring_blocked(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(color, C.c_int32), C.byref(nc)))
+    dinv = np.zeros(A.n_cols, dtype=np.float64)          # (rank-partitioned levels: entries of the ghost columns stay 0)
+    _lib.hcheck(lib.amgh_hybrid_dinv(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(dinv, C.c_double)))
+    return color, int(nc.value), dinv
 
 
 def _is_torch(v):
@@ -60,6 +92,7 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
         raise NgsAMGError("sm_type list must have one entry per level")
     arr = (_lib.amgx_level_desc * n)()
     keep = [arr, hierarchy]
+    info = [None] * n            # per level: block-hybrid Gauss-Seidel data actually used (tests configure the oracle with it)
     for i, lv in enumerate(levels):
         d = arr[i]
         d.A = lv.A.desc(_lib.amgx_matrix)
@@ -76,6 +109,13 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
         d.sm_symm = int(bool(sm_symm[i] if isinstance(sm_symm, (list, tuple)) else sm_symm))
         d.color = _lib.ptr(lv.color, C.c_int32)
         d.n_colors = int(lv.n_colors)
+        if types[i] == "hgs" and i + 1 < n:
+            B = gs_block_rows(lv.A)
+            if B > 0:
+                col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B)
+                info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv)
+                keep.append(info[i])
+                d.color, d.n_colors, d.dinv, d.gs_block_rows = _lib.ptr(col, C.c_int32), nc, _lib.ptr(dinv, C.c_double), B
         g = getattr(lv, "bgs", None)
         if types[i] == "bgs" and g is None and i + 1 < n:
             raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")
@@ -102,7 +142,7 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
     desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
     desc.device = int(device)
     desc.use_graph = int(bool(use_graph))
-    return desc, keep
+    return desc, keep, info
 
 
 class DeviceAMGMatrix:
@@ -113,7 +153,7 @@ class DeviceAMGMatrix:
         self._cfg = dict(sm_type=sm_type, omega=omega, sm_steps=sm_steps, sm_symm=sm_symm, mg_cycle=mg_cycle, clev=clev,
                          device=device, use_graph=use_graph)
         self.hierarchy = hierarchy
-        desc, self._keep = hierarchy_desc(hierarchy, sm_type, omega, sm_steps, sm_symm, mg_cycle, clev, device, use_graph)
+        desc, self._keep, self.hgs = hierarchy_desc(hierarchy, sm_type, omega, sm_steps, sm_symm, mg_cycle, clev, device, use_graph)
         self._h = C.c_void_p()
         self._owned = True
         if lib.amgx_create(C.byref(desc), C.byref(self._h)) != 0:
@@ -137,6 +177,7 @@ class DeviceAMGMatrix:
         self._owned = False
         self._keep = []
         self._cfg = {}
+        self.hgs = [None] * len(hierarchy.levels)
         self._set_sizes()
         return self
 

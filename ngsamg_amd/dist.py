@@ -989,8 +989,8 @@ class _DeviceDist:
             pass
         for i, top in enumerate(amg.tops):
             types = [sm] * (top.n_levels - 1) + ["jacobi"]
-            tdesc, tkeep = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
-            ldesc, lkeep = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
+            tdesc, tkeep, _ = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
+            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
             halos = (_lib.amgx_halo_desc * k)()
             keep = [tkeep, lkeep, halos]
             for l in range(k):

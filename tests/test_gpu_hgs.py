@@ -1,0 +1,93 @@
+"""Block-hybrid Gauss-Seidel (amgx_level_desc.gs_block_rows, gsb_sweep_kernel) against the oracle's serial hybrid GS with
+the same blocks, colours and modified diagonal: cycles, smoother flag contract, and the iteration-count tie to the
+reference's sequential Gauss-Seidel (within +15 %)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(shape, dirichlet="right|top", mcs=20):
+    from tests.problems import poisson_case
+    return poisson_case(shape, dirichlet, mcs)
+
+
+@pytest.mark.parametrize("shape", [(21, 21, 21), (33, 30, 28), (70, 70)])
+@pytest.mark.parametrize("cycle", ["V", "W", "BS"])
+def test_hgs_cycles_match_hybrid_oracle(shape, cycle):
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.hgs_oracle import hgs_levels
+    p, H = _case(shape)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", mg_cycle=cycle, device=0)
+    assert any(h is not None for h in dev.hgs), "no level took the block-hybrid path"
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    orc = Oracle(lv, sm_type=types, cycle=cycle)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n) * p.free
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = orc.apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("threads", ["512", "1024"])
+@pytest.mark.parametrize("split", [True, False])
+def test_hgs_variants(threads, split, monkeypatch):
+    """512-thread workgroups (other block sizes / lanes per row) and the pre-smoothing without the lower / rest split"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.hgs_oracle import hgs_levels
+    monkeypatch.setenv("AMGX_GSB_THREADS", threads)
+    if not split:
+        monkeypatch.setenv("AMGX_GSB_NO_SPLIT", "1")
+    p, H = _case((26, 24, 22))
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    assert dev.hgs[0]["B"] == int(threads)
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(p.n) * p.free
+    x = dev.apply(b)
+    ref = Oracle(lv, sm_type=types).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("ru,ur,xz", [(False, False, False), (False, True, False), (True, True, True), (False, False, True)])
+@pytest.mark.parametrize("back", [False, True])
+def test_hgs_smoother_flag_contract(ru, ur, xz, back):
+    """GetSmoother(level).Smooth / SmoothBack through amgx_smooth on a block-hybrid level (generic, out-of-place sweep)"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.hgs_oracle import hgs_levels
+    p, H = _case((21, 21, 21))
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    orc = Oracle(lv, sm_type=types)
+    rng = np.random.default_rng(2)
+    A0 = H.levels[0].A.to_scipy()
+    b = rng.standard_normal(p.n) * p.free
+    x0 = np.zeros(p.n) if xz else rng.standard_normal(p.n) * p.free
+    r0 = b - A0 @ x0 if ru else rng.standard_normal(p.n)
+    xg, rg = x0.copy(), r0.copy()
+    dev.Smooth(0, xg, b, rg, ru, ur, xz, back=back)
+    xo, ro = orc.smooth(0, x0.copy(), b, r0.copy(), ru, ur, xz, back)
+    assert np.linalg.norm(xg - xo) <= 1e-11 * max(1.0, np.linalg.norm(xo))
+    if ur:
+        fr = p.free.astype(bool)
+        assert np.linalg.norm((rg - ro)[fr]) <= 1e-10 * max(1.0, np.linalg.norm(ro[fr]))
+
+
+def test_hgs_iterations_within_15_percent_of_sequential_gs():
+    """PCG with the block-hybrid smoother vs the reference's sequential Gauss-Seidel (oracle 'gs') on cfg 1's shape"""
+    import torch
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from ngsamg_amd.krylov import CGSolver
+    from oracle.pyoracle import Oracle
+    p, H = _case((101, 101), "left|top", 5)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n) * p.free
+    cg = CGSolver(dev, dev, tol=1e-12, maxsteps=200)
+    cg.Solve(torch.from_numpy(b).cuda())
+    _, it_seq, _ = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-12, maxit=200)
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)
