@@ -336,6 +336,11 @@ class _AMGPreconditioner:
         if spec:
             for i, t in enumerate(spec[: hier.n_levels]):
                 types[i] = t if t in ("gs", "jacobi", "bgs") else "gs"
+        # Gauss-Seidel runs in the block-hybrid form by default (one launch per sweep: workgroups sweep blocks of consecutive
+        # rows like the ranks of the reference's HybridGSSmoother, gssmoother.cpp:709-861); ngs_amg_gs_hybrid=False selects the
+        # multicolour form (exact Gauss-Seidel in colour order, one launch per colour).  Block levels stay multicolour.
+        if bool(f.get("gs_hybrid", True)):
+            types = ["hgs" if t == "gs" else t for t in types]
         if "bgs" in types:                                               # BuildBGSSmoother(mat, GetGSBlocks(level)), amg_pc.cpp:1060-1072
             hier.build_bgs()
         clev = str(f.get("clev", "inv")).lower()

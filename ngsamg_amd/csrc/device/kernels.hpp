@@ -597,6 +597,9 @@ __global__ __launch_bounds__(BLOCK) void gs_color_kernel(int slice_begin, int sl
 //     one workgroup barrier per colour;
 //   * out of place (xin != xout) unless FROM_ZERO (x = 0 everywhere: no global gathers at all).
 // Replaces 8...30 dependent colour launches per sweep whose colour-major slices touched ~8x the cache lines per gather.
+#ifndef GSB_MINW
+#define GSB_MINW 1
+#endif
 constexpr int GSB_WP = 8;                    // pair-steps per lane held in registers (<= 16 entries + one odd trailing)
 struct GsbArgs {
   const int32_t* rowid;                      // [n_blocks * B] slot -> row, -1 = padding
@@ -608,7 +611,7 @@ struct GsbArgs {
 };
 
 template <int TH, int G, bool FROM_ZERO>
-__global__ __launch_bounds__(TH) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
+__global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
                                                         const double* __restrict__ xin, double* xout) {
   constexpr int B = TH / G;                  // rows per block
   constexpr int RPS = WAVE / G;              // rows per slice

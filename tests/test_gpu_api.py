@@ -72,7 +72,12 @@ def test_smoother_map_and_cinv_surface():
     p = fem.poisson_fast((17, 17, 17))
     c = NgsAMG.h1_scal(_mat(p), p.free, ngs_amg_max_coarse_size=20)
     H = c.GetHierarchy()
-    orc = Oracle(H.levels, sm_type="gs_mc")
+    # default smoother: Gauss-Seidel in the block-hybrid form; the oracle runs the same blocks, colours and modified diagonal
+    from tests.hgs_oracle import hgs_levels
+    info = c.GetAMGMatrix()._dev.hgs
+    assert info[0] is not None
+    lv, types = hgs_levels(H.levels, info)
+    orc = Oracle(lv, sm_type=types)
     rng = np.random.default_rng(0)
     b = rng.standard_normal(p.n) * p.free
     sm = c.GetSmoother(0)
