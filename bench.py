@@ -337,7 +337,8 @@ def main():
             # timed INSIDE the cycle (HIP events around the one kernel while whole cycles run): the figure rocprofv3's
             # kernel trace reports for it; the back-to-back repetition time is kept beside it
             k_ms = amg.time_op(0, 8, reps=50)
-            k_ms_b2b = amg.time_op(0, 7, reps=50)
+            if args.ops:          # back-to-back repetitions only on request: they would mix into the rocprofv3 --stats average
+                k_ms_b2b = amg.time_op(0, 7, reps=50)
             spmv_bytes = matrix_bytes(lv0.A) + matrix_bytes(lv0.PT) + 7 * V0 + 8 * H.levels[1].n * H.levels[1].bs
             k_name = "sell_pre_restrict_kernel<512> (level 0: x = w Dinv b, r = b - A x, b_c = P^T r in one pass)"
             tname = "traffic_pre_restrict_l0.json"
@@ -361,7 +362,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": k_name,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel_ms": round(k_ms, 4), "kernel_ms_timing": "HIP events around the kernel inside the running cycle (amgx_time_op op 8)" if k_ms_b2b else "HIP events, back-to-back repetitions",
+                "kernel_ms": round(k_ms, 4), "kernel_ms_timing": "HIP events around the kernel inside the running cycle (amgx_time_op op 8)" if k_name.startswith("sell_pre_restrict") else "HIP events, back-to-back repetitions",
                 "kernel_ms_back_to_back": round(k_ms_b2b, 4) if k_ms_b2b else None,
                 "algorithmic_bytes": int(spmv_bytes)}
     # whole cycle: bytes the cycle actually streams (device encodings) / time.  The algorithmic byte count of the reference's

@@ -9,6 +9,7 @@
 // of kernel launches on one HIP stream, captured once per (b, x) pair into a hipGraph and replayed.
 #include "../../../include/amgx.h"
 #include "kernels.hpp"
+#include <dlfcn.h>
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -35,6 +36,43 @@ struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
     if (e_ != hipSuccess)                                                                             \
       throw ::amgx::Err(std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
+
+// roctx ranges named like the reference's timers (AMGMatrix::SmoothV: "AMGMatrix::Mult", "level 0" .. "level 3", "rest",
+// "coarse inv", src/base/solve/amg_matrix.cpp:166-178; "ProlMap::TransferF2C" / "ProlMap::TransferC2F",
+// src/base/coarsening/dof_map.cpp:616-630; "GSS3<bs=N>::SmoothRHS", src/base/smoothers/gssmoother.cpp:201,266), so a
+// rocprofv3 --marker-trace of the GPU path lines up with an NGSolve trace of the CPU path.  Host-side ranges around the
+// enqueue sections; active only with AMGX_ROCTX=1 (libroctx64 is resolved at run time).
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  static Roctx& get() {
+    static Roctx r;
+    static bool init = false;
+    if (!init) {
+      init = true;
+      if (std::getenv("AMGX_ROCTX")) {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) { r.push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); r.pop = (int (*)())dlsym(h, "roctxRangePop"); }
+        if (!r.push || !r.pop) { r.push = nullptr; r.pop = nullptr; }
+      }
+    }
+    return r;
+  }
+};
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(Roctx::get().push != nullptr) { if (on) Roctx::get().push(name); }
+  explicit Range(const std::string& name) : Range(name.c_str()) {}
+  ~Range() { if (on) Roctx::get().pop(); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+};
+static const char* level_range_name(int l) {          // lev_timers of the reference: levels >= 4 share "rest"
+  static const char* n[] = {"level 0", "level 1", "level 2", "level 3", "rest"};
+  return n[l < 4 ? l : 4];
+}
 
 template <class T>
 struct DevBuf {
@@ -800,6 +838,7 @@ struct Handle {
   // cbeg, cend: only the colours [cbeg, cend) (cend < 0: all) -- the stages of the hybrid smoother on rank-partitioned
   // levels are colour ranges (dist.hpp)
   void gs_sweep(const DevLevel& L, int dir, double* x, const double* b, bool lower_only = false, int cbeg = 0, int cend = -1) {
+    Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
     const DevGS& g = L.gs;
     const DevMatrix::Sell& copy = (lower_only && g.has_split) ? g.lower : g.sell;
     if (L.gsb.on()) throw Err("gs_sweep: the level uses the block-hybrid form");
@@ -845,6 +884,7 @@ struct Handle {
 
   // one block-hybrid Gauss-Seidel sweep (gsb_sweep_kernel): ONE launch; xin == nullptr: sweep from x = 0
   void gsb_sweep(const DevLevel& L, int dir, const DevMatrix::Sell& copy, const double* xin, double* xout, const double* b) {
+    Range rg("GSS3<bs=1>::SmoothRHS");
     const DevGSB& g = L.gsb;
     if (g.n_blocks == 0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
@@ -892,6 +932,7 @@ struct Handle {
   }
 
   void coarse_solve(const double* rhs, double* x) {
+    Range rg("coarse inv");
     const DevLevel& L = lev.back();
     if (clev != AMGX_CLEV_INV || coarse_n == 0) { zero(x, L.len()); return; }   // amg_matrix.cpp:242-246
     const int grid = (int)((coarse_n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
@@ -900,6 +941,7 @@ struct Handle {
   }
 
   void transfer_f2c(int l, const double* xf, double* xc) {                                               // dof_map.cpp:636-654
+    Range rg("ProlMap::TransferF2C");
     const DevRestrict& R = lev[l].R;
     if (R.empty()) { mult(lev[l].PT, xf, xc); return; }
     hipLaunchKernelGGL(restrict_chunk_kernel, dim3(R.n_chunks), dim3(BLOCK), 0, stream, lev[l].n, R.chunk_slot.p, R.slot_ptr.p,
@@ -908,7 +950,7 @@ struct Handle {
                        R.oidx.p, R.part.p, xc);
     HIPCHK(hipGetLastError());
   }
-  void add_c2f(int l, double fac, double* xf, const double* xc) { mult_add(lev[l].P, fac, xc, xf, xf); }   // dof_map.cpp:697-709
+  void add_c2f(int l, double fac, double* xf, const double* xc) { Range rg("ProlMap::TransferC2F"); mult_add(lev[l].P, fac, xc, xf, xf); }   // dof_map.cpp:697-709
 
   // ------------------------------------------------------------------ smoothers (flag contract: base_smoother.hpp:68-112)
   void base_smooth(DevLevel& L, int dir, double* x, const double* b, double* res, bool res_updated, bool update_res, bool x_zero) {
@@ -1101,15 +1143,18 @@ struct Handle {
     if (L == 1) { coarse_solve(b, x); return; }
     const int T = tail_level > 0 ? tail_level : L - 1;     // levels >= T run inside tail_kernel
     for (int l = 0; l < T; ++l) {
+      Range rg(level_range_name(l));
       double* xl = l == 0 ? x : lev[l].x.p;
       const double* bl = l == 0 ? b : lev[l].rhs.p;
       pre_smooth_restrict(l, xl, bl, lev[l].res.p, lev[l + 1].rhs.p, folded(lev[l]));
     }
     if (tail_level > 0) {
+      Range rg("rest");                                    // the coarse tail incl. "coarse inv" in one workgroup
       hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(TAIL_BLOCK), 0, stream, tail_ops, tail_prog.p);
       HIPCHK(hipGetLastError());
     } else coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
     for (int l = T - 1; l >= 0; --l) {
+      Range rg(level_range_name(l));
       double* xl = l == 0 ? x : lev[l].x.p;
       const double* bl = l == 0 ? b : lev[l].rhs.p;
       post_smooth(l, xl, bl, lev[l].res.p, lev[l + 1].x.p, folded(lev[l]));
@@ -1177,6 +1222,7 @@ struct Handle {
   }
 
   void do_cycle(double* x, const double* b) {
+    Range rg("AMGMatrix::Mult");
     if (cycle == AMGX_CYCLE_W) w_rec(0, x, b);
     else if (cycle == AMGX_CYCLE_BS) cycle_bs(x, b);
     else cycle_v(x, b);

@@ -177,6 +177,7 @@ struct Comm {
 
   // owner -> ghost, overwrite (reference CO2CU: BufferM, send, ApplyG; dcc_map.cpp:138-178, 280-302)
   int exchange_begin(const std::vector<Item>& items) {
+    Range rg("DCCMap::StartCO2CU");
     const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
     ++n_exchanges;
     order(compute, comm_stream, tk, ev_ready[tk]);                 // everything the vectors depend on is enqueued
@@ -218,10 +219,11 @@ struct Comm {
     done_value[tk] = signal(comm_stream, NEV + tk, ev_done[tk]);
     return tk;
   }
-  void exchange_end(int ticket) { wait(compute, NEV + ticket, ev_done[ticket], done_value[ticket]); }
+  void exchange_end(int ticket) { Range rg("DCCMap::ApplyCO2CU"); wait(compute, NEV + ticket, ev_done[ticket], done_value[ticket]); }
 
   // ghost -> owner, add, ghost entries zeroed afterwards (reference DIS2CO: BufferG, send, ApplyM; dcc_map.cpp:76-136, 249-274)
   void accumulate(const std::vector<Item>& items) {
+    Range rg("DCCMap::StartDIS2CO");
     const int tk = ev_next; ev_next = (ev_next + 1) % NEV;
     ++n_exchanges;
     order(compute, comm_stream, tk, ev_ready[tk]);
@@ -552,6 +554,7 @@ struct DistCycle {
 // b_status 0 (DISTRIBUTED): b carries [owned | ghost] entries and the ghost entries are contributions to their owners
 // (b.Distribute() state of the reference, amg_matrix.cpp:164); 1 (CUMULATED): the owned entries are complete.
 static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_status, int flags) {
+  Range rg("AMGMatrix::Mult");
   std::vector<Dist*>& M = c.members;
   if (M.empty()) throw Err("amgx_dist_apply: the communicator has no rank-partitioned hierarchy");
   if (c.kind == AMGX_COMM_LOCAL && (int)M.size() != c.nranks) throw Err("amgx_dist_apply: not all local ranks have been created");

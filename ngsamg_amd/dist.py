@@ -354,6 +354,7 @@ def interior_first(s):
         s.coords = np.ascontiguousarray(s.coords[perm])
     s.n_interior = int((~has_ghost).sum())
     s.iperm = iperm
+    s.perm0 = perm if getattr(s, "perm0", None) is None else s.perm0[perm]     # new -> the caller's original numbering
     return s
 
 

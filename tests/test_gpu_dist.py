@@ -266,3 +266,78 @@ def test_loopback_device_fused_kernels_on_rank_partitioned_levels(R, box, dim, d
     ref = Oracle(amg.global_levels(), sm_type="jacobi").apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+def test_bridged_reference_layout_on_device():
+    """NGSolve-style partition (duplicated interface dofs, partial-sum rows) -> owner rows (ngsamg_amd/bridge.py) -> native
+    distributed cycle; the DISTRIBUTED right-hand side is brought to the owners by amgx_halo_exchange(mode 1) on the
+    shared-dof map (DCCMap DIS2CO), the CUMULATED solution is returned to all copies by mode 0 (CO2CU)."""
+    import ctypes as C
+    import torch
+    from ngsamg_amd import _lib, bridge as B, dist as D
+    from oracle.pyoracle import Oracle
+    pgrid, gshape = (2, 2, 2), (15, 15, 15)
+    R = 8
+    comm = D.LoopbackComm(R)
+    locs, gids = zip(*[B.shared_poisson_partition(r, pgrid, gshape) for r in range(R)])
+    states, vmaps = B.from_shared_layout(comm, list(locs))
+    n = int(np.prod(gshape))
+    rng = np.random.default_rng(4)
+    free_g = np.ones(n)
+    for L, g in zip(locs, gids):
+        free_g[g] = L.free
+    bg = rng.standard_normal(n) * free_g
+    shares = [rng.uniform(0.2, 1.0, size=L.n_loc) for L in locs]
+    tot = np.zeros(n)
+    for g, s in zip(gids, shares):
+        np.add.at(tot, g, s)
+    loc_b = [bg[g] * s / tot[g] for g, s in zip(gids, shares)]          # DISTRIBUTED local vectors
+    # ---- shared-dof map on the device
+    lib = _lib.hip()
+    cc = C.c_void_p()
+    assert lib.amgx_comm_create(_lib.AMGX_COMM_LOCAL, R, 0, None, 0, C.byref(cc)) == 0
+    halos, keep, vecs = [], [], []
+    for r, vm in enumerate(vmaps):
+        d = _lib.amgx_halo_desc()
+        d.n_peers = vm.peers.size
+        d.peer_rank, d.send_ptr, d.send_idx, d.recv_ptr = _lib.ptr(vm.peers, C.c_int32), _lib.ptr(vm.send_ptr, C.c_int64), _lib.ptr(vm.send_idx, C.c_int32), _lib.ptr(vm.recv_ptr, C.c_int64)
+        h = C.c_void_p()
+        assert lib.amgx_halo_create(cc, C.byref(d), vm.n_own, vm.n_ext - vm.n_own, 1, r, C.byref(h)) == 0, lib.amgx_comm_last_error(cc)
+        halos.append(h)
+        vecs.append(torch.from_numpy(vm.to_ext(loc_b[r])).cuda())
+    hp = (C.c_void_p * R)(*halos)
+    vp = (C.c_void_p * R)(*[v.data_ptr() for v in vecs])
+    assert lib.amgx_halo_exchange(cc, R, hp, vp, 1) == 0, lib.amgx_comm_last_error(cc)
+    lib.amgx_comm_synchronize(cc)
+    ref_owned = B.accumulate_host(comm, vmaps, [vm.to_ext(v) for vm, v in zip(vmaps, loc_b)])
+    for r, vm in enumerate(vmaps):
+        assert np.allclose(vecs[r][:vm.n_own].cpu().numpy(), ref_owned[r], rtol=1e-14, atol=1e-14)
+        assert np.allclose(ref_owned[r], bg[gids[r][vm.perm[:vm.n_own]]], rtol=1e-13, atol=1e-13)
+    # ---- the cycle on the converted hierarchy (interior-first renumbering happens inside: keep the rank's own order)
+    order0 = [np.arange(s.n) for s in states]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=80, device=0, max_coarse_size=10)
+    # DistributedAMG renumbered the owned dofs [interior | boundary]; states[r].perm0 maps new -> bridge numbering
+    bs = [torch.from_numpy(ref_owned[r][states[r].perm0]).cuda() for r in range(R)]
+    xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in states]
+    amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    ref = Oracle(amg.global_levels(), sm_type="jacobi").apply(np.concatenate([b.cpu().numpy() for b in bs]))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+    # ---- CUMULATED solution back on every copy of a shared dof
+    for r, vm in enumerate(vmaps):
+        xo = np.empty(states[r].n)
+        xo[states[r].perm0] = xs[r].cpu().numpy()
+        vecs[r][:vm.n_own] = torch.from_numpy(xo).cuda()
+    assert lib.amgx_halo_exchange(cc, R, hp, vp, 0) == 0, lib.amgx_comm_last_error(cc)
+    lib.amgx_comm_synchronize(cc)
+    xg = np.full(n, np.nan)
+    for r, vm in enumerate(vmaps):
+        xl = vm.from_ext(vecs[r].cpu().numpy(), locs[r].n_loc)
+        prev = xg[gids[r]]
+        assert np.all(np.isnan(prev) | (prev == xl))              # all copies of a shared dof agree
+        xg[gids[r]] = xl
+    assert not np.isnan(xg).any()
+    for h in halos:
+        lib.amgx_halo_destroy(h)
+    lib.amgx_comm_destroy(cc)
