@@ -137,7 +137,8 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "global_applies_per_s": round(args.steps / elapsed, 2),
-            "config": {"workload": f"cfg4-style weak scaling of cfg2: global grid {tuple(pg[d] * nv for d in range(3))} = "
+            "config": {"workload": (f"cfg4: " if args.config == "cfg4" else "cfg4-style weak scaling of cfg2: ") +
+                                   f"global grid {tuple(pg[d] * nv for d in range(3))} = "
                                    f"{world} x {nv}^3 vertices, hashed jitter (seed 1), Dirichlet right|top, {args.smoother} omega=0.9, V(1,1)",
                        "parallelism": f"{world} ranks (one process per GPU), partition {pg}, {amg.k} rank-partitioned levels "
                                       f"[interior | boundary] with halo pack kernels + ncclSend/ncclRecv on a communication stream behind the C ABI "
@@ -201,7 +202,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--nv", type=int, default=215, help="vertices per direction (215 = cfg 2)")
+    ap.add_argument("--nv", type=int, default=None, help="vertices per direction (default 215 = cfg 2; 126 for cfg 3 / cfg 5)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2: 3D H1 Poisson ~10M DOF (the headline metric); cfg3: 3D elasticity 126^3 nodes, 3x3 fine / 6x6 coarse blocks; "
+                         "cfg5: the same with rotations, 6x6 blocks on every level (BASELINE.json configs[2], configs[4] single-GPU shape); "
+                         "cfg4 (with --gpus 8): 3D H1 Poisson 342^3 = 40M DOF as 2 x 2 x 2 boxes of 171^3 vertices (BASELINE.json configs[3])")
     ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "gs", "gs_mc"],
                     help="gs = Gauss-Seidel in the block-hybrid form (one launch per sweep); gs_mc = multicolour Gauss-Seidel (one launch per colour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,17 +273,38 @@ def main():
     from ngsamg_amd.hierarchy import Hierarchy
     from ngsamg_amd.device import DeviceAMGMatrix, vcycle_bytes, matrix_bytes
 
-    nv = args.nv
+    nv = args.nv if args.nv else (215 if args.config == "cfg2" else 171 if args.config == "cfg4" else 126)
+    if args.config == "cfg4":
+        os.environ["NGSAMG_PGRID"] = "box"
+        if world == 1 and not force_dist:
+            raise SystemExit("--config cfg4 is the rank-partitioned configuration: use --gpus 8 (or 2 / 4)")
+    if (world > 1 or force_dist) and args.config not in ("cfg2", "cfg4"):
+        raise SystemExit("--config cfg3 / cfg5 run on one GPU (the rank-partitioned elasticity path is not built yet)")
     if world > 1 or force_dist:
         run_distributed(args, torch, dist, world, rank, device, nv)
         return
 
     # ---- host setup (cold path, not timed) -------------------------------------------------------------
     t0 = time.time()
-    prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
-    A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
-    t1 = time.time()
-    H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
+    if args.config == "cfg2":
+        prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
+        A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
+        t1 = time.time()
+        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
+        wl = (f"cfg2: 3D P1 Poisson {nv}^3 = {prob.n} DOF, jittered Kuhn tets (seed 1), "
+              f"Dirichlet right|top, {args.smoother} omega=0.9, V(1,1), max_coarse_size=50")
+    else:
+        rot = args.config == "cfg5"
+        prob = fem.elasticity_fast((nv, nv, nv), dirichlet="left", mu=1.0, lam=0.5, rotations=rot)
+        A = Matrix(prob.n, prob.n, prob.bs, prob.bs, prob.rowptr, prob.col, prob.val)
+        t1 = time.time()
+        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=1, max_coarse_size=50, regularize_cmats=0 if rot else 1)
+        wl = (f"{args.config}: 3D linear elasticity {nv}^3 nodes = {prob.n * prob.bs} DOF, mu=1 lam=0.5, "
+              f"{'displacements + rotations, 6x6 blocks on every level' if rot else '3x3 blocks on level 0, 6x6 below'}, clamped left, "
+              f"block-{args.smoother} omega=0.9, V(1,1), max_coarse_size=50")
+    bs0 = prob.bs
+    free_s = np.repeat(prob.free, bs0).astype(np.float64)
+    n_s = prob.n * bs0
     t2 = time.time()
     dev_sm = {"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother]
     amg = DeviceAMGMatrix(H, sm_type=dev_sm, omega=0.9, mg_cycle="V", clev="inv", device=device,
@@ -291,7 +317,7 @@ def main():
 
     # ---- timed region: K applications, inputs resident in HBM ------------------------------------------
     rng = np.random.default_rng(0)
-    b_host = rng.standard_normal(prob.n) * prob.free
+    b_host = rng.standard_normal(n_s) * free_s
     stream = torch.cuda.Stream(device=device)
     with torch.cuda.stream(stream):
         b = torch.from_numpy(b_host).to(f"cuda:{device}")
@@ -332,7 +358,7 @@ def main():
     k_name, tname = "sell_spmv_kernel<EP_RES> (level 0: r = b - A x)", "traffic_spmv_l0.json"
     spmv_bytes = matrix_bytes(lv0.A) + 3 * V0
     k_ms = k_ms_b2b = None
-    if args.smoother == "jacobi":
+    if args.smoother == "jacobi" and args.config == "cfg2":
         try:
             # timed INSIDE the cycle (HIP events around the one kernel while whole cycles run): the figure rocprofv3's
             # kernel trace reports for it; the back-to-back repetition time is kept beside it
@@ -347,10 +373,13 @@ def main():
             k_ms = None
     if k_ms is None:
         k_ms = amg.time_op(0, 0, reps=50)
+        if args.config != "cfg2":
+            k_name = f"bsell_spmv_kernel<{bs0}, EP_RES> (level 0: r = b - A x, {bs0}x{bs0} blocks)"
+            tname = f"traffic_bsell_res_{args.config}.json"
     achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
     traffic = traffic_src = None
     tpath = os.path.join(ROOT, "profiles", tname)
-    if os.path.exists(tpath) and nv == 215:
+    if os.path.exists(tpath) and nv == (215 if args.config == "cfg2" else 126):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("hbm_bytes_per_launch")
@@ -368,11 +397,21 @@ def main():
     # whole cycle: bytes the cycle actually streams (device encodings) / time.  The algorithmic byte count of the reference's
     # op sequence divided by the same time is NOT a bandwidth for the folded cycle (it skips a pass over A and the
     # pass over P): it is reported as the speed-up measure it is.
-    if folded:
+    if folded and args.config == "cfg2":
         sb = 0
         for l in range(H.n_levels - 1):
             Vl, Vc = 8 * H.levels[l].n * H.levels[l].bs, 8 * H.levels[l + 1].n * H.levels[l + 1].bs
             sb += sum(amg.matrix_info(l, w)["stream_bytes"] for w in ("Apre", "PT", "Q")) + 5 * Vl + 2 * Vc
+    elif args.config != "cfg2":
+        # block levels: folded where Q exists (A once + PT + Q), literal otherwise (A twice + P + PT), device encodings
+        sb = 0
+        for l in range(H.n_levels - 1):
+            Vl, Vc = 8 * H.levels[l].n * H.levels[l].bs, 8 * H.levels[l + 1].n * H.levels[l + 1].bs
+            mi = {w: amg.matrix_info(l, w) for w in ("A", "P", "PT", "Q")}
+            if mi["Q"]["fmt"] is not None:
+                sb += mi["A"]["stream_bytes"] + mi["PT"]["stream_bytes"] + mi["Q"]["stream_bytes"] + 8 * Vl + 2 * Vc
+            else:
+                sb += 2 * mi["A"]["stream_bytes"] + mi["P"]["stream_bytes"] + mi["PT"]["stream_bytes"] + 15 * Vl + 2 * Vc
     else:
         sb = cycle_bytes
     roofline["cycle_streamed_bytes"] = int(sb)
@@ -423,7 +462,7 @@ def main():
         orc = Oracle(H.levels, sm_type="jacobi" if args.smoother == "jacobi" else "gs", omega=0.9, threads=cores)
         if cores > 1:
             orc.first_touch()                    # NUMA placement: every thread first-writes the rows it streams
-        xo = np.zeros(prob.n)
+        xo = np.zeros(n_s)
         orc.apply(b_host, xo)                    # warm-up (first touch of the work vectors)
         tc0 = time.perf_counter()
         orc.apply(b_host, xo)                    # duration estimate
@@ -452,12 +491,12 @@ def main():
                 xs = cg.Solve(b)
                 rt = torch.empty_like(b)
                 amg.MatVec(0, xs, rt)
-                fm = torch.from_numpy(prob.free.astype(np.float64)).to(b.device)     # the system lives on the free dofs
+                fm = torch.from_numpy(free_s).to(b.device)     # the system lives on the free dofs
                 g_res = float((torch.linalg.norm((b - rt) * fm) / torch.linalg.norm(b)).item())
                 stream.synchronize()
             xc, c_it, c_errs = orc.pcg(b_host, tol=1e-8, maxit=200)
             A0 = H.levels[0].A.to_scipy()
-            c_res = float(np.linalg.norm((b_host - A0 @ xc) * prob.free) / np.linalg.norm(b_host))
+            c_res = float(np.linalg.norm((b_host - A0 @ xc) * free_s) / np.linalg.norm(b_host))
             pcg = {"tol": 1e-8, "gpu_iterations": int(cg.iterations), "cpu_iterations": int(c_it),
                    "gpu_rel_residual": g_res, "cpu_rel_residual": c_res,
                    "solution_rel_diff": float(np.linalg.norm(xs.cpu().numpy() - xc) / np.linalg.norm(xc))}
@@ -480,14 +519,14 @@ def main():
         except Exception as e:
             log(f"1-thread baseline failed: {e!r}")
         cpu = {"value": round(1.0 / cpu_t, 3), "unit": "applies/s", "cores": cores, "kind": "port", "one_thread": one_t,
-               "sample": f"{reps} V-cycle applications of the same {prob.n}-DOF hierarchy (oracle/oracle.c, OpenMP over rows, first-touch placement)",
+               "sample": f"{reps} V-cycle applications of the same {n_s}-DOF hierarchy (oracle/oracle.c, OpenMP over rows, first-touch placement)",
                "GBs_algorithmic": round(cycle_bytes / cpu_t / 1e9, 1), "gpu_vs_oracle_rel_err": parity, "pcg": pcg}
         log(f"cpu baseline: {1.0 / cpu_t:.2f} applies/s on {cores} threads; GPU-vs-oracle rel. error {parity:.2e}")
 
     # what an unmodified host-pointer caller gets (vectors cross PCIe in both directions inside the call): never `value`
     host_rate = None
     try:
-        xh = np.empty(prob.n)
+        xh = np.empty(n_s)
         amg.Mult(b_host, xh)
         th = time.perf_counter()
         for _ in range(5):
@@ -512,12 +551,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel"),
+            "metric": ("V-cycle applies/sec (3D H1 Poisson ~10M DOF, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel")) if args.config == "cfg2"
+                      else f"V-cycle applies/sec (3D elasticity {nv}^3 nodes, block size {bs0}, block-{args.smoother} V(1,1))",
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg2: 3D P1 Poisson {nv}^3 = {prob.n} DOF, jittered Kuhn tets (seed 1), "
-                                   f"Dirichlet right|top, {args.smoother} omega=0.9, V(1,1), max_coarse_size=50",
+            "config": {"workload": wl,
                        "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
                        "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
                        "post_smoothing": ("folded into the prolongation: x' = z + (I - w Dinv A) P x_c, same result up to rounding "

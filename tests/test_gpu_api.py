@@ -20,11 +20,22 @@ def _mat(p):
     return Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
 
 
+def test_2d_lo_reference_size_and_budget():
+    """reference tests/h1/simple/test_2d_lo.py: unit square, maxh = 0.05 (~500 vertices), max_coarse_size 5, tol 1e-12,
+    ms = 30 -- same size class (23 x 23 vertices), same budget"""
+    from ngsamg_amd import ngs_amg
+    p = fem.poisson_fast((23, 23), dirichlet="left|top")
+    c = ngs_amg.Preconditioner(_mat(p), "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2)
+    Solve(_mat(p), p.load, c, ms=30)
+
+
 def test_2d_lo():
+    """the same problem 20x larger than the reference's test mesh: the build's own budget (34-36 iterations measured;
+    the host setup is a simplified SPW)"""
     from ngsamg_amd import ngs_amg
     p = fem.poisson_fast((101, 101), dirichlet="left|top")
     c = ngs_amg.Preconditioner(_mat(p), "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2)
-    sol, cg = Solve(_mat(p), p.load, c, ms=45)
+    sol, cg = Solve(_mat(p), p.load, c, ms=40)
     A = p.to_scipy()
     f = p.free.astype(bool)
     assert np.linalg.norm((A @ sol - p.load)[f]) < 1e-9 * np.linalg.norm(p.load)
@@ -60,9 +71,9 @@ def test_vec_h1(dim):
 def test_elast_3d_lo(rot):
     """reference tests/elasticity/mdim/simple/test_3d_lo.py: beam 10x1x1, mu=1, lam=0, tol 1e-6, ms 40"""
     from ngsamg_amd import NgsAMG
-    p = fem.elasticity_fast((41, 6, 6), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=(10.0, 1.0, 1.0))
+    p = fem.elasticity_fast((41, 5, 5), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=(10.0, 1.0, 1.0))   # maxh = 0.25
     c = NgsAMG.elast_3d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=10)
-    Solve(_mat(p), p.load, c, ms=60, tol=1e-6)
+    Solve(_mat(p), p.load, c, ms=40, tol=1e-6)           # the reference's budget
     assert c.GetBlockSize(0) == (6 if rot else 3) and c.GetBlockSize(1) == 6
 
 
@@ -212,7 +223,9 @@ def test_2d_coefficient_jumps(jump, geom):
 
     diri = "left|right|top|bottom" if geom == "squares" else "top|bottom"
     p = fem.poisson_fast((81, 81), dirichlet=diri, coef=coef)
-    budget = {"gs": 30 if geom == "squares" else 100, "bgs": 25}
+    # reference budgets: 25 (squares: default smoother; fibres: bgs).  Point GS on the fibres is NOT a reference test (its
+    # fibre test sets sm_type = bgs): kept as a record of the build's simple setup on anisotropic patterns
+    budget = {"gs": 25 if geom == "squares" else 100, "bgs": 25}
     for sm in ("gs", "bgs"):
         c = ngs_amg.Preconditioner(_mat(p), "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2,
                                    ngs_amg_sm_type=sm)
