@@ -182,6 +182,17 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *           around that one kernel; the average is what rocprofv3 --kernel-trace reports for it (roofline.achieved) */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
 
+/* Krylov solvers with all vectors resident on the GPU: the callers of the preconditioner on the
+ * reference side are NGSolve's CGSolver / GMRes (tests/h1/amg_utils.py:346).  Operator = the level-0 matrix of the handle,
+ * preconditioner = the handle's cycle (use_precond = 0: none).  x holds the initial guess and receives the solution.
+ *   amgx_pcg  : err_k = sqrt(|<C r_k, r_k>|), stops at err_k <= tol * err_0 (CGSolver's criterion)
+ *   amgx_gmres: restarted GMRES(restart), left-preconditioned, err_k = |C r_k|
+ * errs (optional, maxit + 1 entries) receives err_0 ... err_iters; *iters the iteration count.  BLAS-1 work runs in
+ * hand-written kernels with deterministic reductions; the host reads one scalar per iteration. */
+int amgx_pcg(amgx_handle h, const double* b, double* x, double tol, int maxit, int use_precond, int flags, double* errs, int32_t* iters);
+int amgx_gmres(amgx_handle h, const double* b, double* x, double tol, int maxit, int restart, int use_precond, int flags, double* errs,
+               int32_t* iters);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Rank-partitioned hierarchies (one process per GPU; SURVEY.md 8b "halo tables + RCCL communicator", 8e).
  *

@@ -223,7 +223,7 @@ AMGX_SYMBOLS = [
     "amgx_cycle_down", "amgx_cycle_up",
     "amgx_prolong", "amgx_matvec", "amgx_transfer_f2c",
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
-    "amgx_matrix_stream_bytes", "amgx_time_op",
+    "amgx_matrix_stream_bytes", "amgx_time_op", "amgx_pcg", "amgx_gmres",
     "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
     "amgx_comm_synchronize", "amgx_comm_info", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply",
     "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
@@ -270,6 +270,8 @@ def hip():
     lib.amgx_matrix_info.argtypes = [vp, C.c_int, C.c_int, c_i32p, c_i64p, c_i32p]
     lib.amgx_matrix_stream_bytes.argtypes = [vp, C.c_int, C.c_int, c_i64p]
     lib.amgx_time_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
+    lib.amgx_pcg.argtypes = [vp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, c_f64p, c_i32p]
+    lib.amgx_gmres.argtypes = [vp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_i32p]
     # rank-partitioned hierarchies
     lib.amgx_comm_unique_id.argtypes = [C.c_char_p]
     lib.amgx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]

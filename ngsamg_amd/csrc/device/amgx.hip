@@ -2306,4 +2306,5 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
 
 }  // extern "C"
 
+#include "krylov.hpp"
 #include "dist.hpp"

@@ -5,7 +5,9 @@
 // few, SMALL batches of loads in flight per wave with the next batch requested before the current one is consumed
 // (rows are short: a wave lives for only a few memory round trips, and bursts of gathers stall the CU's address path);
 // own-row epilogue operands requested ahead of the row product; gathers of x served by L2 / Infinity Cache.
-// No MFMA: SpMV with a single right-hand side is not a contraction.
+// No MFMA: SpMV with a single right-hand side is not a contraction.  Measured (tools/mfma_lab.hip, profiles/r02/mfma_ab.txt):
+// the 6x6 block-row product through v_mfma_f64_16x16x4_f64 (two block rows per instruction, 2 of 16 result columns used)
+// is 1.67x SLOWER than the VALU form at the cfg-5 shape and bit-identical.
 //
 // Matrix formats on the device (built once at amgx_create, see amgx.hip):
 //   SELL-64-pair ("sliced ELL"), G lanes per row: slices of 64/G consecutive rows = one wavefront; inside a slice the

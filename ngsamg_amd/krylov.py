@@ -70,3 +70,58 @@ class CGSolver:
                     self.iterations = stop
                     break
         return x
+
+
+class _NativeSolver:
+    """common part of the solvers that run completely inside the native library (amgx_pcg / amgx_gmres): hand-written
+    BLAS-1 kernels with deterministic reductions, scalars of the recurrences on the device, one scalar read per iteration"""
+
+    def __init__(self, mat, pre=None, tol=1e-12, maxsteps=100):
+        from .device import DeviceAMGMatrix
+        if not isinstance(mat, DeviceAMGMatrix):
+            raise TypeError("native Krylov solvers take a DeviceAMGMatrix (its level-0 matrix is the operator)")
+        if pre is not None and getattr(pre, "_dev", pre) is not mat and pre is not mat:
+            inner = getattr(getattr(pre, "GetAMGMatrix", lambda: None)(), "_dev", None)
+            if inner is not mat:
+                raise ValueError("native Krylov solvers precondition with the cycle of the same handle (pre = mat or None)")
+        self.mat, self.use_pre, self.tol, self.maxsteps = mat, pre is not None, tol, maxsteps
+        self.errors, self.iterations = [], 0
+
+    def _run(self, fn, rhs, sol, extra):
+        import ctypes as C
+        import numpy as np
+        from .device import _Vec, _is_torch
+        n = self.mat.sizes[0]
+        if sol is None:
+            if _is_torch(rhs):
+                import torch
+                sol = torch.zeros_like(rhs)
+            else:
+                sol = np.zeros(n)
+        vb, vx = _Vec(rhs, n, "rhs"), _Vec(sol, n, "sol", True)
+        errs = np.zeros(self.maxsteps + 1)
+        it = C.c_int32()
+        flags = self.mat._flags(vb, vx)
+        self.mat._ck(fn(self.mat._h, vb.addr, vx.addr, float(self.tol), int(self.maxsteps), *extra, int(self.use_pre), flags,
+                        errs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(it)))
+        self.iterations = int(it.value)
+        self.errors = errs[: self.iterations + 1].tolist()
+        return sol
+
+
+class NativeCGSolver(_NativeSolver):
+    """NGSolve CGSolver stand-in running inside libngsamg_hip (amgx_pcg): err_k = sqrt(|<C r_k, r_k>|), stop at err_k <= tol err_0"""
+
+    def Solve(self, rhs, sol=None):
+        return self._run(self.mat._lib.amgx_pcg, rhs, sol, ())
+
+
+class NativeGMResSolver(_NativeSolver):
+    """restarted, left-preconditioned GMRES inside libngsamg_hip (amgx_gmres); err_k = |C r_k|"""
+
+    def __init__(self, mat, pre=None, tol=1e-12, maxsteps=100, restart=30):
+        super().__init__(mat, pre, tol, maxsteps)
+        self.restart = int(restart)
+
+    def Solve(self, rhs, sol=None):
+        return self._run(self.mat._lib.amgx_gmres, rhs, sol, (self.restart,))

@@ -69,9 +69,11 @@ def test_vec_h1(dim):
 
 @pytest.mark.parametrize("rot", [False, True])
 def test_elast_3d_lo(rot):
-    """reference tests/elasticity/mdim/simple/test_3d_lo.py: beam 10x1x1, mu=1, lam=0, tol 1e-6, ms 40"""
+    """reference tests/elasticity/mdim/simple/test_3d_lo.py (test_3d_lo, test_3d_lo_R): mu=1, lam=0, tol 1e-6, ms 40"""
     from ngsamg_amd import NgsAMG
-    p = fem.elasticity_fast((41, 5, 5), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=(10.0, 1.0, 1.0))   # maxh = 0.25
+    # test_3d_lo: beam 10 x 1 x 1; test_3d_lo_R (rotations): beam 2 x 1 x 1; both maxh = 0.25
+    shape, ext = ((9, 5, 5), (2.0, 1.0, 1.0)) if rot else ((41, 5, 5), (10.0, 1.0, 1.0))
+    p = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=ext)
     c = NgsAMG.elast_3d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=10)
     Solve(_mat(p), p.load, c, ms=40, tol=1e-6)           # the reference's budget
     assert c.GetBlockSize(0) == (6 if rot else 3) and c.GetBlockSize(1) == 6
