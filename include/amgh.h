@@ -44,6 +44,9 @@ typedef struct amgh_options {
   int32_t dim;               /* spatial dimension                                     */
   int32_t energy;            /* 0 = H1 (h1_scal/h1_2d/h1_3d), 1 = elasticity          */
   int32_t log_level;
+  int32_t enable_multistep;  /* ngs_amg_enable_multistep: reach first_aaf by several concatenated coarsening steps of ~aaf each,   */
+                             /*   P = P_1 P_2 ... (reference default for H1: true, h1_impl.hpp:331; default HERE: 0, because the   */
+                             /*   concatenated P has ~3x the entries per row: fewer iterations, slower application)    */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -456,36 +456,71 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     if (lev > 0 && nf <= o.max_coarse_size) break;
     if (lev == 0 && nfree <= o.max_coarse_size && nfree == nf) break;
     double t0 = omp_get_wtime();
-    Graph G = strength_graph(F.A, F.free, dim, o.energy);
     const double target = (lev == 0) ? o.first_aaf : o.aaf;
-    std::vector<int32_t> agg;
-    int rounds = 0;
-    double t1 = omp_get_wtime();
-    int64_t nc = aggregate(G, F.free, target, o, agg, rounds);
-    double t2 = omp_get_wtime();
-    if (nc == 0 || nc >= nfree) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
-    BCSR W = prolongation_weights(G, agg, nc, o);
-    double t3 = omp_get_wtime();
     const int bs_f = F.A.br;
     const int bs_c = (o.energy == 1) ? dim + nrot : bs_f;
-    // coarse coordinates = mean of the aggregate's members
-    std::vector<double> xc;
-    if (!F.coords.empty()) {
-      xc.assign(nc * dim, 0.0);
-      std::vector<int32_t> cnt(nc, 0);
-      for (int64_t i = 0; i < nf; i++) if (agg[i] >= 0) { cnt[agg[i]]++; for (int d = 0; d < dim; d++) xc[(int64_t)agg[i] * dim + d] += F.coords[i * dim + d]; }
-      for (int64_t I = 0; I < nc; I++) for (int d = 0; d < dim; d++) xc[I * dim + d] /= std::max(1, cnt[I]);
-    }
-    F.P = block_prolongation(W, bs_f, bs_c, dim, o.energy, F.coords, xc);
-    double t4 = omp_get_wtime();
-    F.PT = transpose(F.P);
-    F.agg = agg;
+    // One coarsening step = pairwise rounds + smoothed prolongation + Galerkin product.  enable_multistep (reference
+    // base_factory: "multistep", H1 default, h1_impl.hpp:331): while the level is still larger than its target, another
+    // step is taken on the intermediate matrix and the prolongations are CONCATENATED (P = P_1 P_2 ...), the intermediate
+    // levels are not smoothed on.  Every sub-step coarsens by ~aaf with its own smoothed prolongation, so the concatenated
+    // P interpolates from a wider coarse neighbourhood than one smoothing step over the big final aggregates could.
     Level C;
-    double t5 = omp_get_wtime();
-    C.A = restrict_matrix(F.PT, F.A, F.P);
+    std::vector<int32_t> agg;
+    std::vector<double> xc;
+    int rounds = 0, substeps = 0;
+    int64_t nc = 0;
+    {
+      const BCSR* curA = &F.A;
+      BCSR tmpA;
+      std::vector<uint8_t> cur_free = F.free;
+      std::vector<double> cur_coords = F.coords;
+      BCSR Ptot;
+      bool failed = false;
+      while (true) {
+        Graph G = strength_graph(*curA, cur_free, dim, o.energy);
+        const double step_target = (o.enable_multistep && target < o.aaf) ? std::max(target, o.aaf) : target;
+        std::vector<int32_t> sagg;
+        int r = 0;
+        int64_t cur_free_n = 0;
+        for (auto f : cur_free) cur_free_n += f;
+        const int64_t snc = aggregate(G, cur_free, step_target, o, sagg, r);
+        if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }
+        rounds += r;
+        BCSR W = prolongation_weights(G, sagg, snc, o);
+        const int sbf = curA->br;
+        std::vector<double> sxc;
+        if (!cur_coords.empty()) {
+          sxc.assign(snc * dim, 0.0);
+          std::vector<int32_t> cnt(snc, 0);
+          const int64_t cn = curA->n_rows;
+          for (int64_t i = 0; i < cn; i++) if (sagg[i] >= 0) { cnt[sagg[i]]++; for (int d = 0; d < dim; d++) sxc[(int64_t)sagg[i] * dim + d] += cur_coords[i * dim + d]; }
+          for (int64_t I = 0; I < snc; I++) for (int d = 0; d < dim; d++) sxc[I * dim + d] /= std::max(1, cnt[I]);
+        }
+        BCSR Pk = block_prolongation(W, sbf, bs_c, dim, o.energy, cur_coords, sxc);
+        BCSR PkT = transpose(Pk);
+        BCSR nextA = restrict_matrix(PkT, *curA, Pk);
+        if (substeps == 0) { Ptot = std::move(Pk); agg = sagg; }
+        else {
+          Ptot = matmul(Ptot, Pk);
+          for (auto& a : agg) if (a >= 0) a = sagg[a];
+        }
+        tmpA = std::move(nextA);
+        curA = &tmpA;
+        cur_free.assign(snc, 1);
+        cur_coords = std::move(sxc);
+        nc = snc;
+        substeps++;
+        if (!o.enable_multistep || (double)nc <= 1.3 * target * (double)nfree || substeps >= 4) break;
+      }
+      if (failed || substeps == 0) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
+      F.P = std::move(Ptot);
+      F.PT = transpose(F.P);
+      F.agg = agg;
+      C.A = std::move(tmpA);
+      xc = std::move(cur_coords);
+    }
     double t6 = omp_get_wtime();
-    log << "  time: graph " << t1 - t0 << " agg " << t2 - t1 << " weights " << t3 - t2 << " blockP " << t4 - t3
-        << " transpose " << t5 - t4 << " rap " << t6 - t5 << "\n";
+    log << "  time: coarsening step(s) " << t6 - t0 << " (" << substeps << " sub-step" << (substeps == 1 ? "" : "s") << ")\n";
     C.free.assign(nc, 1);
     C.coords = std::move(xc);
     log << "  rounds=" << rounds << " nc=" << nc << " P nnz=" << F.P.nnz() << "\n";

@@ -12,6 +12,7 @@ struct Options {
   int64_t max_coarse_size = 50;
   double first_aaf = 0.05;       // target n_1/n_0      (h1_impl.hpp:333)
   double aaf = 0.125;            // target n_{l+1}/n_l  (h1_impl.hpp:334)
+  int enable_multistep = 0;      // concatenate several coarsening steps until a level reaches its target (h1_impl.hpp:331)
   // smoothed prolongation (h1_impl.hpp:320-324, elasticity_pc_impl.hpp:58-62)
   int enable_sp = 1;
   double sp_omega = 1.0;

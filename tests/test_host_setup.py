@@ -140,3 +140,22 @@ def test_setup_errors():
     e = fem.elasticity_fast((4, 4, 4))
     with pytest.raises(NgsAMGError):
         Hierarchy(to_matrix(e), e.free, None, dim=3, energy=1)     # elasticity needs coordinates
+
+
+@pytest.mark.parametrize("shape,dim", [((65, 65), 2), ((21, 21, 21), 3)])
+def test_multistep_concatenated_prolongation(shape, dim):
+    """ngs_amg_enable_multistep (reference h1_impl.hpp:331): a level is reached by several concatenated coarsening steps;
+    the concatenated P still reproduces constants, P^T is its exact transpose and the coarse matrix is the Galerkin product"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    p = fem.poisson_fast(shape, dirichlet="left|top")
+    H = Hierarchy(to_matrix(p), p.free, p.coords, dim=dim, energy=0, max_coarse_size=5, enable_multistep=1)
+    assert H.n_levels >= 3
+    for l, L in enumerate(H.levels[:-1]):
+        P, PT, A = L.P.to_scipy(), L.PT.to_scipy(), L.A.to_scipy()
+        Ac = H.levels[l + 1].A.to_scipy()
+        assert abs(PT - P.T).max() == 0.0
+        assert abs(Ac - P.T @ A @ P).max() < 1e-11 * abs(A).max() * 50
+        rs = np.asarray(P.sum(axis=1)).ravel()
+        free = L.free.astype(bool)
+        assert np.allclose(rs[free], 1.0, atol=1e-13)
+        assert L.agg is not None and L.agg.max() < H.levels[l + 1].n
