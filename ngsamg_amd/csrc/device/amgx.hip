@@ -147,6 +147,9 @@ struct DevGS {                          // colour-major data for multicolour Gau
   // block: colour-major row list over the CSR of A
   std::vector<int> color_row_ptr;       // [n_colors+1]
   DevBuf<int32_t> rowlist;
+  // block, preferred: colour-major BSELL copy (bgs_bsell_color_kernel); color_slice_ptr / rowid as in the scalar form
+  DevMatrix bcopy;
+  bool bsell_ok = false;
 };
 
 struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_kernel): blocks of B consecutive rows
@@ -394,30 +397,32 @@ static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
 }
 
 // block SELL image of a square-block matrix (see kernels.hpp BSellMat); returns false if the padding would exceed `max_pad`
-static bool build_bsell(const amgx_matrix& A, DevMatrix& D, double max_pad) {
+// rows (optional): the block rows in storage order (-1 = padding slot), m of them; default = natural order
+static bool build_bsell(const amgx_matrix& A, DevMatrix& D, double max_pad, const int32_t* rows = nullptr, int64_t m = -1) {
   const int bs = A.br;
   const int RB = WAVE / bs;
-  const int64_t n = A.n_rows;
+  const int64_t n = rows ? m : A.n_rows;
   const int64_t ns = (n + RB - 1) / RB;
+  auto row_of = [&](int64_t q) -> int64_t { return q < n ? (rows ? rows[q] : q) : -1; };
   std::vector<int64_t> sp(ns + 1, 0);
   for (int64_t s = 0; s < ns; ++s) {
     int w = 0;
-    for (int64_t r = s * RB; r < std::min<int64_t>(n, (s + 1) * RB); ++r) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+    for (int64_t q = s * RB; q < std::min<int64_t>(n, (s + 1) * RB); ++q) { const int64_t r = row_of(q); if (r >= 0) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r])); }
     sp[s + 1] = sp[s] + w;
   }
-  const int64_t steps = sp[ns], nnz = A.rowptr[n];
+  const int64_t steps = sp[ns], nnz = A.rowptr[A.n_rows];
   if (nnz == 0 || (double)steps * RB > max_pad * (double)nnz) return false;
   std::vector<int32_t> col((size_t)steps * RB, 0);
   std::vector<double> val((size_t)steps * bs * WAVE, 0.0);
   for (int64_t s = 0; s < ns; ++s) {
     const int w = (int)(sp[s + 1] - sp[s]);
     for (int rb = 0; rb < RB; ++rb) {
-      const int64_t r = s * RB + rb;
-      const int64_t rbeg = r < n ? A.rowptr[r] : 0;
-      const int len = r < n ? (int)(A.rowptr[r + 1] - rbeg) : 0;
+      const int64_t r = row_of(s * RB + rb);
+      const int64_t rbeg = r >= 0 ? A.rowptr[r] : 0;
+      const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rbeg) : 0;
       for (int k = 0; k < w; ++k) {
         const int64_t kk = sp[s] + k;
-        col[kk * RB + rb] = k < len ? A.col[rbeg + k] : (int32_t)std::min<int64_t>(r, n - 1);   // padding: a valid block column
+        col[kk * RB + rb] = k < len ? A.col[rbeg + k] : (int32_t)std::min<int64_t>(std::max<int64_t>(r, 0), A.n_rows - 1);   // padding: a valid block column
         if (k >= len) continue;
         const double* b = A.val + (rbeg + k) * bs * bs;
         double* vk = val.data() + kk * (bs * WAVE);
@@ -859,6 +864,14 @@ struct Handle {
           default: LAUNCH_GSC(16); break;
         }
 #undef LAUNCH_GSC
+      } else if (g.bsell_ok) {
+        const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
+        if (s1 == s0) continue;
+        const int grid = (s1 - s0 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        const BSellMat BM = g.bcopy.bsell.view();
+        if (L.bs == 6) hipLaunchKernelGGL((bgs_bsell_color_kernel<6>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
+        else if (L.bs == 3) hipLaunchKernelGGL((bgs_bsell_color_kernel<3>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
+        else hipLaunchKernelGGL((bgs_bsell_color_kernel<2>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
       } else {
         const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
         if (r1 == r0) continue;
@@ -1344,6 +1357,25 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
     std::vector<int> pos(g.color_row_ptr.begin(), g.color_row_ptr.end() - 1);
     for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) rows[pos[d.color[i]]++] = (int32_t)i;
     g.rowlist.upload(rows);
+    // colour-major BSELL copy: every colour padded to whole slices of RB block rows (big levels: one more copy of A,
+    // 2x the sweep speed; small levels keep the CSR row-list kernel: their colours are shorter than a slice)
+    const int bs = d.A.br;
+    int64_t min_rows = 4096;
+    if (const char* e = std::getenv("AMGX_BGS_BSELL_MIN")) min_rows = std::atoll(e);      // test hook
+    if ((bs == 2 || bs == 3 || bs == 6) && n / std::max(1, nc) >= min_rows && !std::getenv("AMGX_NO_BGS_BSELL")) {
+      const int RB = WAVE / bs;
+      std::vector<int64_t> cstart(nc + 1, 0);
+      for (int c = 0; c < nc; ++c) cstart[c + 1] = cstart[c] + ((cnt[c + 1] + RB - 1) / RB) * RB;
+      std::vector<int32_t> prow(cstart[nc], -1);
+      std::vector<int64_t> p2(cstart.begin(), cstart.end() - 1);
+      for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0) prow[p2[d.color[i]]++] = (int32_t)i;
+      if (build_bsell(d.A, g.bcopy, 1.6, prow.data(), (int64_t)prow.size())) {
+        g.color_slice_ptr.resize(nc + 1);
+        for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / RB);
+        g.rowid.upload(prow);
+        g.bsell_ok = true;
+      }
+    }
   }
 }
 

@@ -748,6 +748,56 @@ __global__ __launch_bounds__(BLOCK) void bgs_color_kernel(int list_begin, int li
   if (active && g == 0) x[i] += u;
 }
 
+// multicolour Gauss-Seidel, block BS x BS, on a COLOUR-MAJOR BSELL copy of A (slices never cross a colour): the matrix
+// streams in aligned 1 KiB chunks like bsell_spmv_kernel (the CSR row-list kernel above reads 8-byte elements at block
+// strides: 2-3 TB/s).  x_B += Dinv_B (b_B - A_B: x), the block solve goes through wave shuffles.  rowid[slot] = block row
+// (or -1: padding).  In place: rows of one colour are not coupled, a block row is read and written by one lane group.
+template <int BS>
+__global__ __launch_bounds__(BLOCK) void bgs_bsell_color_kernel(int slice_begin, int slice_end, BSellMat M,
+                                                                const int32_t* __restrict__ rowid, const double* __restrict__ dinv,
+                                                                const double* __restrict__ b, double* x) {
+  constexpr int RB = WAVE / BS;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(slice_begin + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (s >= slice_end) return;
+  const int rbl = lane / BS < RB ? lane / BS : RB - 1;
+  const int r = lane % BS;
+  const int brow = rowid[(int64_t)s * RB + rbl];
+  const bool active = lane < RB * BS && brow >= 0;
+  const int64_t k0 = M.slice_ptr[s];
+  const int w = (int)(M.slice_ptr[s + 1] - k0);
+  const double* __restrict__ vb = M.val + k0 * (BS * WAVE);
+  const int32_t* __restrict__ cb = M.col + k0 * RB;
+  const int64_t i = (int64_t)(brow >= 0 ? brow : 0) * BS + r;
+  double bv = 0.0, od[BS];
+#pragma unroll
+  for (int c = 0; c < BS; ++c) od[c] = 0.0;
+  if (active) {
+    bv = b[i];
+#pragma unroll
+    for (int c = 0; c < BS; ++c) od[c] = dinv[(int64_t)brow * (BS * BS) + r * BS + c];
+  }
+  double acc = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < w; ++k) {
+    const int c = cb[k * RB + rbl];
+    const double* xv = x + (int64_t)c * BS;
+    const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) {
+      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+      acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+    }
+    if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+  }
+  const double t = active ? bv - acc : 0.0;
+  const int base = lane - r;
+  double u = 0.0;
+#pragma unroll
+  for (int c = 0; c < BS; ++c) u += od[c] * __shfl(t, base + c, WAVE);
+  if (active) x[i] += u;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Column-blocked restriction  b_c = P^T r  for large scalar levels (reference ProlMap::TransferF2C,
 // dof_map.cpp:636-654).  The gather form over P^T touches ~40 different cache lines of r per coarse row and is

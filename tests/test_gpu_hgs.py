@@ -91,3 +91,22 @@ def test_hgs_iterations_within_15_percent_of_sequential_gs():
     cg.Solve(torch.from_numpy(b).cuda())
     _, it_seq, _ = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-12, maxit=200)
     assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("cycle", ["V", "W"])
+def test_block_gs_on_colour_major_bsell(rot, cycle, monkeypatch):
+    """point-block Gauss-Seidel of the elasticity levels through bgs_bsell_color_kernel (colour-major BSELL copy; big
+    levels only in production, forced onto the small test levels here) == the oracle's GS in colour order"""
+    from tests.problems import elasticity_case
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_BGS_BSELL_MIN", "1")
+    p, H = elasticity_case((9, 8, 7), rot, 10)
+    dev = DeviceAMGMatrix(H, sm_type="gs", mg_cycle=cycle, device=0)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = Oracle(H.levels, sm_type="gs_mc", cycle=cycle).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
