@@ -816,12 +816,14 @@ struct Handle {
   void copy(double* dst, const double* src, int64_t n) { if (n && dst != src) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, stream)); }
 
   // x (+)= omega * dinv * v
-  void diag_apply(const DevLevel& L, const double* v, double* x, bool add) {
-    if (L.n == 0) return;
-    const int grid = grid_for(L.n);
+  // rows: block rows to process (default: the owned rows; a rank-partitioned level may ask for its ghost rows too)
+  void diag_apply(const DevLevel& L, const double* v, double* x, bool add, int64_t rows = -1) {
+    if (rows < 0) rows = L.n;
+    if (rows == 0) return;
+    const int grid = grid_for(rows);
 #define LAUNCH_D(BS)                                                                                                   \
-  if (add) hipLaunchKernelGGL((diag_apply_kernel<BS, true>), dim3(grid), dim3(BLOCK), 0, stream, L.n, L.dinv.p, v, x, L.omega); \
-  else hipLaunchKernelGGL((diag_apply_kernel<BS, false>), dim3(grid), dim3(BLOCK), 0, stream, L.n, L.dinv.p, v, x, L.omega)
+  if (add) hipLaunchKernelGGL((diag_apply_kernel<BS, true>), dim3(grid), dim3(BLOCK), 0, stream, rows, L.dinv.p, v, x, L.omega); \
+  else hipLaunchKernelGGL((diag_apply_kernel<BS, false>), dim3(grid), dim3(BLOCK), 0, stream, rows, L.dinv.p, v, x, L.omega)
     switch (L.bs) {
       case 1: LAUNCH_D(1); break;
       case 2: LAUNCH_D(2); break;
@@ -1023,6 +1025,12 @@ struct Handle {
       spmv_ep<EP_PRE>(L.Apre, b, r, EpArgs{b, nullptr, L.dinv.p, L.omega, x, ep_nt | (fold ? EPF_FOLD : 0)}, sp);
     } else if (sp.part == PART_INT) {
       return;                                  // the other forms are not split: they run completely in the boundary part
+    } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI && L.ncols > L.n && !fold) {
+      // rank-partitioned level without a pre-smoothing image (block levels): x = omega * Dinv * b is needed on the ghost
+      // rows too (their b and dinv entries came with the exchange / the setup), so it is formed in the gathered buffer
+      diag_apply(L, b, L.tmp.p, false, L.ncols);
+      residual(L.A, L.tmp.p, b, r);
+      copy(x, L.tmp.p, L.len());
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       if (fold && L.bs > 1) {
         // x_pre = omega * Dinv * b into tmp; then ONE pass: r = b - A x_pre and z = x_pre + omega * Dinv * r

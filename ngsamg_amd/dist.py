@@ -234,8 +234,17 @@ class RankState:
     pass
 
 
-def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, seed=1):
-    """Rows of the global P1 Poisson matrix owned by `rank` (box of `box` vertices per rank), columns [owned | ghost]."""
+def _vexp(idx, bs):
+    """scalar indices of the block rows idx (AoS: entry = bs * dof + comp)"""
+    idx = np.asarray(idx, dtype=np.int64)
+    if bs == 1:
+        return idx
+    return (idx[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
+
+
+def _assemble_owned(rank, pgrid, box, kind, bs, mu, lam, dirichlet, jitter, seed, extent=None):
+    """Rows of the global P1 matrix (kind 0: Poisson, 1: elasticity, 2: elasticity with rotations) owned by `rank` (box of
+    `box` vertices per rank), columns [owned | ghost].  Block problems are held as scalar CSR with AoS numbering."""
     dim = len(pgrid)
     gshape = tuple(pgrid[d] * box[d] for d in range(dim))
     pc = np.unravel_index(rank, pgrid)
@@ -245,6 +254,8 @@ def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, 
     ehi = [min(gshape[d], hi[d] + 1) for d in range(dim)]
     eshape = tuple(ehi[d] - elo[d] for d in range(dim))
     X = hashed_coords(elo, ehi, gshape, jitter, seed)
+    if extent is not None:
+        X = X * np.asarray(extent, dtype=float)
     ne = int(np.prod(eshape))
     coords = np.ascontiguousarray(X.reshape(ne, dim))
     lib = _lib.host()
@@ -253,17 +264,20 @@ def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, 
     _lib.hcheck(lib.amgh_kuhn_pattern(dim, _lib.ptr(shp, C.c_int64), _lib.ptr(rowptr, C.c_int64)))
     nnz = int(rowptr[-1])
     col = np.empty(nnz, dtype=np.int32)
-    val = np.empty(nnz)
-    _lib.hcheck(lib.amgh_kuhn_assemble(dim, _lib.ptr(shp, C.c_int64), _lib.ptr(coords, C.c_double), 0, 1, 1.0, 0.0, None,
+    val = np.empty(nnz * bs * bs)
+    _lib.hcheck(lib.amgh_kuhn_assemble(dim, _lib.ptr(shp, C.c_int64), _lib.ptr(coords, C.c_double), int(kind), int(bs), float(mu), float(lam), None,
                                        _lib.ptr(rowptr, C.c_int64), _lib.ptr(col, C.c_int32), _lib.ptr(val, C.c_double), None))
-    A_ext = sp.csr_matrix((val, col, rowptr), shape=(ne, ne))
+    if bs == 1:
+        A_ext = sp.csr_matrix((val, col, rowptr), shape=(ne, ne))
+    else:
+        A_ext = sp.bsr_matrix((val.reshape(nnz, bs, bs), col, rowptr), shape=(ne * bs, ne * bs)).tocsr()
+    Pat = sp.csr_matrix((np.ones(nnz), col, rowptr), shape=(ne, ne))          # vertex graph
     # owned vertices inside the extended box, lexicographic
     eidx = np.arange(ne).reshape(eshape)
     sl = tuple(slice(lo[d] - elo[d], hi[d] - elo[d]) for d in range(dim))
     owned_e = eidx[sl].reshape(-1)
     n_own = owned_e.size
-    A_rows = A_ext[owned_e]                       # complete rows (all cells around an owned vertex are in the ext box)
-    used = np.unique(A_rows.indices)
+    used = np.unique(Pat[owned_e].indices)
     is_owned = np.zeros(ne, dtype=bool)
     is_owned[owned_e] = True
     ghost_e = used[~is_owned[used]]
@@ -277,7 +291,9 @@ def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, 
     newidx = np.full(ne, -1, dtype=np.int64)
     newidx[owned_e] = np.arange(n_own)
     newidx[ghost_e] = n_own + np.arange(ghost_e.size)
-    A_loc = sp.csr_matrix((A_rows.data, newidx[A_rows.indices], A_rows.indptr), shape=(n_own, n_own + ghost_e.size))
+    A_rows = sp.csr_matrix(A_ext[_vexp(owned_e, bs)])    # complete rows (all cells around an owned vertex are in the ext box)
+    cv, cc = np.divmod(A_rows.indices, bs)
+    A_loc = sp.csr_matrix((A_rows.data, newidx[cv] * bs + cc, A_rows.indptr), shape=(n_own * bs, (n_own + ghost_e.size) * bs))
     A_loc.sort_indices()
     ocoord = np.stack(np.unravel_index(owned_e, eshape), axis=1) + np.asarray(elo)
     free = np.ones(n_own, dtype=np.uint8)
@@ -288,7 +304,7 @@ def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, 
         ax, v = names[nm]
         free[ocoord[:, ax] == v] = 0
     st = RankState()
-    st.rank, st.n = rank, n_own
+    st.rank, st.n, st.bs = rank, n_own, int(bs)
     st.A = A_loc
     st.free = free
     st.coords = coords[owned_e]
@@ -297,14 +313,37 @@ def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, 
     return st
 
 
+def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, seed=1):
+    """Rows of the global P1 Poisson matrix owned by `rank` (box of `box` vertices per rank), columns [owned | ghost]."""
+    return _assemble_owned(rank, pgrid, box, 0, 1, 1.0, 0.0, dirichlet, jitter, seed)
+
+
+def assemble_elasticity_owned(rank, pgrid, box, rotations=False, mu=1.0, lam=0.5, dirichlet="left", jitter=0.2, seed=1, extent=None):
+    """The same for 3D / 2D linear elasticity: dim x dim blocks, or (dim + nrot)^2 blocks with rotational dofs
+    (the model problems of ngsamg_amd.fem.elasticity_fast); the state carries bs and is used with energy = 1"""
+    dim = len(pgrid)
+    bs = dim + (dim * (dim - 1) // 2 if rotations else 0)
+    return _assemble_owned(rank, pgrid, box, 2 if rotations else 1, bs, mu, lam, dirichlet, jitter, seed, extent)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # distributed setup
 # ------------------------------------------------------------------------------------------------------------
 
-def _mat(A):
+def _mat(A, br=1, bc=None):
+    """host (block-)CSR Matrix from a scalar scipy matrix with AoS numbering (br x bc blocks, every touched block stored fully)"""
+    bc = br if bc is None else bc
     A = sp.csr_matrix(A)
     A.sort_indices()
-    return Matrix(A.shape[0], A.shape[1], 1, 1, A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data)
+    if br == 1 and bc == 1:
+        return Matrix(A.shape[0], A.shape[1], 1, 1, A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data)
+    B = sp.bsr_matrix(A, blocksize=(br, bc))
+    B.sort_indices()
+    return Matrix(A.shape[0] // br, A.shape[1] // bc, br, bc, B.indptr.astype(np.int64), B.indices.astype(np.int32), B.data)
+
+
+def _bs(s):
+    return int(getattr(s, "bs", 1))
 
 
 def _spmm(A, B):
@@ -337,15 +376,15 @@ def interior_first(s):
     purpose: split_ind, gssmoother.cpp:664-678; stages in hybrid_base_smoother.cpp:501-574).  The peers still address
     this rank's vertices by the old numbers; _send_lists(..., translate=True) settles that."""
     A = sp.csr_matrix(s.A)
-    n = s.n
-    rows = np.repeat(np.arange(n), np.diff(A.indptr))
+    n, bs = s.n, _bs(s)
+    rows = np.repeat(np.arange(n * bs), np.diff(A.indptr)) // bs
     has_ghost = np.zeros(n, dtype=bool)
-    has_ghost[rows[A.indices >= n]] = True
+    has_ghost[rows[A.indices >= n * bs]] = True
     perm = np.concatenate([np.nonzero(~has_ghost)[0], np.nonzero(has_ghost)[0]])        # new -> old
     iperm = np.empty(n, dtype=np.int64)
     iperm[perm] = np.arange(n)
-    colmap = np.concatenate([iperm, n + np.arange(A.shape[1] - n)])
-    A2 = sp.csr_matrix(A[perm])
+    colmap = _vexp(np.concatenate([iperm, n + np.arange(A.shape[1] // bs - n)]), bs)
+    A2 = sp.csr_matrix(A[_vexp(perm, bs)])
     A2 = sp.csr_matrix((A2.data, colmap[A2.indices], A2.indptr), shape=A.shape)
     A2.sort_indices()
     s.A = A2
@@ -404,80 +443,102 @@ def _symmetrise(comm, states, sends, dtype):
 
 
 def _exchange_ghost_values(comm, states, owned_vals):
-    """owner -> ghosts for a per-vertex array (setup-time, host)"""
-    sends = [{q: np.ascontiguousarray(v[idx]) for q, idx in s.send.items()} for s, v in zip(states, owned_vals)]
-    sends = _symmetrise(comm, states, sends, owned_vals[0].dtype)
+    """owner -> ghosts for a per-vertex array, 1-D or [n, k] (setup-time, host)"""
+    k = owned_vals[0].shape[1:] if owned_vals[0].ndim > 1 else ()
+    dt = owned_vals[0].dtype
+    sends = [{q: np.ascontiguousarray(v[idx]).reshape(-1) for q, idx in s.send.items()} for s, v in zip(states, owned_vals)]
+    sends = _symmetrise(comm, states, sends, dt)
     recvs = comm.exchange(sends)
     outs = []
     for s, r in zip(states, recvs):
-        g = np.zeros(s.ghost_owner.size, dtype=owned_vals[0].dtype)
+        g = np.zeros((s.ghost_owner.size,) + k, dtype=dt)
         for q, (a, b) in s.recv_seg.items():
-            g[a:b] = r[q]
+            g[a:b] = r[q].reshape((b - a,) + k)
         outs.append(g)
     return outs
 
 
+def _take_rows(indptr, idx):
+    """positions of the entries of the rows idx of a CSR structure, row after row"""
+    idx = np.asarray(idx, dtype=np.int64)
+    lens = (indptr[idx + 1] - indptr[idx]).astype(np.int64)
+    tot = int(lens.sum())
+    if tot == 0:
+        return lens, np.empty(0, dtype=np.int64)
+    start = np.repeat(indptr[idx] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+    return lens, start + np.arange(tot)
+
+
+_SETUP_ONLY_KEYS = ("dist_min_rows", "gs_stage_min_rows", "energy")
+
+
 def coarsen_distributed_level(comm, states, dim, first, opts):
-    """one distributed coarsening step: local aggregation + prolongation, halo of P rows, Galerkin product"""
+    """one distributed coarsening step: local aggregation + prolongation, halo of P rows, Galerkin product.
+    Block levels (elasticity: opts["energy"] = 1) are handled through their scalar CSR images; the prolongation travels
+    as block rows (fine block size bf, coarse block size bc = dim + nrot)."""
     o = dict(opts)
+    energy = int(o.get("energy", 0))
     nxt = []
-    P_owns = []
+    P_blk = []
     stuck = False
     for s in states:
-        A_oo = sp.csr_matrix(s.A[:, :s.n])
+        bf = _bs(s)
+        A_oo = sp.csr_matrix(s.A[:, :s.n * bf])
         kw = dict(o)
-        kw["first_aaf"] = o.get("first_aaf", 0.05 if dim == 3 else 0.1) if first else o.get("aaf", 2.0 ** -dim)
+        dflt = (0.05 if dim == 3 else 0.1) if energy == 0 else (0.1 if dim == 3 else 0.15)
+        kw["first_aaf"] = o.get("first_aaf", dflt) if first else o.get("aaf", 2.0 ** -dim)
         kw["max_levels"] = 2
         kw["max_coarse_size"] = 1
-        H = Hierarchy(_mat(A_oo), s.free, s.coords, dim=dim, energy=0, **{k: v for k, v in kw.items() if k not in ("dist_min_rows",)})
+        H = Hierarchy(_mat(A_oo, bf), s.free, s.coords, dim=dim, energy=energy, **{k: v for k, v in kw.items() if k not in _SETUP_ONLY_KEYS})
         if H.n_levels < 2:
             stuck = True
             H = None
             break
-        P = sp.csr_matrix(H.levels[0].P.to_scipy())
+        PM = H.levels[0].P
+        bc = PM.bc
         agg = np.array(H.levels[0].agg, copy=True)        # blocks of the block smoother (never cross ranks)
         c = RankState()
-        c.rank = s.rank
-        c.n = P.shape[1]
+        c.rank, c.n, c.bs = s.rank, PM.n_cols, bc
         c.coords = H.levels[1].coords.copy() if H.levels[1].coords is not None else None
         # coarse numbering [interior | boundary]: a coarse row can only reach a coarse ghost through a fine row that has a
         # ghost column, so "some fine vertex of my prolongation column is a boundary row" is a safe boundary test
         Af = sp.csr_matrix(s.A)
-        frows = np.repeat(np.arange(s.n), np.diff(Af.indptr))
+        frows = np.repeat(np.arange(s.n * bf), np.diff(Af.indptr)) // bf
         bnd_f = np.zeros(s.n, dtype=np.float64)
-        bnd_f[frows[Af.indices >= s.n]] = 1.0
-        bnd_c = (abs(P).T @ bnd_f) > 0
+        bnd_f[frows[Af.indices >= s.n * bf]] = 1.0
+        Pat = sp.csr_matrix((np.ones(PM.col.size), PM.col, PM.rowptr), shape=(s.n, c.n))
+        bnd_c = (Pat.T @ bnd_f) > 0
         permc = np.concatenate([np.nonzero(~bnd_c)[0], np.nonzero(bnd_c)[0]])
         ipermc = np.empty(c.n, dtype=np.int64)
         ipermc[permc] = np.arange(c.n)
-        P = sp.csr_matrix((P.data, ipermc[P.indices], P.indptr), shape=P.shape)
-        P.sort_indices()
+        Pb = sp.bsr_matrix((PM.val.reshape(-1, bf, bc).copy(), ipermc[PM.col], PM.rowptr.copy()), shape=(s.n * bf, c.n * bc))
+        Pb.sort_indices()
         if c.coords is not None:
             c.coords = np.ascontiguousarray(c.coords[permc])
         c.n_interior = int((~bnd_c).sum())
         s.agg = np.where(agg >= 0, ipermc[np.maximum(agg, 0)], -1).astype(np.int32)
-        P_owns.append(P)
+        P_blk.append((Pb.indptr.astype(np.int64), Pb.indices.astype(np.int64), np.asarray(Pb.data), bf, bc))
         c.free = np.ones(c.n, dtype=np.uint8)
         nxt.append(c)
     # a rank whose local coarsening made no progress must not leave the others waiting in the next collective: agree first
     if any(comm.allgather([stuck for _ in states])[0]):
         raise NgsAMGError("distributed coarsening got stuck on a rank (raise dist_min_rows or lower max_dist_levels)")
-    # P rows of the ghost vertices: owners send (row lengths, coarse ids at the owner, weights) for their send lists
+    # P rows of the ghost vertices: owners send (row lengths, coarse ids at the owner, blocks) for their send lists
     cnt_s, col_s, val_s = [], [], []
-    for s, P in zip(states, P_owns):
+    for s, (ip, ix, dat, bf, bc) in zip(states, P_blk):
         dc, dcol, dval = {}, {}, {}
         for q, idx in s.send.items():
-            rows = P[idx]
-            dc[q] = np.diff(rows.indptr).astype(np.int64)
-            dcol[q] = rows.indices.astype(np.int64)
-            dval[q] = rows.data.astype(np.float64)
+            lens, sel = _take_rows(ip, idx)
+            dc[q] = lens
+            dcol[q] = ix[sel].astype(np.int64)
+            dval[q] = np.ascontiguousarray(dat[sel], dtype=np.float64).reshape(-1)
         cnt_s.append(dc)
         col_s.append(dcol)
         val_s.append(dval)
     cnt_r = comm.exchange(_symmetrise(comm, states, cnt_s, np.int64))
     col_r = comm.exchange(_symmetrise(comm, states, col_s, np.int64))
     val_r = comm.exchange(_symmetrise(comm, states, val_s, np.float64))
-    for s, c, P, cr, lr, vr in zip(states, nxt, P_owns, cnt_r, col_r, val_r):
+    for s, c, (ip, ix, dat, bf, bc), cr, lr, vr in zip(states, nxt, P_blk, cnt_r, col_r, val_r):
         peers = sorted(s.recv_seg, key=lambda q: s.recv_seg[q][0])      # ghost order = peer order
         # coarse ghosts: unique (owner, coarse id at owner), sorted by (owner, id)
         own, rid = [], []
@@ -489,6 +550,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         c.ghost_rindex = np.concatenate(rid) if rid else np.empty(0, dtype=np.int64)
         seg = _peer_segments(c.ghost_owner)
         ng = s.ghost_owner.size
+        ncx = c.n + c.ghost_owner.size
         lens = np.zeros(ng, dtype=np.int64)
         cols, vals = [], []
         for q in peers:
@@ -501,31 +563,48 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
             vals.append(vr[q])
         rows_ptr = np.concatenate([[0], np.cumsum(lens)])
         gcols = np.concatenate(cols) if cols else np.empty(0, dtype=np.int64)
-        gvals = np.concatenate(vals) if vals else np.empty(0)
-        P_gh = sp.csr_matrix((gvals, gcols, rows_ptr), shape=(ng, c.n + c.ghost_owner.size))
-        P_own_ext = sp.csr_matrix((P.data, P.indices, P.indptr), shape=(s.n, c.n + c.ghost_owner.size))
+        gvals = (np.concatenate(vals) if vals else np.empty(0)).reshape(-1, bf, bc)
+        P_gh = sp.bsr_matrix((gvals, gcols, rows_ptr), shape=(ng * bf, ncx * bc)).tocsr()
+        P_own_ext = sp.bsr_matrix((dat, ix, ip), shape=(s.n * bf, ncx * bc)).tocsr()
         P_ext = sp.vstack([P_own_ext, P_gh], format="csr")
+        P = sp.csr_matrix(sp.bsr_matrix((dat, ix, ip), shape=(s.n * bf, c.n * bc)))
         AP = _spmm(s.A, P_ext)
         c.A = _spmm(sp.csr_matrix(P.T), AP)
         c.A.sort_indices()
         s.AP, s.P_own_ext = AP, P_own_ext          # for the folded prolongation Q = P - w Dinv (A P), see _fold
-        s.P = sp.csr_matrix(P)
+        s.P = P
         s.P.sort_indices()
         s.PT = sp.csr_matrix(P.T)
         s.PT.sort_indices()
+        s.bs_c = bc
     _send_lists(comm, nxt)
     return nxt
 
 
-def _dinv_ext(comm, states):
+def _block_dinv(A_oo, bs, free, pinv):
+    """inverted block diagonal through the host library (gssmoother.cpp:143-170 incl. the pseudo-inverse rule)"""
+    lib = _lib.host()
+    M = _mat(A_oo, bs)
+    d = M.desc()
+    out = np.zeros(M.n_rows * bs * bs)
+    fr = np.ascontiguousarray(free, dtype=np.uint8)
+    _lib.hcheck(lib.amgh_calc_dinv(C.byref(d), _lib.ptr(fr, C.c_uint8), int(bool(pinv)), _lib.ptr(out, C.c_double)))
+    return out.reshape(M.n_rows, bs * bs)
+
+
+def _dinv_ext(comm, states, pinv=False):
     dins = []
     for s in states:
-        d = s.A[:, :s.n].diagonal()
-        di = np.where(s.free.astype(bool), 1.0 / np.where(d != 0, d, 1.0), 0.0)
+        bs = _bs(s)
+        if bs == 1:
+            d = s.A[:, :s.n].diagonal()
+            di = np.where(s.free.astype(bool), 1.0 / np.where(d != 0, d, 1.0), 0.0)
+        else:
+            di = _block_dinv(sp.csr_matrix(s.A[:, :s.n * bs]), bs, s.free, pinv)
         dins.append(di)
     gh = _exchange_ghost_values(comm, states, dins)
     for s, di, g in zip(states, dins, gh):
-        s.dinv_ext = np.concatenate([di, g])
+        s.dinv_ext = np.concatenate([di, g]).reshape(-1)
 
 
 def _fold(states, omega):
@@ -587,7 +666,9 @@ class _TopHierarchy:
             use_gs = gs and not last
             color = s.color if use_gs else np.full(s.n, -1, dtype=np.int32)
             dinv = s.dinv_gs_ext if use_gs else s.dinv_ext
-            self.levels.append(Level(A=_mat(s.A), P=None if last else _mat(s.P), PT=None if last else _mat(s.PT),
+            bf = _bs(s)
+            bc = int(getattr(s, "bs_c", bf))
+            self.levels.append(Level(A=_mat(s.A, bf), P=None if last else _mat(s.P, bf, bc), PT=None if last else _mat(s.PT, bc, bf),
                                      free=s.free, dinv=np.ascontiguousarray(dinv), coords=None, color=color,
                                      n_colors=s.n_colors if use_gs else 0, agg=None,
                                      Q=_mat(s.Q) if (fold and not last and not use_gs) else None,
@@ -610,9 +691,16 @@ class DistributedAMG:
         if sm_type not in ("jacobi", "gs", "bgs"):
             raise NgsAMGError("DistributedAMG: sm_type must be jacobi, gs or bgs")
         self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
+        # energy = 1: linear elasticity (states from assemble_elasticity_owned: block levels, rigid-body prolongation blocks,
+        # coarse block size dim + nrot); block levels run block-Jacobi in the literal stage order
+        self.energy = int(opts.get("energy", 0))
+        blocks = any(_bs(s) > 1 for s in states0) or self.energy == 1
+        if blocks and sm_type != "jacobi":
+            raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi only")
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
-        self.fold = bool(fold) and sm_type == "jacobi"
+        self.fold = bool(fold) and sm_type == "jacobi" and not blocks
+        pinv = bool(opts.get("regularize_cmats", self.energy == 1 and all(_bs(s) == dim for s in states0)))
         for s in states0:
             interior_first(s)
         _send_lists(comm, states0, translate=True)
@@ -626,7 +714,7 @@ class DistributedAMG:
         if len(levels) == 1:       # always at least one distributed level
             levels.append(coarsen_distributed_level(comm, levels[0], dim, True, opts))
         for lv in levels:
-            _dinv_ext(comm, lv)
+            _dinv_ext(comm, lv, pinv)
         if sm_type in ("gs", "bgs"):
             for lv in levels[:-1]:
                 _hybrid_gs_data(comm, lv)
@@ -648,20 +736,23 @@ class DistributedAMG:
         offs = np.concatenate([[0], np.cumsum(self.counts)])
         self.offs = offs
         pieces = []
+        bk = _bs(last[0])
         for s in last:
-            gcol_map = np.concatenate([offs[s.rank] + np.arange(s.n), offs[s.ghost_owner] + s.ghost_rindex]).astype(np.int64)
+            gmapv = np.concatenate([offs[s.rank] + np.arange(s.n), offs[s.ghost_owner] + s.ghost_rindex]).astype(np.int64)
             A = sp.csr_matrix(s.A)
-            pieces.append((s.rank, A.indptr.copy(), gcol_map[A.indices], A.data.copy()))
+            cv, cc = np.divmod(A.indices, bk)
+            pieces.append((s.rank, A.indptr.copy(), gmapv[cv] * bk + cc, A.data.copy(), None if s.coords is None else np.asarray(s.coords)))
         allp = comm.allgather(pieces)[0]
         allp = sorted(allp, key=lambda t: t[0])
         ntot = int(offs[-1])
         indptr = np.concatenate([[0]] + [np.diff(p[1]) for p in allp]).cumsum()
-        Ag = sp.csr_matrix((np.concatenate([p[3] for p in allp]), np.concatenate([p[2] for p in allp]), indptr), shape=(ntot, ntot))
+        Ag = sp.csr_matrix((np.concatenate([p[3] for p in allp]), np.concatenate([p[2] for p in allp]), indptr), shape=(ntot * bk, ntot * bk))
         Ag.sort_indices()
         self.A_tail = Ag
-        topts = {k: v for k, v in opts.items() if k != "first_aaf"}
+        topts = {k: v for k, v in opts.items() if k not in ("first_aaf",) + _SETUP_ONLY_KEYS}
         topts["first_aaf"] = opts.get("aaf", 2.0 ** -dim)
-        self.tail_hier = Hierarchy(_mat(Ag), None, None, dim=dim, energy=0, **topts)
+        coords_g = np.concatenate([p[4] for p in allp]) if (self.energy == 1 and all(p[4] is not None for p in allp)) else None
+        self.tail_hier = Hierarchy(_mat(Ag, bk), None, coords_g, dim=dim, energy=self.energy, **topts)
         if sm_type == "bgs":
             self.tail_hier.build_bgs(pinv=False)
         # ---- per-rank execution objects --------------------------------------------------------------------
@@ -681,7 +772,8 @@ class DistributedAMG:
     def level_k_map(self, i):
         """level k of local rank i in its [owned | ghost] layout -> index in the gathered (replicated) vector"""
         sk = self.dist_levels[self.k][i]
-        return np.concatenate([self.offs[sk.rank] + np.arange(sk.n), self.offs[sk.ghost_owner] + sk.ghost_rindex]).astype(np.int64)
+        mv = np.concatenate([self.offs[sk.rank] + np.arange(sk.n), self.offs[sk.ghost_owner] + sk.ghost_rindex]).astype(np.int64)
+        return _vexp(mv, _bs(sk))
 
     # ---------------------------------------------------------------------------------------------------------
     def _alloc(self):
@@ -690,28 +782,31 @@ class DistributedAMG:
             b = {"bext": [], "text": [], "x": [], "r": [], "send": [], "sidx": []}
             for l in range(self.k):
                 s = self.dist_levels[l][i]
-                next_ = s.n + s.ghost_owner.size
+                bsl = _bs(s)
+                next_ = (s.n + s.ghost_owner.size) * bsl
                 b["bext"].append(ops.zeros(next_))
                 b["text"].append(ops.zeros(next_))
-                b["x"].append(ops.zeros(s.n))
-                b["r"].append(ops.zeros(s.n))
+                b["x"].append(ops.zeros(s.n * bsl))
+                b["r"].append(ops.zeros(s.n * bsl))
                 b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type in ("gs", "bgs") or self.fold) else None)
                 b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type in ("gs", "bgs") else None)
                 # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
                 peers = sorted(s.send)
-                allidx = np.concatenate([s.send[q] for q in peers]) if peers else np.empty(0, dtype=np.int64)
+                allidx = _vexp(np.concatenate([s.send[q] for q in peers]), bsl) if peers else np.empty(0, dtype=np.int64)
                 sbuf = ops.zeros(allidx.size)
                 off, views = 0, {}
                 for q in peers:
-                    views[q] = sbuf[off:off + s.send[q].size]
-                    off += s.send[q].size
+                    views[q] = sbuf[off:off + s.send[q].size * bsl]
+                    off += s.send[q].size * bsl
                 b["send"].append(views)
                 b["sidx"].append((ops.index(allidx), sbuf))
             sk = self.dist_levels[self.k][i]
-            b["bk"] = ops.zeros(max(self.counts))
-            b["bglob"] = ops.zeros(int(self.offs[-1]))
-            b["xglob"] = ops.zeros(int(self.offs[-1]))
-            b["nk"] = sk.n
+            bk = _bs(sk)
+            b["bk"] = ops.zeros(max(self.counts) * bk)
+            b["bglob"] = ops.zeros(int(self.offs[-1]) * bk)
+            b["xglob"] = ops.zeros(int(self.offs[-1]) * bk)
+            b["nk"] = sk.n * bk
+            b["bsk"] = bk
             if self.fold:
                 # level k in the [owned | ghost] layout of this rank, picked from the replicated tail solution
                 gmap = self.level_k_map(i)
@@ -728,7 +823,7 @@ class DistributedAMG:
             if sbuf.numel():
                 ops.gather(vec, idx, sbuf)
             sends.append(b["send"][l])
-            recvs.append({q: vec[s.n + a:s.n + e] for q, (a, e) in s.recv_seg.items()})
+            recvs.append({q: vec[(s.n + a) * _bs(s):(s.n + e) * _bs(s)] for q, (a, e) in s.recv_seg.items()})
         self.comm.halo(sends, recvs)
 
     def rhs_buffer(self, i=0):
@@ -749,20 +844,22 @@ class DistributedAMG:
         if self.fold:
             return self._mult_folded(bs, xs)
         k = self.k
+        nown = lambda l, i: self.dist_levels[l][i].n * _bs(self.dist_levels[l][i])        # owned scalar entries
         for l in range(k):
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
                 if l == 0 and bs[i].data_ptr() != b["bext"][0].data_ptr():
-                    b["bext"][0][:s.n].copy_(bs[i])
+                    b["bext"][0][:nown(0, i)].copy_(bs[i])
             self._halo(l, "bext")
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
                 xl = xs[i] if l == 0 else b["x"][l]
                 ops.jacobi_pre(l, b["bext"][l], xl, b["r"][l])
-                nxt = b["bext"][l + 1][:self.dist_levels[l + 1][i].n] if l + 1 < k else b["bk"][:b["nk"]]
+                nxt = b["bext"][l + 1][:nown(l + 1, i)] if l + 1 < k else b["bk"][:b["nk"]]
                 ops.restrict(l, b["r"][l], nxt)
         # replicated tail: all-gather the level-k right-hand side, every rank runs the same serial cycle
-        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], self.counts)
+        bk = self.buf[0]["bsk"]
+        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], [c * bk for c in self.counts])
         for i, ops in enumerate(self.ops):
             b = self.buf[i]
             ops.tail_apply(b["bglob"], b["xglob"])
@@ -770,14 +867,14 @@ class DistributedAMG:
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
                 r = self.dist_levels[l][i].rank
-                xc = b["x"][l + 1] if l + 1 < k else b["xglob"][int(self.offs[r]):int(self.offs[r]) + b["nk"]]
+                xc = b["x"][l + 1] if l + 1 < k else b["xglob"][int(self.offs[r]) * bk:int(self.offs[r]) * bk + b["nk"]]
                 xl = xs[i] if l == 0 else b["x"][l]
-                ops.prolong(l, xl, xc, b["text"][l][:s.n])
+                ops.prolong(l, xl, xc, b["text"][l][:nown(l, i)])
             self._halo(l, "text")
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
                 xl = xs[i] if l == 0 else b["x"][l]
-                ops.jacobi_post(l, b["text"][l], b["bext"][l][:s.n], xl)
+                ops.jacobi_post(l, b["text"][l], b["bext"][l][:nown(l, i)], xl)
         return xs
 
     def _mult_folded(self, bs, xs):
@@ -861,29 +958,32 @@ class DistributedAMG:
             cntc = comm.allgather([s.n for s in nxt])[0]
             offc = np.concatenate([[0], np.cumsum(cntc)])
             pa, pp, pf, pd = [], [], [], []
+            bf = _bs(lv[0])
+            bc = int(getattr(lv[0], "bs_c", bf))
             for s in lv:
-                gmap = np.concatenate([off[s.rank] + np.arange(s.n), off[s.ghost_owner] + s.ghost_rindex]).astype(np.int64)
+                gmapv = np.concatenate([off[s.rank] + np.arange(s.n), off[s.ghost_owner] + s.ghost_rindex]).astype(np.int64)
                 A = sp.csr_matrix(s.A)
-                pa.append((s.rank, np.diff(A.indptr), gmap[A.indices], A.data))
+                cv, cc = np.divmod(A.indices, bf)
+                pa.append((s.rank, np.diff(A.indptr), gmapv[cv] * bf + cc, A.data))
                 P = sp.csr_matrix(s.P)
-                pp.append((s.rank, np.diff(P.indptr), offc[s.rank] + P.indices, P.data))
+                pp.append((s.rank, np.diff(P.indptr), offc[s.rank] * bc + P.indices, P.data))
                 pf.append((s.rank, s.free))
-                pd.append((s.rank, s.dinv_ext[:s.n]))
+                pd.append((s.rank, s.dinv_ext[:s.n * bf * bf]))
             ga = sorted(comm.allgather(pa)[0], key=lambda t: t[0])
             gp = sorted(comm.allgather(pp)[0], key=lambda t: t[0])
             gf = sorted(comm.allgather(pf)[0], key=lambda t: t[0])
             gd = sorted(comm.allgather(pd)[0], key=lambda t: t[0])
             n, nc = int(off[-1]), int(offc[-1])
             A = sp.csr_matrix((np.concatenate([t[3] for t in ga]), np.concatenate([t[2] for t in ga]),
-                               np.concatenate([[0]] + [t[1] for t in ga]).cumsum()), shape=(n, n))
+                               np.concatenate([[0]] + [t[1] for t in ga]).cumsum()), shape=(n * bf, n * bf))
             P = sp.csr_matrix((np.concatenate([t[3] for t in gp]), np.concatenate([t[2] for t in gp]),
-                               np.concatenate([[0]] + [t[1] for t in gp]).cumsum()), shape=(n, nc))
+                               np.concatenate([[0]] + [t[1] for t in gp]).cumsum()), shape=(n * bf, nc * bc))
             A.sort_indices()
             P.sort_indices()
             PT = sp.csr_matrix(P.T)
             PT.sort_indices()
             free = np.concatenate([t[1] for t in gf]).astype(np.uint8)
-            L = Level(A=_mat(A), P=_mat(P), PT=_mat(PT), free=free, dinv=np.concatenate([t[1] for t in gd]),
+            L = Level(A=_mat(A, bf), P=_mat(P, bf, bc), PT=_mat(PT, bc, bf), free=free, dinv=np.concatenate([t[1] for t in gd]),
                       coords=None, color=np.full(n, -1, dtype=np.int32), n_colors=0, agg=None)
             if self.sm_type == "gs":
                 # hybrid GS as ONE serial smoother: every rank is a block, its rows are visited in its colour-major order
@@ -1080,8 +1180,8 @@ class _DeviceDist:
             raise NgsAMGError("Mult: one b and one x per local rank")
         for i, (b, x) in enumerate(zip(bs, xs)):
             s = self.amg.dist_levels[0][i]
-            nb = s.n if b_status else s.n + s.ghost_owner.size
-            for v, m, nm in ((b, nb, "b"), (x, s.n, "x")):
+            nb = (s.n if b_status else s.n + s.ghost_owner.size) * _bs(s)
+            for v, m, nm in ((b, nb, "b"), (x, s.n * _bs(s), "x")):
                 if not (v.is_cuda and v.dtype == torch.float64 and v.is_contiguous() and v.numel() == m):
                     raise NgsAMGError(f"{nm}[{i}]: need a contiguous float64 CUDA tensor with {m} entries")
         pb = (C.c_void_p * n)(*[b.data_ptr() for b in bs])

@@ -6,6 +6,14 @@ import torch
 from oracle.pyoracle import Oracle
 
 
+def _dapply(dinv, v, bs):
+    """block-diagonal inverse times vector (AoS blocks of bs entries; dinv: [nblocks * bs * bs] row-major)"""
+    if bs == 1:
+        return dinv[:v.size] * v
+    nb = v.size // bs
+    return np.einsum("nij,nj->ni", dinv[:nb * bs * bs].reshape(nb, bs, bs), v.reshape(nb, bs)).reshape(-1)
+
+
 def cpu_backend(omega=0.9, sm_type="jacobi"):
     tails = {}
 
@@ -35,9 +43,9 @@ def cpu_backend(omega=0.9, sm_type="jacobi"):
 
         def jacobi_pre(self, l, bext, x, r):
             L = self.top.levels[l]
-            n = L.A.n_rows
+            n = L.A.n_rows * L.A.br
             be = bext.numpy()
-            xe = omega * L.dinv * be                       # ghost entries of x from ghost dinv * ghost b
+            xe = omega * _dapply(L.dinv, be, L.A.br)       # ghost entries of x from ghost dinv * ghost b
             x.numpy()[:] = xe[:n]
             r.numpy()[:] = be[:n] - self.A[l] @ xe
 
@@ -61,9 +69,9 @@ def cpu_backend(omega=0.9, sm_type="jacobi"):
 
         def jacobi_post(self, l, text, b, x):
             L = self.top.levels[l]
-            n = L.A.n_rows
+            n, bs = L.A.n_rows * L.A.br, L.A.br
             te = text.numpy()
-            x.numpy()[:] = te[:n] + omega * L.dinv[:n] * (b.numpy() - self.A[l] @ te)
+            x.numpy()[:] = te[:n] + omega * _dapply(L.dinv, b.numpy() - self.A[l] @ te, bs)
 
         def tail_apply(self, b, x):
             x.numpy()[:] = self.tail.apply(b.numpy().copy())
