@@ -60,10 +60,20 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     # nv^2 face each, instead of up to 7 neighbours (3 faces + 3 edges + 1 corner) in a 2 x 2 x 2 arrangement: fewer and
     # smaller point-to-point messages per halo exchange, fewer ghost columns.  NGSAMG_PGRID=box: cfg 4's arrangement
     pg = D.proc_grid(world, 3) if os.environ.get("NGSAMG_PGRID") == "box" else (world, 1, 1)
-    st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
-    t1 = time.time()
-    amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10,
-                           sm_type="jacobi" if args.smoother == "jacobi" else "gs")
+    elast = args.config in ("cfg3", "cfg5")
+    if elast:
+        rot = args.config == "cfg5"
+        st = D.assemble_elasticity_owned(rank, pg, (nv, nv, nv), rotations=rot, mu=1.0, lam=0.5, dirichlet="left", jitter=0.2, seed=1)
+        t1 = time.time()
+        amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=20000, device=device, max_coarse_size=50, max_levels=10,
+                               energy=1, regularize_cmats=0 if rot else 1)
+    else:
+        st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
+        t1 = time.time()
+        amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10,
+                               sm_type="jacobi" if args.smoother == "jacobi" else "gs")
+    bs0 = int(getattr(st, "bs", 1))
+    free_s = np.repeat(st.free, bs0).astype(np.float64)
     t2 = time.time()
     lib = _lib.hip()
     kind, nr, rk = C.c_int32(), C.c_int32(), C.c_int32()
@@ -81,7 +91,8 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
         L = amg.tops[0].levels[l]
         n = L.A.n_rows
         nc = amg.tops[0].levels[l + 1].A.n_rows
-        per_rank += 2 * matrix_bytes(L.A) + matrix_bytes(L.P) + matrix_bytes(L.PT) + 16 * n + 15 * 8 * n + 2 * 8 * nc
+        bl, bcl = L.A.br, amg.tops[0].levels[l + 1].A.br
+        per_rank += 2 * matrix_bytes(L.A) + matrix_bytes(L.P) + matrix_bytes(L.PT) + 16 * bl * bl * n + 15 * 8 * bl * n + 2 * 8 * bcl * nc
     per_rank += vcycle_bytes(amg.tail_hier)[0]
     rng = np.random.default_rng(rank)
     stream = torch.cuda.Stream(device=device)
@@ -90,9 +101,9 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
             b = amg.rhs_buffer(0)         # resident in the [owned | ghost] layout: no per-apply copy of b
         except Exception as e:            # (torch without __cuda_array_interface__ support: one device copy per apply)
             log(f"rhs_buffer unavailable ({e!r}); b is copied into the halo layout every apply")
-            b = torch.empty(st.n, dtype=torch.float64, device=f"cuda:{device}")
-        b.copy_(torch.from_numpy(rng.standard_normal(st.n) * st.free))
-        x = torch.empty(st.n, dtype=torch.float64, device=f"cuda:{device}")
+            b = torch.empty(st.n * bs0, dtype=torch.float64, device=f"cuda:{device}")
+        b.copy_(torch.from_numpy(rng.standard_normal(st.n * bs0) * free_s))
+        x = torch.empty(st.n * bs0, dtype=torch.float64, device=f"cuda:{device}")
         for _ in range(args.warmup):
             amg.Mult([b], [x])
         stream.synchronize()
@@ -114,7 +125,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     dist.all_reduce(xn)
     ms_per_step = 1e3 * elapsed / args.steps
     k_probe = None
-    if args.smoother == "jacobi":
+    if args.smoother == "jacobi" and not elast:
         try:          # every rank times its own level-0 kernel (no collectives inside), so that all ranks leave together
             with torch.cuda.stream(stream):
                 k_probe = amg.ops[0].top.time_op(0, 7, reps=50)
@@ -125,8 +136,8 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     # `world` such units (value / world = applications of the GLOBAL operator per second, reported beside it)
     applies_per_s = world * args.steps / elapsed
     lv0 = amg.tops[0].levels[0]
-    spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.A.n_rows
-    k_name = "sell_spmv_kernel<EP_RES> (level 0 owned rows, rank 0)"
+    spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.A.n_rows * lv0.A.br
+    k_name = "sell_spmv_kernel<EP_RES> (level 0 owned rows, rank 0)" if not elast else f"block residual kernel {lv0.A.br}x{lv0.A.br} (level 0 owned rows x [owned | ghost], rank 0)"
     k_ms = k_probe
     if k_ms is not None:   # the dominant kernel of the folded cycle (same accounting as the single-GPU line), back to back
         spmv_bytes = matrix_bytes(lv0.A) + matrix_bytes(lv0.PT) + 7 * 8 * lv0.A.n_rows + 8 * amg.tops[0].levels[1].A.n_rows
@@ -136,21 +147,24 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
     if rank == 0:
         out = {
-            "metric": "V-cycle applies/sec (3D H1 Poisson ~10M DOF per GPU, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel"),
+            "metric": ("V-cycle applies/sec (3D H1 Poisson ~10M DOF per GPU, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel")) if not elast
+                      else f"V-cycle applies/sec (3D elasticity {nv}^3 nodes per GPU, block size {bs0}, block-Jacobi V(1,1))",
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "rccl_ranks": int(nr.value),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "global_applies_per_s": round(args.steps / elapsed, 2),
-            "config": {"workload": (f"cfg4: " if args.config == "cfg4" else "cfg4-style weak scaling of cfg2: ") +
+            "config": {"workload": (f"cfg4: " if args.config == "cfg4" else f"{args.config} per rank, weak scaling: " if elast else "cfg4-style weak scaling of cfg2: ") +
                                    f"global grid {tuple(pg[d] * nv for d in range(3))} = "
-                                   f"{world} x {nv}^3 vertices, hashed jitter (seed 1), Dirichlet right|top, {args.smoother} omega=0.9, V(1,1)",
+                                   f"{world} x {nv}^3 vertices, hashed jitter (seed 1), " +
+                                   (f"linear elasticity mu=1 lam=0.5, block size {bs0}, clamped left, block-jacobi" if elast else f"Dirichlet right|top, {args.smoother}") +
+                                   " omega=0.9, V(1,1)",
                        "parallelism": f"{world} ranks (one process per GPU), partition {pg}, {amg.k} rank-partitioned levels "
                                       f"[interior | boundary] with halo pack kernels + ncclSend/ncclRecv on a communication stream behind the C ABI "
                                       f"({ex_per_cycle:.0f} exchanges per cycle, interior rows overlap them), level {amg.k} gathered by ncclAllGather, "
                                       f"coarse hierarchy replicated from n = {amg.tail_hier.levels[0].n}; "
                                       f"value = ranks x steps / time (one unit = one V-cycle over one rank's 10M-DOF share); "
                                       f"global_applies_per_s = steps / time",
-                       "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(world * st.n)},
+                       "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(world * st.n * bs0)},
             "x_norm": float(xn.item()) ** 0.5,
             "roofline": {"bound": "hbm", "kernel": k_name,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -282,8 +296,8 @@ def main():
         os.environ["NGSAMG_PGRID"] = "box"
         if world == 1 and not force_dist:
             raise SystemExit("--config cfg4 is the rank-partitioned configuration: use --gpus 8 (or 2 / 4)")
-    if (world > 1 or force_dist) and args.config not in ("cfg2", "cfg4"):
-        raise SystemExit("--config cfg3 / cfg5 run on one GPU (the rank-partitioned elasticity path is not built yet)")
+    if (world > 1 or force_dist) and args.config in ("cfg3", "cfg5") and args.smoother != "jacobi":
+        raise SystemExit("--config cfg3 / cfg5 on several ranks: block-Jacobi only (--smoother jacobi)")
     if world > 1 or force_dist:
         run_distributed(args, torch, dist, world, rank, device, nv)
         return

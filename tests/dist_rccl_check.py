@@ -27,6 +27,7 @@ def parse():
     ap.add_argument("--sm", default="jacobi")
     ap.add_argument("--pgrid", default="box", choices=["box", "slab"])
     ap.add_argument("--no-fold", action="store_true")
+    ap.add_argument("--elast", default="", choices=["", "3", "6"], help="linear elasticity with 3x3 (displacements) or 6x6 (with rotations) fine blocks")
     ap.add_argument("--dmin", type=int, default=500)
     ap.add_argument("--port", type=int, default=0)
     return ap.parse_args()
@@ -106,16 +107,22 @@ def main():
     try:
         comm = D.TorchComm()
         pg = (world, 1, 1) if args.pgrid == "slab" else D.proc_grid(world, 3)
-        st = D.assemble_poisson_owned(rank, pg, (args.box,) * 3)
-        amg = D.DistributedAMG(comm, [st], dim=3, dist_min_rows=args.dmin, device=dev, max_coarse_size=20, sm_type=args.sm,
-                               fold=not args.no_fold, gs_stage_min_rows=1000)
+        if args.elast:
+            st = D.assemble_elasticity_owned(rank, pg, (args.box,) * 3, rotations=args.elast == "6")
+            amg = D.DistributedAMG(comm, [st], dim=3, dist_min_rows=args.dmin, device=dev, max_coarse_size=10, energy=1,
+                                   regularize_cmats=0 if args.elast == "6" else 1)
+        else:
+            st = D.assemble_poisson_owned(rank, pg, (args.box,) * 3)
+            amg = D.DistributedAMG(comm, [st], dim=3, dist_min_rows=args.dmin, device=dev, max_coarse_size=20, sm_type=args.sm,
+                                   fold=not args.no_fold, gs_stage_min_rows=1000)
+        bs0 = getattr(st, "bs", 1)
         assert amg._dev is not None
         lib = _lib.hip()
         kind, nr, rk = C.c_int32(), C.c_int32(), C.c_int32()
         lib.amgx_comm_info(amg._dev._comm, C.byref(kind), C.byref(nr), C.byref(rk), None)
         assert (kind.value, nr.value, rk.value) == (_lib.AMGX_COMM_RCCL, world, rank), "RCCL communicator does not span all ranks"
         rng = np.random.default_rng(rank)
-        bh = rng.standard_normal(st.n) * st.free
+        bh = rng.standard_normal(st.n * bs0) * np.repeat(st.free, bs0)
         b = torch.from_numpy(bh).to(f"cuda:{dev}")
         x = torch.full_like(b, float("nan"))
         s = torch.cuda.Stream()
@@ -132,8 +139,8 @@ def main():
             ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate(allb))
             got = np.concatenate(allx)
             err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
-            tol = 1e-12 if args.sm == "jacobi" else 1e-10
-            print(f"world={world} pgrid={pg} box={args.box}^3 sm={args.sm} fold={amg.fold} distributed levels={amg.k} "
+            tol = (1e-12 if args.sm == "jacobi" else 1e-10) if not args.elast else 1e-11
+            print(f"world={world} pgrid={pg} box={args.box}^3 sm={args.sm} elast={args.elast or 'no'} fold={amg.fold} distributed levels={amg.k} "
                   f"exchanges per cycle={amg._dev.n_exchanges() // 3} rel.err vs serial oracle = {err:.3e} self-loop halo ok = {loop_ok}")
             ok = err < tol and loop_ok
             print("RCCL CHECK", "PASSED" if ok else "FAILED")

@@ -120,6 +120,11 @@ def _run_check(*argv, timeout=600):
     return r.stdout
 
 
+def test_rccl_world_size_one_elasticity():
+    """the block path (6x6 coarse blocks) through a real RCCL communicator at world size 1"""
+    _run_check("--world", "1", "--box", "10", "--elast", "3", "--dmin", "50")
+
+
 @pytest.mark.parametrize("sm", ["jacobi", "gs"])
 def test_rccl_world_size_one(sm):
     """The native driver over a real RCCL communicator on ONE GPU (child process): ncclCommInitRank, the all-gather of

@@ -36,3 +36,12 @@ def test_rccl_slab_partition_as_in_bench(world):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs")
     _run("--world", str(world), "--box", "24", "--pgrid", "slab")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("elast", ["3", "6"])
+def test_rccl_elasticity_ranks_match_serial_oracle(world, elast):
+    """cfg 5's shape on several GPUs: rank-partitioned elasticity (block size 3 or 6), halo messages of block vectors"""
+    if _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run("--world", str(world), "--box", "12", "--elast", elast, "--dmin", "50")
