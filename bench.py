@@ -71,7 +71,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
         st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
         t1 = time.time()
         amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10,
-                               sm_type="jacobi" if args.smoother == "jacobi" else "gs")
+                               sm_type={"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother])
     bs0 = int(getattr(st, "bs", 1))
     free_s = np.repeat(st.free, bs0).astype(np.float64)
     t2 = time.time()

@@ -84,6 +84,10 @@ int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* co
  * couplings leaving the block of |a_kj| / sqrt(d_k d_j)  (CalcModDiag, hybrid_smoother_utils.hpp:35-142); scalar matrices */
 int amgh_coloring_blocked(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int32_t* color_out, int32_t* n_colors);
 int amgh_hybrid_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, double* dinv_out);
+/* the same for a rank-partitioned level (A: owned rows x [owned | ghost] columns): ghost_diag = the diagonal entries of the
+ * n_cols - n_rows ghost rows as their owners hold them (the reference sums the shares of all ranks, hybrid_smoother_utils.hpp:35-110) */
+int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, const double* ghost_diag_or_null,
+                         double* dinv_out);
 
 /* Block Gauss-Seidel data (reference BSmoother, src/base/smoothers/block_gssmoother.cpp:17-150).  Blocks are sets of
  * block rows -- the aggregates of the level, as GetGSBlocks builds them (amg_pc_vertex_impl.hpp:1171-1269); block k owns

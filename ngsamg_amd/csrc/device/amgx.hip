@@ -898,15 +898,19 @@ struct Handle {
   }
 
   // one block-hybrid Gauss-Seidel sweep (gsb_sweep_kernel): ONE launch; xin == nullptr: sweep from x = 0
-  void gsb_sweep(const DevLevel& L, int dir, const DevMatrix::Sell& copy, const double* xin, double* xout, const double* b) {
+  // blk0, blk1: only the blocks [blk0, blk1) (blk1 < 0: all): blocks are independent of each other within a sweep, so the
+  // rank-partitioned driver sweeps its boundary and interior blocks in separate launches around the halo exchange
+  void gsb_sweep(const DevLevel& L, int dir, const DevMatrix::Sell& copy, const double* xin, double* xout, const double* b,
+                 int blk0 = 0, int blk1 = -1) {
     Range rg("GSS3<bs=1>::SmoothRHS");
     const DevGSB& g = L.gsb;
-    if (g.n_blocks == 0) return;
+    if (blk1 < 0 || blk1 > g.n_blocks) blk1 = g.n_blocks;
+    if (blk1 <= blk0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
     GsbArgs a{g.rowid.p, g.slotcolor.p, L.dinv.p, b, g.n_colors, dir};
     const SellMat M = copy.view();
     const bool fz = xin == nullptr;
-#define LAUNCH_GSB3(TT, GG, ZZ) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ>), dim3(g.n_blocks), dim3(TT), 0, stream, L.n, 0, M, a, xin, xout)
+#define LAUNCH_GSB3(TT, GG, ZZ) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
 #define LAUNCH_GSB2(TT, GG) { if (fz) LAUNCH_GSB3(TT, GG, true); else LAUNCH_GSB3(TT, GG, false); }
 #define LAUNCH_GSB(TT) switch (g.G) { case 1: LAUNCH_GSB2(TT, 1); break; case 2: LAUNCH_GSB2(TT, 2); break; case 4: LAUNCH_GSB2(TT, 4); break; \
                                       case 8: LAUNCH_GSB2(TT, 8); break; default: LAUNCH_GSB2(TT, 16); break; }
@@ -1119,6 +1123,23 @@ struct Handle {
     if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.gsb.has_split && !L.RG.empty() && sp.part == PART_ALL) {
       // sweep from zero, then residual of the untouched part + chunk-local restriction in one pass (r stays in LDS)
       gsb_sweep(L, 0, L.gsb.lowin, nullptr, x, b);
+      gsb_residual_restrict(l, x, r, b_coarse);
+      return;
+    }
+    pre_smooth(L, x, b, r, fold, sp);
+    if (sp.part != PART_INT) transfer_f2c(l, r, b_coarse);
+  }
+
+  // after a block-hybrid sweep from zero: r = c .* x - A_rest x (x may carry ghost entries) and b_coarse = P^T r
+  void gsb_residual_restrict(int l, const double* x, double* r, double* b_coarse) {
+    DevLevel& L = lev[l];
+    if (!L.gsb.has_split) throw Err("gsb_residual_restrict: the level has no lower / rest split");
+    if (L.RG.empty()) {
+      spmv_ep<EP_CRES>(L.gsb.rest, x, r, EpArgs{x, nullptr, L.gsb.cvec.p, 0.0, nullptr, ep_nt & EPF_HOIST});
+      transfer_f2c(l, r, b_coarse);
+      return;
+    }
+    {
       const DevRestrict& R = L.RG;
       const DevMatrix& M = L.gsb.rest;
       const int nch = (M.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
@@ -1132,10 +1153,7 @@ struct Handle {
       hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
-      return;
     }
-    pre_smooth(L, x, b, r, fold, sp);
-    if (sp.part != PART_INT) transfer_f2c(l, r, b_coarse);
   }
 
   // coarse-grid correction + post-smoothing: x += P x_c; SmoothBack(x, b, r, 0, 0, 0)   (amg_matrix.cpp:263-302)

@@ -281,6 +281,7 @@ struct Dist {
   int sm_type = AMGX_SM_JACOBI;
   bool fold = true;
   bool overlap = true;
+  bool gsb = false;                      // Gauss-Seidel levels in the block-hybrid form
   std::vector<HaloTable> halo;           // [k]
   std::vector<std::array<int, 4>> stage; // [k] colour ranges of the hybrid Gauss-Seidel stages: [s0,s1) first local part,
                                          //     [s1,s2) boundary ("EX") rows, [s2,s3) second local part (gssmoother.cpp:721-782)
@@ -358,11 +359,17 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
     if (D->sm_type != AMGX_SM_JACOBI) throw Err("amgx_dist_create: fold needs Jacobi levels");
     for (int l = 0; l < k; ++l) if (!D->top->folded(D->top->lev[l])) throw Err("amgx_dist_create: fold requested but level " + std::to_string(l) + " has no Q");
   }
+  if (D->sm_type == AMGX_SM_GS) {
+    int on = 0;
+    for (int l = 0; l < k; ++l) on += D->top->lev[l].gsb.on() ? 1 : 0;
+    if (on != 0 && on != k) throw Err("amgx_dist_create: either all or none of the rank-partitioned Gauss-Seidel levels use gs_block_rows");
+    D->gsb = on == k;
+  }
   D->bext.resize(k); D->xext.resize(k); D->text.resize(k); D->rl.resize(k);
   auto zalloc = [&](DevBuf<double>& b, int64_t len) { b.alloc((size_t)std::max<int64_t>(1, len)); HIPCHK(hipMemset(b.p, 0, std::max<int64_t>(1, len) * sizeof(double))); };
   for (int l = 0; l < k; ++l) {
     zalloc(D->bext[l], D->next(l)); zalloc(D->xext[l], D->next(l)); zalloc(D->rl[l], D->n(l));
-    if (!D->fold && D->sm_type == AMGX_SM_JACOBI) zalloc(D->text[l], D->next(l));
+    if ((!D->fold && D->sm_type == AMGX_SM_JACOBI) || D->gsb) zalloc(D->text[l], D->next(l));
   }
   // level k: gathered in rank order
   D->counts.assign(d->counts, d->counts + c->nranks);
@@ -510,6 +517,59 @@ struct DistCycle {
     if (d->sm_type == AMGX_SM_BGS) d->top->bgs_sweep(L, dir, xv, b, c0, c1);
     else d->top->gs_sweep(L, dir, xv, b, false, c0, c1);
   }
+  // ---- Gauss-Seidel in the block-hybrid form (gsb_sweep_kernel): the blocks of a sweep are independent of each other
+  //      (couplings that leave a block -- ghost columns included -- use the sweep-start vector), so the boundary blocks are
+  //      swept first, the exchange of x starts, and the interior blocks run behind it; on the way up the interior blocks
+  //      run while x + P x_c travels.  Two launches per sweep instead of one per colour and stage.
+  void hybrid_gsb(const std::vector<const double*>& b0) {
+    const int k = M[0]->k;
+    auto bl = [&](Dist* d, size_t i, int l) { return l == 0 ? b0[i] : (const double*)d->bext[l].p; };
+    auto nbi = [&](Dist* d, int l) { return (int)(d->halo[l].n_int / d->top->lev[l].gsb.B); };
+    for (int l = 0; l < k; ++l) {
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        DevLevel& L = d->top->lev[l];
+        const DevMatrix::Sell& cp = L.gsb.has_split ? L.gsb.lowin : L.gsb.full;
+        d->top->zero(d->xext[l].p + d->n(l), d->next(l) - d->n(l));
+        d->top->gsb_sweep(L, 0, cp, nullptr, d->xext[l].p, bl(d, i, l), nbi(d, l), -1);
+      }
+      const int tk = c.exchange_begin(items(l, 1));
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        DevLevel& L = d->top->lev[l];
+        d->top->gsb_sweep(L, 0, L.gsb.has_split ? L.gsb.lowin : L.gsb.full, nullptr, d->xext[l].p, bl(d, i, l), 0, nbi(d, l));
+      }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        DevLevel& L = d->top->lev[l];
+        if (L.gsb.has_split) d->top->gsb_residual_restrict(l, d->xext[l].p, d->rl[l].p, bnext(d, l));
+        else { d->top->residual(L.A, d->xext[l].p, bl(d, i, l), d->rl[l].p); d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l)); }
+      }
+    }
+    gather_level_k();
+    tail_and_pick();
+    for (int l = k - 1; l >= 0; --l) {
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        const double* xc = l + 1 < k ? d->xext[l + 1].p : d->xk_ext.p;
+        d->top->mult_add(d->top->lev[l].P, 1.0, xc, d->xext[l].p, d->text[l].p);
+      }
+      const int tk = c.exchange_begin(items(l, 2));
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        DevLevel& L = d->top->lev[l];
+        d->top->gsb_sweep(L, 1, L.gsb.full, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), 0, nbi(d, l));
+      }
+      c.exchange_end(tk);
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        DevLevel& L = d->top->lev[l];
+        d->top->gsb_sweep(L, 1, L.gsb.full, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), nbi(d, l), -1);
+      }
+    }
+  }
+
   void hybrid_gs(const std::vector<const double*>& b0) {
     const int k = M[0]->k;
     auto bl = [&](Dist* d, size_t i, int l) { return l == 0 ? b0[i] : (const double*)d->bext[l].p; };
@@ -577,6 +637,7 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     c.accumulate(it);
   }
   if (M[0]->sm_type == AMGX_SM_JACOBI) { if (M[0]->fold) cy.jacobi_folded(); else cy.jacobi_literal(); }
+  else if (M[0]->gsb) cy.hybrid_gsb(b0);
   else cy.hybrid_gs(b0);
   if (host) {
     for (size_t i = 0; i < M.size(); ++i) HIPCHK(hipMemcpyAsync(x[i], M[i]->x0.p, M[i]->n(0) * sizeof(double), hipMemcpyDeviceToHost, c.compute));

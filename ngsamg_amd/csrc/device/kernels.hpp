@@ -664,7 +664,7 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
 #pragma unroll
   for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
     const int loc = cl[j] - (int)r0;
-    const bool inb = loc >= 0 && loc < B;
+    const bool inb = loc >= 0 && loc < B && cl[j] < n_rows;       // (ghost columns of a rank-partitioned level are never in-block)
     if (!FROM_ZERO) { if (!inb && v[j] != 0.0) acc_off += v[j] * xin[cl[j]]; }
     if (!inb) v[j] = 0.0;
     cl[j] = inb ? loc : 0;

@@ -149,12 +149,17 @@ int amgh_coloring_blocked(const amgh_matrix* A, const uint8_t* free_or_null, int
 }
 
 int amgh_hybrid_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, double* dinv_out) {
+  return amgh_hybrid_dinv_ext(A, free_or_null, block_rows, nullptr, dinv_out);
+}
+
+int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, const double* ghost_diag_or_null,
+                         double* dinv_out) {
   return guard([&] {
     check_matrix(A);
     if (A->br != 1 || A->bc != 1) throw amgh::Error("amgh_hybrid_dinv: scalar matrices only");
     if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv: bad arguments");
     amgh::BCSR M = to_bcsr(A);
-    amgh::hybrid_mod_dinv(M, free_or_null, block_rows, dinv_out);
+    amgh::hybrid_mod_dinv(M, free_or_null, block_rows, dinv_out, ghost_diag_or_null);
   });
 }
 

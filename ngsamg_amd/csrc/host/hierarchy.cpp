@@ -408,12 +408,13 @@ int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_ro
 // inverse of the l1-type modified diagonal of the hybrid smoother (reference CalcModDiag, hybrid_smoother_utils.hpp:35-142):
 //   ad_k = sum over the couplings of row k that leave its block of |a_kj| / sqrt(a_kk a_jj);  md_k = max(1, 0.51 (1 + ad_k)) a_kk
 // scalar matrices; non-free rows get 0
-void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv) {
+void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag) {
   const int64_t n = A.n_rows;
   std::vector<double> d((size_t)A.n_cols, 0.0);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++)
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { d[i] = A.val[k]; break; }
+  if (ghost_diag) for (int64_t j = n; j < A.n_cols; j++) d[j] = ghost_diag[j - n];      // rank-partitioned level: owners' diagonals
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
     dinv[i] = 0.0;
@@ -423,7 +424,7 @@ void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, dou
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
       const int64_t j = A.col[k];
       if (j >= b0 && j < b1) continue;
-      const double dj = j < n ? d[j] : 0.0;
+      const double dj = d[j];
       if (d[i] > 0.0 && dj > 0.0) ad += std::fabs(A.val[k]) / std::sqrt(d[i] * dj);
     }
     dinv[i] = 1.0 / (std::max(1.0, 0.51 * (1.0 + ad)) * d[i]);

@@ -54,6 +54,6 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
 void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv);
 int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color);
 int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color);
-void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv);
+void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag = nullptr);
 
 }  // namespace amgh

@@ -110,9 +110,10 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
         d.color = _lib.ptr(lv.color, C.c_int32)
         d.n_colors = int(lv.n_colors)
         if types[i] == "hgs" and i + 1 < n:
-            B = gs_block_rows(lv.A)
+            pre = getattr(lv, "hgs_pre", None)      # rank-partitioned levels: computed by the distributed setup (needs ghost diagonals)
+            B = pre["B"] if pre else gs_block_rows(lv.A)
             if B > 0:
-                col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B)
+                col, nc, dinv = (pre["color"], pre["n_colors"], pre["dinv"]) if pre else hybrid_gs_data(lv.A, lv.free, B)
                 info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv)
                 keep.append(info[i])
                 d.color, d.n_colors, d.dinv, d.gs_block_rows = _lib.ptr(col, C.c_int32), nc, _lib.ptr(dinv, C.c_double), B

@@ -643,6 +643,39 @@ def _hybrid_gs_data(comm, states):
         s.color, s.n_colors = color, int(nc.value)
 
 
+def _hybrid_gsb_data(comm, states, block_rows=None):
+    """block-hybrid Gauss-Seidel on a rank-partitioned level (amgx_level_desc.gs_block_rows): blocks of B consecutive owned
+    rows; blocked colouring; inverse of the l1-modified diagonal whose off-block weight includes the couplings to ghost
+    columns (their diagonal entries come from the owners)"""
+    from .device import gs_block_rows
+    lib = _lib.host()
+    diags = [np.asarray(s.A[:, :s.n].diagonal()) for s in states]
+    gdiag = _exchange_ghost_values(comm, states, diags)
+    Bs = []
+    for s in states:
+        M = _mat(s.A)
+        Bs.append(int(block_rows) if block_rows else gs_block_rows(M))
+    B = min(min(x) for x in comm.allgather(Bs))          # (0 if any rank cannot use the block form)
+    for s, gd in zip(states, gdiag):
+        if B <= 0:
+            raise NgsAMGError("hgs: a rank-partitioned level cannot use the block-hybrid form (rows too long or level too small); use sm_type = gs")
+        M = _mat(s.A)
+        d = M.desc()
+        fr = np.ascontiguousarray(s.free, dtype=np.uint8)
+        color = np.full(s.n, -1, dtype=np.int32)
+        nc = C.c_int32()
+        _lib.hcheck(lib.amgh_coloring_blocked(C.byref(d), _lib.ptr(fr, C.c_uint8), B, _lib.ptr(color, C.c_int32), C.byref(nc)))
+        dinv = np.zeros(M.n_cols)
+        gd = np.ascontiguousarray(gd, dtype=np.float64)
+        _lib.hcheck(lib.amgh_hybrid_dinv_ext(C.byref(d), _lib.ptr(fr, C.c_uint8), B, _lib.ptr(gd, C.c_double) if gd.size else None, _lib.ptr(dinv, C.c_double)))
+        s.color, s.n_colors, s.dinv_gs_ext, s.gs_B = color, int(nc.value), dinv, B
+        # the same sweep for the serial oracle / CPU stage backend: visiting order (block, colour), blocks never see each other's updates
+        rows = np.nonzero(color >= 0)[0]
+        key = (rows // B).astype(np.int64) * (int(nc.value) + 1) + color[rows]
+        s.gs_order = rows[np.argsort(key, kind="stable")].astype(np.int32)
+        s.gs_blockid = (np.arange(s.n) // B).astype(np.int32)
+
+
 def _hybrid_bgs_data(states):
     """hybrid block Gauss-Seidel (reference HybridBS, block_gssmoother.cpp:505-585): BSmoother on the rank-local matrix M
     whose diagonal is replaced by the l1-modified one (mod_diag), blocks = local aggregates; needs _hybrid_gs_data first"""
@@ -673,6 +706,10 @@ class _TopHierarchy:
                                      n_colors=s.n_colors if use_gs else 0, agg=None,
                                      Q=_mat(s.Q) if (fold and not last and not use_gs) else None,
                                      bgs=s.bgs if (bgs and not last) else None))
+            L = self.levels[-1]
+            if use_gs and hasattr(s, "gs_B"):
+                L.hgs_pre = dict(B=s.gs_B, color=s.color, n_colors=s.n_colors, dinv=s.dinv_gs_ext)
+                L.gs_order, L.gs_block = s.gs_order, s.gs_blockid
         self.coarse_n = 0
         self.coarse_inv = np.empty(0)
         self.n_levels = len(self.levels)
@@ -688,8 +725,8 @@ class DistributedAMG:
 
     def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=50000, max_dist_levels=3, device=0,
                  backend=None, sm_type="jacobi", fold=True, **opts):
-        if sm_type not in ("jacobi", "gs", "bgs"):
-            raise NgsAMGError("DistributedAMG: sm_type must be jacobi, gs or bgs")
+        if sm_type not in ("jacobi", "gs", "hgs", "bgs"):
+            raise NgsAMGError("DistributedAMG: sm_type must be jacobi, gs (multicolour stages), hgs (block-hybrid Gauss-Seidel) or bgs")
         self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
         # energy = 1: linear elasticity (states from assemble_elasticity_owned: block levels, rigid-body prolongation blocks,
         # coarse block size dim + nrot); block levels run block-Jacobi in the literal stage order
@@ -718,6 +755,9 @@ class DistributedAMG:
         if sm_type in ("gs", "bgs"):
             for lv in levels[:-1]:
                 _hybrid_gs_data(comm, lv)
+        if sm_type == "hgs":
+            for lv in levels[:-1]:
+                _hybrid_gsb_data(comm, lv, opts.get("hgs_block_rows"))
         if sm_type == "gs":
             for lv in levels[:-1]:
                 _gs_stages(comm, lv, opts.get("gs_stage_min_rows", 65536))
@@ -756,7 +796,7 @@ class DistributedAMG:
         if sm_type == "bgs":
             self.tail_hier.build_bgs(pinv=False)
         # ---- per-rank execution objects --------------------------------------------------------------------
-        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type in ("gs", "bgs")), fold=self.fold, bgs=(sm_type == "bgs"))
+        self.tops = [_TopHierarchy([lv[i] for lv in levels], gs=(sm_type in ("gs", "hgs", "bgs")), fold=self.fold, bgs=(sm_type == "bgs"))
                      for i in range(len(states0))]
         self._dev = None
         if backend is None:
@@ -788,8 +828,8 @@ class DistributedAMG:
                 b["text"].append(ops.zeros(next_))
                 b["x"].append(ops.zeros(s.n * bsl))
                 b["r"].append(ops.zeros(s.n * bsl))
-                b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type in ("gs", "bgs") or self.fold) else None)
-                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type in ("gs", "bgs") else None)
+                b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type in ("gs", "hgs", "bgs") or self.fold) else None)
+                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type in ("gs", "hgs", "bgs") else None)
                 # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
                 peers = sorted(s.send)
                 allidx = _vexp(np.concatenate([s.send[q] for q in peers]), bsl) if peers else np.empty(0, dtype=np.int64)
@@ -839,7 +879,7 @@ class DistributedAMG:
         [owned | ghost] entries, the ghost entries are added to their owners first (DISTRIBUTED vector)"""
         if self._dev is not None:
             return self._dev.Mult(bs, xs, b_status)
-        if self.sm_type in ("gs", "bgs"):
+        if self.sm_type in ("gs", "hgs", "bgs"):
             return self._mult_gs(bs, xs)
         if self.fold:
             return self._mult_folded(bs, xs)
@@ -997,6 +1037,17 @@ class DistributedAMG:
                     block.append(np.full(t[2].size, t[0], dtype=np.int32))
                 L.gs_order = np.concatenate(order).astype(np.int32)
                 L.gs_block = np.concatenate(block)
+            if self.sm_type == "hgs":
+                pg = [(s.rank, s.dinv_gs_ext[:s.n], s.gs_order, s.gs_blockid) for s in lv]
+                gg = sorted(comm.allgather(pg)[0], key=lambda t: t[0])
+                L.dinv = np.concatenate([t[1] for t in gg])
+                order, block, boff = [], [], 0
+                for t in gg:
+                    order.append(off[t[0]] + t[2])
+                    block.append(boff + t[3])
+                    boff += int(t[3].max()) + 1 if t[3].size else 0
+                L.gs_order = np.concatenate(order).astype(np.int32)
+                L.gs_block = np.concatenate(block).astype(np.int32)
             if self.sm_type == "bgs":
                 # hybrid block GS as ONE serial smoother: blocks of all ranks (global row ids), visited rank by rank and
                 # colour-major inside a rank; rows of another rank are read at their sweep-start values (gs_block)
@@ -1091,7 +1142,8 @@ class _DeviceDist:
         for i, top in enumerate(amg.tops):
             types = [sm] * (top.n_levels - 1) + ["jacobi"]
             tdesc, tkeep, _ = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
-            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
+            # (the replicated tail of an "hgs" hierarchy keeps the multicolour form: its levels are small)
+            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type="gs" if sm == "hgs" else sm, omega=amg.omega, device=self.device)
             halos = (_lib.amgx_halo_desc * k)()
             keep = [tkeep, lkeep, halos]
             for l in range(k):

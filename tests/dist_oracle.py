@@ -7,7 +7,7 @@ def oracle_sm_types(amg):
         return ["jacobi"] * (amg.k + amg.tail_hier.n_levels)
     if amg.sm_type == "bgs":
         return ["bgs_mc"] * (amg.k + amg.tail_hier.n_levels)
-    return ["gs_order"] * amg.k + ["gs_mc"] * amg.tail_hier.n_levels
+    return ["gs_order"] * amg.k + ["gs_mc"] * amg.tail_hier.n_levels          # gs and hgs: explicit order (+ blocks) on the distributed levels
 
 
 def oracle_bgs(amg, levels):

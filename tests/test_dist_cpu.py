@@ -12,12 +12,12 @@ from tests.dist_cpu_backend import cpu_backend
 from tests.dist_oracle import oracle_bgs, oracle_sm_types
 
 
-def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True):
+def _run_loopback(R, box, dim, dist_min_rows, sm="jacobi", fold=True, **extra):
     comm = D.LoopbackComm(R)
     pg = D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
     amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dist_min_rows, backend=cpu_backend(sm_type=sm),
-                           max_coarse_size=10, sm_type=sm, fold=fold)
+                           max_coarse_size=10, sm_type=sm, fold=fold, **extra)
     rng = np.random.default_rng(0)
     bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
     xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
@@ -226,3 +226,17 @@ def test_loopback_elasticity_matches_serial_oracle(R, box, rot):
     t = np.zeros((A.shape[0] // bs0, bs0))
     t[:, 0] = 1.0
     assert np.abs(A @ t.ravel()).max() < 1e-11
+
+
+@pytest.mark.parametrize("R,box,dim,dmin,B", [(2, (12, 12, 12), 3, 100, 64), (4, (10, 10, 10), 3, 50, 32), (8, (8, 8, 8), 3, 20, 64), (4, (24, 24), 2, 50, 128)])
+def test_loopback_block_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin, B):
+    """sm_type = hgs: block-hybrid Gauss-Seidel on rank-partitioned levels (blocks of B consecutive owned rows, l1-modified
+    diagonal incl. the couplings to ghost columns) == the oracle's serial hybrid GS with the same blocks and order"""
+    amg, got, ref = _run_loopback(R, box, dim, dmin, "hgs", hgs_block_rows=B)
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg))
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
+    _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)
+    assert errs[-1] < 1e-8 * errs[0] and it < 60
