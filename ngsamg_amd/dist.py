@@ -793,6 +793,20 @@ class DistributedAMG:
         topts["first_aaf"] = opts.get("aaf", 2.0 ** -dim)
         coords_g = np.concatenate([p[4] for p in allp]) if (self.energy == 1 and all(p[4] is not None for p in allp)) else None
         self.tail_hier = Hierarchy(_mat(Ag, bk), None, coords_g, dim=dim, energy=self.energy, **topts)
+        if sm_type == "hgs":
+            # the replicated tail sweeps in the block-hybrid form too (one launch per sweep instead of one per colour):
+            # blocks, colours and modified diagonals are fixed here so that every consumer of the hierarchy sees the same data
+            from .device import gs_block_rows, hybrid_gs_data
+            for L in self.tail_hier.levels[:-1]:
+                B = gs_block_rows(L.A)
+                if B > 0:
+                    col, nc, dinv = hybrid_gs_data(L.A, L.free, B)
+                    L.hgs_pre = dict(B=B, color=col, n_colors=nc, dinv=dinv)
+                    rows = np.nonzero(col >= 0)[0]
+                    key = (rows // B).astype(np.int64) * (nc + 1) + col[rows]
+                    L.gs_order = rows[np.argsort(key, kind="stable")].astype(np.int32)
+                    L.gs_block = (np.arange(L.A.n_rows) // B).astype(np.int32)
+                    L.hgs_dinv = dinv
         if sm_type == "bgs":
             self.tail_hier.build_bgs(pinv=False)
         # ---- per-rank execution objects --------------------------------------------------------------------
@@ -1071,7 +1085,16 @@ class DistributedAMG:
                                 order=np.concatenate(order).astype(np.int32))
                 L.gs_block = np.concatenate(block)
             out.append(L)
-        return out + list(self.tail_hier.levels)
+        tail = []
+        for L in self.tail_hier.levels:
+            if getattr(L, "hgs_pre", None) is not None:
+                from copy import copy
+                L2 = copy(L)
+                L2.dinv = np.ascontiguousarray(L.hgs_dinv[:L.A.n_rows])
+                tail.append(L2)
+            else:
+                tail.append(L)
+        return out + tail
 
 
 def _gs_stages(comm, states, min_rows):
@@ -1142,8 +1165,7 @@ class _DeviceDist:
         for i, top in enumerate(amg.tops):
             types = [sm] * (top.n_levels - 1) + ["jacobi"]
             tdesc, tkeep, _ = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
-            # (the replicated tail of an "hgs" hierarchy keeps the multicolour form: its levels are small)
-            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type="gs" if sm == "hgs" else sm, omega=amg.omega, device=self.device)
+            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
             halos = (_lib.amgx_halo_desc * k)()
             keep = [tkeep, lkeep, halos]
             for l in range(k):

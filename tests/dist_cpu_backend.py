@@ -24,8 +24,18 @@ def cpu_backend(omega=0.9, sm_type="jacobi"):
             self.P = [L.P.to_scipy() if L.P is not None else None for L in top.levels]
             self.Q = [L.Q.to_scipy() if getattr(L, "Q", None) is not None else None for L in top.levels]
             if id(tail_hier) not in tails:
-                tails[id(tail_hier)] = Oracle(tail_hier.levels, sm_type={"jacobi": "jacobi", "gs": "gs_mc", "hgs": "gs_mc", "bgs": "bgs_mc"}[sm_type], omega=omega,
-                                              bgs=[L.bgs for L in tail_hier.levels] if sm_type == "bgs" else None)
+                tl, tt = list(tail_hier.levels), {"jacobi": "jacobi", "gs": "gs_mc", "hgs": "gs_mc", "bgs": "bgs_mc"}[sm_type]
+                if sm_type == "hgs":
+                    from copy import copy
+                    tt = []
+                    for q, L in enumerate(tl):
+                        if getattr(L, "hgs_pre", None) is not None:
+                            tl[q] = copy(L)
+                            tl[q].dinv = np.ascontiguousarray(L.hgs_dinv[:L.A.n_rows])
+                            tt.append("gs_order")
+                        else:
+                            tt.append("gs_mc")
+                tails[id(tail_hier)] = Oracle(tl, sm_type=tt, omega=omega, bgs=[L.bgs for L in tail_hier.levels] if sm_type == "bgs" else None)
             # rank-local smoother objects: one single-level oracle per distributed level (rectangular A, no coarse solve)
             self.loc = [(Oracle([L], sm_type="gs_mc", clev="none") if sm_type == "gs" else
                          Oracle([L], sm_type="gs_order", clev="none") if sm_type == "hgs" else

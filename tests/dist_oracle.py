@@ -7,7 +7,9 @@ def oracle_sm_types(amg):
         return ["jacobi"] * (amg.k + amg.tail_hier.n_levels)
     if amg.sm_type == "bgs":
         return ["bgs_mc"] * (amg.k + amg.tail_hier.n_levels)
-    return ["gs_order"] * amg.k + ["gs_mc"] * amg.tail_hier.n_levels          # gs and hgs: explicit order (+ blocks) on the distributed levels
+    # gs / hgs: explicit visiting order (+ blocks with frozen couplings) on the distributed levels; tail levels that sweep in
+    # the block-hybrid form carry their order too, the others run in colour order
+    return ["gs_order"] * amg.k + ["gs_order" if getattr(L, "gs_order", None) is not None else "gs_mc" for L in amg.tail_hier.levels]
 
 
 def oracle_bgs(amg, levels):

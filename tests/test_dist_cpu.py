@@ -228,7 +228,8 @@ def test_loopback_elasticity_matches_serial_oracle(R, box, rot):
     assert np.abs(A @ t.ravel()).max() < 1e-11
 
 
-@pytest.mark.parametrize("R,box,dim,dmin,B", [(2, (12, 12, 12), 3, 100, 64), (4, (10, 10, 10), 3, 50, 32), (8, (8, 8, 8), 3, 20, 64), (4, (24, 24), 2, 50, 128)])
+@pytest.mark.parametrize("R,box,dim,dmin,B", [(2, (12, 12, 12), 3, 100, 64), (4, (10, 10, 10), 3, 50, 32), (8, (8, 8, 8), 3, 20, 64), (4, (24, 24), 2, 50, 128),
+                                              (2, (30, 30, 30), 3, 10000, 256)])          # last: block-hybrid levels in the replicated tail too
 def test_loopback_block_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin, B):
     """sm_type = hgs: block-hybrid Gauss-Seidel on rank-partitioned levels (blocks of B consecutive owned rows, l1-modified
     diagonal incl. the couplings to ghost columns) == the oracle's serial hybrid GS with the same blocks and order"""

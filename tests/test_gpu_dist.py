@@ -372,7 +372,8 @@ def test_loopback_device_elasticity_matches_serial_oracle(R, box, rot):
     assert np.linalg.norm(got - ref) <= 1e-11 * np.linalg.norm(ref)
 
 
-@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (8, (12, 12, 12), 3, 100), (4, (48, 48), 2, 300)])
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (8, (12, 12, 12), 3, 100), (4, (48, 48), 2, 300),
+                                            (2, (40, 40, 40), 3, 20000)])          # last: the replicated tail has block-hybrid levels too
 def test_loopback_device_block_hybrid_gs(R, box, dim, dmin):
     """sm_type = hgs on rank-partitioned levels through the native driver (boundary blocks, exchange, interior blocks; two
     launches per sweep) == the oracle's serial hybrid GS with the same blocks (256 owned rows), colours and modified diagonal"""
