@@ -179,7 +179,9 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *   op = 6: coarse-grid correction + post-smoothing as the V-cycle runs it on this level
  *   op = 7: sell_pre_restrict_kernel alone (op 5 without the small restrict_sum_kernel); error if the level has none
  *   op = 8: the same kernel timed INSIDE the cycle: `reps` whole cycles are launched directly (no graph) with HIP events
- *           around that one kernel; the average is what rocprofv3 --kernel-trace reports for it (roofline.achieved) */
+ *           around that one kernel; the average is what rocprofv3 --kernel-trace reports for it (roofline.achieved)
+ *   op = 9: like 8 for the backward block-hybrid Gauss-Seidel sweep of the level (gsb_sweep_kernel, the dominant kernel
+ *           of a Gauss-Seidel cycle); error if the level has no such sweep */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
 
 /* Krylov solvers with all vectors resident on the GPU: the callers of the preconditioner on the

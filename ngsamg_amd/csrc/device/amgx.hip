@@ -393,7 +393,13 @@ static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
   D.slice_ptr.upload(S.slice_ptr);
   D.val.upload(S.val);
   if (S.n_comp_slices < ns) D.col32.upload(S.col32);               // only read by 32-bit slices
-  if (S.n_comp_slices > 0) { D.col16.upload(S.col16); D.cbase.upload(S.cbase); }
+  if (S.n_comp_slices > 0) {
+    D.col16.upload(S.col16);
+    // slack behind the last slice: gsb_sweep_kernel reads the column bases of a slice as one unconditional group of 2*GSB_WP + 1
+    std::vector<int32_t> cb(S.cbase);
+    cb.resize(cb.size() + 32, 0);
+    D.cbase.upload(cb);
+  }
 }
 
 // block SELL image of a square-block matrix (see kernels.hpp BSellMat); returns false if the padding would exceed `max_pad`
@@ -640,7 +646,8 @@ struct Handle {
   bool use_graph = true;
   bool skip_rsum = false;               // amgx_time_op(op 7): time sell_pre_restrict_kernel alone
   // amgx_time_op(op 8): HIP events around the fused down kernel of `probe_level` INSIDE the cycle (direct launches)
-  int probe_level = -1;
+  // (op 9): the same around the backward block-hybrid Gauss-Seidel sweep of `probe_level`
+  int probe_level = -1, probe_kind = 8;
   hipEvent_t probe_e0 = nullptr, probe_e1 = nullptr;
   int ep_nt = 1;                        // non-temporal epilogue operands (AMGX_NO_EP_NT=1 disables)
   int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
@@ -1100,7 +1107,7 @@ struct Handle {
       int64_t ca, cb;
       unit_range(sp, FB, nch, ca, cb);
       const int grid = (int)(cb - ca), c0 = (int)ca;
-      const bool probe = probe_level == l && probe_e0;
+      const bool probe = probe_level == l && probe_kind == 8 && probe_e0;
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       if (grid > 0) {
         if (FB == 256)
@@ -1169,7 +1176,10 @@ struct Handle {
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
+      const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
+      if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       gsb_sweep(L, 1, L.gsb.full, L.tmp.p, x, b);   // backward block-hybrid sweep, tmp -> x
+      if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
     } else {
       add_c2f(l, 1.0, x, xc);
       level_smooth(L, 1, x, b, r, false, false, false);
@@ -2310,10 +2320,13 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
         default: throw amgx::Err("amgx_time_op: unknown op");
       }
     };
-    if (op == 8) {
+    if (op == 8 || op == 9) {
       // the dominant kernel timed where it runs: inside the cycle, between the previous cycle's last kernel and the
       // partial-sum reduction (cache state and clocks of the real application), averaged over `reps` cycles
-      if (L.RF.empty() || !(h.plain(L) && L.sm_type == AMGX_SM_JACOBI)) throw amgx::Err("amgx_time_op: level has no fused pre-smoothing + restriction kernel");
+      if (op == 8 && (L.RF.empty() || !(h.plain(L) && L.sm_type == AMGX_SM_JACOBI))) throw amgx::Err("amgx_time_op: level has no fused pre-smoothing + restriction kernel");
+      if (op == 9 && !(has_c && h.plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols && !h.folded(L)))
+        throw amgx::Err("amgx_time_op: level has no block-hybrid Gauss-Seidel sweep");
+      h.probe_kind = op;
       if (h.stream == nullptr) throw amgx::Err("amgx_time_op: op 8 needs a non-default stream");
       HIPCHK(hipEventCreate(&h.probe_e0));
       HIPCHK(hipEventCreate(&h.probe_e1));

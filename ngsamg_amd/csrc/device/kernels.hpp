@@ -199,7 +199,7 @@ __device__ __forceinline__ void sell_consume(const SellRegs<K>& R, const int32_t
     x0[k] = x[c0];
     x1[k] = x[c1];
   }
-  if (xd && p == 0) { xd[0] = x0[0]; xd[1] = R.v0[0]; }
+  if (p == 0) { xd[0] = x0[0]; xd[1] = R.v0[0]; }
 #pragma unroll
   for (int k = 0; k < K; ++k) { acc0 += R.v0[k] * x0[k]; acc1 += R.v1[k] * x1[k]; }
 }
@@ -249,7 +249,8 @@ __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb
 // dot product of SELL row (slice s, lane) with x; row = global row id of this lane (for row-relative columns)
 // xd (optional, 2 doubles): receives the x value gathered for entry 0 of this lane's row and the matrix value of that
 // entry (meaningful when M.diag_first)
-__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd = nullptr) {
+// (xd is always a real local of the caller: a conditionally-null pointer kept the pair in scratch memory)
+__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd) {
   const int64_t sp0 = M.slice_ptr[s];
   const int64_t base = sp0 & ~(int64_t)63;
   const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
@@ -271,10 +272,14 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
   else sell_pairs<false>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
   if (w & 1) {
     const double x0 = x[c16 ? r0 + cb[w - 1] + cs : cs];
-    if (xd && np == 0) { xd[0] = x0; xd[1] = vs; }
+    if (np == 0) { xd[0] = x0; xd[1] = vs; }
     acc0 += vs * x0;
   }
   return acc0 + acc1;
+}
+__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x) {
+  double xd[2];
+  return sell_row_dot(M, s, lane, row, x, xd);
 }
 
 // SELL-64-pair, scalar, G lanes per row (G = 1: one thread per row), one wave per slice of 64/G rows
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int sl
   const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
   EpOps ops{0.0, 0.0, 0.0};
   if (hoist && writer) ops = ep_operands<EP>(row, ep, use_xd, wdiag);
-  double acc = sell_row_dot(M, s, lane, row, x, use_xd ? xd : nullptr);
+  double acc = sell_row_dot(M, s, lane, row, x, xd);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
   if (writer) {
@@ -617,19 +622,22 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
                                                         const double* __restrict__ xin, double* xout) {
   constexpr int B = TH / G;                  // rows per block
   constexpr int RPS = WAVE / G;              // rows per slice
-  __shared__ double xs[B];
+  __shared__ double xs[B], bs[B], ds[B];     // x of the block; b and the (modified) inverse diagonal in natural row order
   const int blk = block0 + blockIdx.x;
   const int64_t r0 = (int64_t)blk * B;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int s = __builtin_amdgcn_readfirstlane(blk * (TH / WAVE) + (tid >> 6));
-  if (tid < B) { const int64_t r = r0 + tid; xs[tid] = (!FROM_ZERO && r < n_rows) ? xin[r] : 0.0; }
+  // ---- phase 1: every load that depends on nothing goes out before anything is consumed (a wait inside this phase
+  // would serialise ~30 round trips per wave: measured 456 us -> see profiles/r02/gs_block_ab.txt)
+  double x_own = 0.0, b_nat = 0.0, d_nat = 0.0;
+  if (tid < B && r0 + tid < n_rows) {        // natural order: coalesced, and independent of the slot -> row map
+    if (!FROM_ZERO) x_own = xin[r0 + tid];
+    b_nat = a.b[r0 + tid];
+    d_nat = a.dinv[r0 + tid];
+  }
   const int slot = s * RPS + lane / G;
   const int row = a.rowid[slot];
-  const int mycol = row >= 0 ? (int)a.slotcolor[slot] : 255;
-  const bool writer = mycol != 255 && (lane % G) == 0;
-  double dv = 0.0, bv = 0.0;
-  if (writer) { dv = a.dinv[row]; bv = a.b[row]; }
-  // ---- this lane's entries: values + decoded columns
+  const int col_raw = (int)a.slotcolor[slot];
   const int64_t sp0 = M.slice_ptr[s];
   const int64_t base = sp0 & ~(int64_t)63;
   const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
@@ -639,40 +647,73 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
   const int32_t* __restrict__ cb = M.cbase + (base >> 6);
   double v[2 * GSB_WP + 1];
   int cl[2 * GSB_WP + 1];
+  uint32_t ra[GSB_WP], rb[GSB_WP];           // raw index words: 16-bit form = one packed pair in ra; 32-bit form = ra, rb
 #pragma unroll
   for (int p = 0; p < GSB_WP; ++p) {
+    v[2 * p] = 0.0; v[2 * p + 1] = 0.0; ra[p] = 0; rb[p] = 0;
     if (p < np) {                                            // wave-uniform
       v[2 * p] = ld_nt(vb + (p * WAVE + lane) * 2);
       v[2 * p + 1] = ld_nt(vb + (p * WAVE + lane) * 2 + 1);
-      if (c16) {
-        const uint32_t pk = ld_nt(reinterpret_cast<const uint32_t*>(M.col16 + base) + p * WAVE + lane);
-        cl[2 * p] = cb[2 * p] + (int)(pk & 0xffffu);
-        cl[2 * p + 1] = cb[2 * p + 1] + (int)(pk >> 16);
-      } else {
-        cl[2 * p] = ld_nt(M.col32 + base + (p * WAVE + lane) * 2);
-        cl[2 * p + 1] = ld_nt(M.col32 + base + (p * WAVE + lane) * 2 + 1);
+      if (c16) ra[p] = ld_nt(reinterpret_cast<const uint32_t*>(M.col16 + base) + p * WAVE + lane);
+      else {
+        ra[p] = (uint32_t)ld_nt(M.col32 + base + (p * WAVE + lane) * 2);
+        rb[p] = (uint32_t)ld_nt(M.col32 + base + (p * WAVE + lane) * 2 + 1);
       }
-    } else { v[2 * p] = 0.0; v[2 * p + 1] = 0.0; cl[2 * p] = (int)r0; cl[2 * p + 1] = (int)r0; }
+    }
   }
+  int cbv[2 * GSB_WP + 1];                   // column bases of the slice: one group of scalar loads (the array has slack at its end)
+#pragma unroll
+  for (int j = 0; j < 2 * GSB_WP + 1; ++j) cbv[j] = 0;
+  if (c16) {
+#pragma unroll
+    for (int j = 0; j < 2 * GSB_WP + 1; ++j) cbv[j] = cb[j];
+  }
+  uint32_t rt = 0;
+  v[2 * GSB_WP] = 0.0;
   if (w & 1) {
     const int64_t o = (int64_t)(w - 1) * WAVE + lane;
     v[2 * GSB_WP] = ld_nt(vb + o);
-    cl[2 * GSB_WP] = c16 ? cb[w - 1] + (int)ld_nt(M.col16 + base + o) : ld_nt(M.col32 + base + o);
-  } else { v[2 * GSB_WP] = 0.0; cl[2 * GSB_WP] = (int)r0; }
-  // ---- off-block part now (frozen values), in-block part as (value, LDS slot)
-  double acc_off = 0.0;
+    rt = c16 ? (uint32_t)ld_nt(M.col16 + base + o) : (uint32_t)ld_nt(M.col32 + base + o);
+  }
+  // ---- phase 2: the column decode (needs the index words)
+  const int mycol = row >= 0 ? col_raw : 255;
+  const bool writer = mycol != 255 && (lane % G) == 0;
+#pragma unroll
+  for (int p = 0; p < GSB_WP; ++p) {
+    cl[2 * p] = (int)r0; cl[2 * p + 1] = (int)r0;
+    if (p < np) {
+      if (c16) { cl[2 * p] = cbv[2 * p] + (int)(ra[p] & 0xffffu); cl[2 * p + 1] = cbv[2 * p + 1] + (int)(ra[p] >> 16); }
+      else { cl[2 * p] = (int)ra[p]; cl[2 * p + 1] = (int)rb[p]; }
+    }
+  }
+  // (the odd trailing column of a slice of width w <= 2*GSB_WP + 1 is column w - 1: a wave-uniform pick from the group)
+  int cbt = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * GSB_WP + 1; j += 2) cbt = (w - 1 == j) ? cbv[j] : cbt;
+  cl[2 * GSB_WP] = (w & 1) ? (c16 ? cbt + (int)rt : (int)rt) : (int)r0;
+  // ---- phase 3: off-block part (frozen values): all gathers requested, then summed; in-block part keeps (value, LDS slot)
+  double xg[2 * GSB_WP + 1];
 #pragma unroll
   for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
     const int loc = cl[j] - (int)r0;
     const bool inb = loc >= 0 && loc < B && cl[j] < n_rows;       // (ghost columns of a rank-partitioned level are never in-block)
-    if (!FROM_ZERO) { if (!inb && v[j] != 0.0) acc_off += v[j] * xin[cl[j]]; }
-    if (!inb) v[j] = 0.0;
-    cl[j] = inb ? loc : 0;
+    xg[j] = 0.0;
+    if (!FROM_ZERO) { if (!inb) xg[j] = xin[cl[j]]; }
+    cl[j] = inb ? loc : -1;
+  }
+  double acc_off = 0.0;
+#pragma unroll
+  for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
+    const bool inb = cl[j] >= 0;
+    if (!FROM_ZERO) acc_off += inb ? 0.0 : v[j] * xg[j];
+    if (!inb) { v[j] = 0.0; cl[j] = 0; }
   }
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc_off += __shfl_xor(acc_off, o, G);
+  if (tid < B) { xs[tid] = x_own; bs[tid] = b_nat; ds[tid] = d_nat; }
   const int own = row >= 0 ? row - (int)r0 : 0;
-  __syncthreads();                                           // xs is loaded
+  __syncthreads();                                           // xs, bs, ds are loaded
+  const double dv = writer ? ds[own] : 0.0, bv = writer ? bs[own] : 0.0;
   for (int q = 0; q < a.n_colors; ++q) {
     const int c = a.backward ? a.n_colors - 1 - q : q;
     if (__any(mycol == c)) {                                 // slices hold one or two colours (slots are colour-sorted)
@@ -891,7 +932,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     double xd[2] = {0.0, 0.0};
     const bool wdiag = M.wdiag && M.diag_first;
     if (!wdiag && (nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
-    double acc = sell_row_dot(M, s, lane, row, b, wdiag ? xd : nullptr);
+    double acc = sell_row_dot(M, s, lane, row, b, xd);
     if (row < n_rows) {
       if (wdiag) {
         // diagonal slot = omega*Dinv_i (no dinv stream, b_i from the gather): see sell_spmv_kernel
