@@ -184,6 +184,38 @@ int amgx_matrix_stream_bytes(amgx_handle h, int level, int which, int64_t* bytes
  *           of a Gauss-Seidel cycle); error if the level has no such sweep */
 int amgx_time_op(amgx_handle h, int level, int op, int reps, double* avg_ms);
 
+/* ---- GSS4: Gauss-Seidel on a subset of the rows, on a compressed device copy ------------------------------------------
+ * Reference: GSS4<TM> (src/base/smoothers/gssmoother.hpp:99-143, gssmoother.cpp:407-583), the smoother of the EX stage of
+ * HybridGSSmoother (gssmoother.cpp:697-698).  Only the rows of the subset are copied to the device ("xdofs" and the
+ * compressed matrix cA of GSS4::SetUp, :456-507) together with the transposed couplings the RES form needs.
+ *   amgx_gss4_smooth      Smooth (dir 0) / SmoothBack (dir 1):        x_k += dinv_k (b_k - A_k: x)               (:565-583)
+ *   amgx_gss4_smooth_res  SmoothRES / SmoothBackRES:  w = -dinv_k res_k; res += A_k:^T w; x_k -= w               (:543-561)
+ *   amgx_gss4_mult_add    MultAdd:                                    x_k += s dinv_k b_k  for k in the subset   (:531-539)
+ * Rows of equal colour are relaxed in parallel, colours ascending (dir 0) or descending (dir 1); the reference's
+ * one-row-at-a-time order is the special case of one row per colour.  Vectors: x and b have A.n_rows * bs entries, except
+ * that the gathered vector (x of amgx_gss4_smooth, res of amgx_gss4_smooth_res) has A.n_cols * bs. */
+typedef struct amgx_gss4_desc {
+  amgx_matrix A;              /* square blocks 1, 2, 3, 6; n_cols >= n_rows (ghost columns are read, never updated)          */
+  const uint8_t* subset;      /* [n_rows] 1 = row is smoothed, or NULL (all rows)                                            */
+  const double* dinv;         /* [n_rows*bs*bs] inverse of the diagonal block or of its replacement (mod_diag), read on the   */
+                              /*   subset only: the caller applies CalcInverse / CalcPseudoInverseTryNormal (:417-438)        */
+  const int32_t* color;       /* [n_rows] colour of the rows of the subset (coupled rows differ), -1 elsewhere               */
+  int32_t n_colors;
+  int32_t device;
+} amgx_gss4_desc;
+typedef struct amgx_gss4_t* amgx_gss4;
+
+int amgx_gss4_create(const amgx_gss4_desc* desc, amgx_gss4* out);
+int amgx_gss4_destroy(amgx_gss4 g);
+const char* amgx_gss4_last_error(amgx_gss4 g);            /* g may be NULL for create-time errors */
+int amgx_gss4_set_stream(amgx_gss4 g, void* hip_stream);
+int amgx_gss4_synchronize(amgx_gss4 g);
+/* rows of the subset, rows the subset couples to (= rows of res the RES form updates), blocks stored */
+int amgx_gss4_info(amgx_gss4 g, int64_t* n_rows, int64_t* n_touched, int64_t* nnz);
+int amgx_gss4_smooth(amgx_gss4 g, int dir, double* x, const double* b, int flags);
+int amgx_gss4_smooth_res(amgx_gss4 g, int dir, double* x, double* res, int flags);
+int amgx_gss4_mult_add(amgx_gss4 g, double s, const double* b, double* x, int flags);
+
 /* Krylov solvers with all vectors resident on the GPU: the callers of the preconditioner on the
  * reference side are NGSolve's CGSolver / GMRes (tests/h1/amg_utils.py:346).  Operator = the level-0 matrix of the handle,
  * preconditioner = the handle's cycle (use_precond = 0: none).  x holds the initial guess and receives the solution.

@@ -557,6 +557,110 @@ def CreateHybridBlockGSS(mat, blocks, NG_MPI_overlap=True, NG_MPI_thread=False, 
     return BaseSmoother(AMGMatrix(hier, dev), 0)
 
 
+class GSS4:
+    """Gauss-Seidel on a subset of the rows of a sparse matrix, on a compressed device copy (reference GSS4<TM>,
+    gssmoother.hpp:99-143, gssmoother.cpp:407-583; the EX-stage smoother of HybridGSSmoother).
+
+        GSS4(mat, subset=None, repl_diag=None, pinv=False, bs=1)
+
+    repl_diag: replacement diagonal blocks [n, bs, bs] (the hybrid smoother's mod_diag); default = the matrix diagonal.
+    Methods as in the reference: Smooth / SmoothBack (x, b), SmoothRES / SmoothBackRES (x, res), MultAdd(s, b, x).
+    Vectors: numpy arrays (copied in and out) or CUDA float64 tensors (in place).  Rows of equal colour go in parallel."""
+
+    def __init__(self, mat, subset=None, repl_diag=None, pinv=False, bs=1, device=0):
+        import ctypes as C
+        from .device import _Vec
+        self._Vec = _Vec
+        A = _as_matrix(mat, bs)
+        self._A = A
+        n, b = A.n_rows, A.br
+        sub = np.ones(n, dtype=np.uint8) if subset is None else np.ascontiguousarray(np.asarray(subset).astype(np.uint8))
+        if sub.size != n:
+            raise NgsAMGError("GSS4: subset must have one entry per (block) row")
+        host = _lib.host()
+        d = A.desc()
+        if repl_diag is None:
+            dinv = np.zeros(n * b * b)
+            _lib.hcheck(host.amgh_calc_dinv(C.byref(d), _lib.ptr(sub, C.c_uint8), int(bool(pinv)), _lib.ptr(dinv, C.c_double)))
+        else:
+            rd = np.asarray(repl_diag, dtype=np.float64).reshape(n, b, b)
+            dinv = np.zeros((n, b, b))
+            idx = np.flatnonzero(sub)
+            # CalcPseudoInverseTryNormal / CalcInverse on the replacement blocks (gssmoother.cpp:426-434)
+            dinv[idx] = np.linalg.pinv(rd[idx], rcond=1e-12, hermitian=False) if pinv else np.linalg.inv(rd[idx])
+            dinv = np.ascontiguousarray(dinv.ravel())
+        color = np.zeros(n, dtype=np.int32)
+        nc = C.c_int32()
+        _lib.hcheck(host.amgh_coloring(C.byref(d), _lib.ptr(sub, C.c_uint8), _lib.ptr(color, C.c_int32), C.byref(nc)))
+        self.subset, self.dinv, self.color, self.n_colors = sub, dinv, color, int(nc.value)
+        self._lib = _lib.hip()
+        gd = _lib.amgx_gss4_desc()
+        gd.A = A.desc(_lib.amgx_matrix)
+        gd.subset = _lib.ptr(sub, C.c_uint8)
+        gd.dinv = _lib.ptr(dinv, C.c_double)
+        gd.color = _lib.ptr(color, C.c_int32)
+        gd.n_colors, gd.device = self.n_colors, int(device)
+        h = C.c_void_p()
+        if self._lib.amgx_gss4_create(C.byref(gd), C.byref(h)):
+            raise NgsAMGError("amgx_gss4_create: " + self._lib.amgx_gss4_last_error(None).decode())
+        self._h, self._stream = h, 0
+        self._n, self._nc = n * b, A.n_cols * b
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.amgx_gss4_destroy(h)
+            self._h = None
+
+    def _ck(self, rc):
+        if rc:
+            raise NgsAMGError(self._lib.amgx_gss4_last_error(self._h).decode())
+
+    def _flags(self, *vecs):
+        import ctypes as C
+        t = [v.torch for v in vecs]
+        if any(t) and not all(t):
+            raise NgsAMGError("mixing host arrays and device tensors in one call is not supported")
+        if all(t):
+            import torch
+            s = int(torch.cuda.current_stream().cuda_stream)
+            if s != self._stream:
+                self._ck(self._lib.amgx_gss4_set_stream(self._h, C.c_void_p(s)))
+                self._stream = s
+            return _lib.AMGX_DEVICE_PTR
+        return _lib.AMGX_HOST_PTR
+
+    def info(self):
+        import ctypes as C
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self._lib.amgx_gss4_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"rows": a.value, "rows_touched": b.value, "nnz": c.value, "colors": self.n_colors}
+
+    def _rhs(self, back, x, b):
+        vx, vb = self._Vec(x, self._nc, "x", True), self._Vec(b, self._n, "b")
+        self._ck(self._lib.amgx_gss4_smooth(self._h, int(back), vx.addr, vb.addr, self._flags(vx, vb)))
+
+    def _resf(self, back, x, res):
+        vx, vr = self._Vec(x, self._n, "x", True), self._Vec(res, self._nc, "res", True)
+        self._ck(self._lib.amgx_gss4_smooth_res(self._h, int(back), vx.addr, vr.addr, self._flags(vx, vr)))
+
+    def Smooth(self, x, b):
+        self._rhs(False, x, b)
+
+    def SmoothBack(self, x, b):
+        self._rhs(True, x, b)
+
+    def SmoothRES(self, x, res):
+        self._resf(False, x, res)
+
+    def SmoothBackRES(self, x, res):
+        self._resf(True, x, res)
+
+    def MultAdd(self, s, b, x):
+        vb, vx = self._Vec(b, self._n, "b"), self._Vec(x, self._n, "x", True)
+        self._ck(self._lib.amgx_gss4_mult_add(self._h, float(s), vb.addr, vx.addr, self._flags(vb, vx)))
+
+
 class _DirectInverseSmoother(BaseSmoother):
     """RichardsonSmoother(A, A^-1 on the free dofs, omega = 1): what CreateHybridDISmoother degenerates to on one
     rank (python_smoothers.cpp:278-312)"""

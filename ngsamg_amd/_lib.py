@@ -211,6 +211,11 @@ class amgx_dist_desc(C.Structure):
                 ("gs_stage", c_i32p)]
 
 
+class amgx_gss4_desc(C.Structure):
+    _fields_ = [("A", amgx_matrix), ("subset", C.POINTER(C.c_uint8)), ("dinv", c_f64p), ("color", c_i32p),
+                ("n_colors", C.c_int32), ("device", C.c_int32)]
+
+
 AMGX_SM_JACOBI, AMGX_SM_GS, AMGX_SM_BGS = 0, 1, 2
 AMGX_COMM_RCCL, AMGX_COMM_LOCAL = 0, 1
 AMGX_UNIQUE_ID_BYTES = 128
@@ -228,6 +233,8 @@ AMGX_SYMBOLS = [
     "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
     "amgx_comm_synchronize", "amgx_comm_info", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply",
     "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
+    "amgx_gss4_create", "amgx_gss4_destroy", "amgx_gss4_last_error", "amgx_gss4_set_stream", "amgx_gss4_synchronize",
+    "amgx_gss4_info", "amgx_gss4_smooth", "amgx_gss4_smooth_res", "amgx_gss4_mult_add",
 ]
 
 AMGH_SYMBOLS = [
@@ -290,5 +297,16 @@ def hip():
     lib.amgx_halo_create.argtypes = [vp, C.POINTER(amgx_halo_desc), C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.amgx_halo_destroy.argtypes = [vp]
     lib.amgx_halo_exchange.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(dp), C.c_int]
+    # GSS4
+    lib.amgx_gss4_create.argtypes = [C.POINTER(amgx_gss4_desc), C.POINTER(vp)]
+    lib.amgx_gss4_destroy.argtypes = [vp]
+    lib.amgx_gss4_last_error.argtypes = [vp]
+    lib.amgx_gss4_last_error.restype = C.c_char_p
+    lib.amgx_gss4_set_stream.argtypes = [vp, vp]
+    lib.amgx_gss4_synchronize.argtypes = [vp]
+    lib.amgx_gss4_info.argtypes = [vp, c_i64p, c_i64p, c_i64p]
+    lib.amgx_gss4_smooth.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.amgx_gss4_smooth_res.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+    lib.amgx_gss4_mult_add.argtypes = [vp, C.c_double, dp, dp, C.c_int]
     _hip = lib
     return lib

@@ -2379,3 +2379,4 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
 
 #include "krylov.hpp"
 #include "dist.hpp"
+#include "gss4.hpp"

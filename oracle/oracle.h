@@ -20,6 +20,7 @@
  *                    form), 434-498 (Smooth / SmoothBack flag logic)
  *   transfers        src/base/coarsening/dof_map.cpp:636-709
  *   coarse solve     src/base/precond/amg_pc.cpp:843-928 (exact inverse on the free dofs)
+ *   GSS4             src/base/smoothers/gssmoother.cpp:407-583 (gss4.c)
  */
 #ifndef NGSAMG_ORACLE_H
 #define NGSAMG_ORACLE_H
@@ -105,6 +106,18 @@ void orc_set_threads(int n);
 /* multi-threaded CPU baseline only: replace the borrowed level arrays by private copies whose pages are first written
  * by the thread that streams them (NUMA placement); call after orc_set_threads / orc_create */
 int orc_first_touch(orc_handle* h);
+
+/* GSS4 (gss4.c): Gauss-Seidel on a subset of the rows; dinv_full = [n*bs*bs] inverted (replacement) diagonal blocks, read on
+ * the subset.  order (optional): visiting order of the compressed rows 0..m-1 (forward), NULL = ascending (reference). */
+typedef struct orc_gss4 orc_gss4;
+int orc_gss4_create(const orc_matrix* A, const uint8_t* subset, const double* dinv_full, orc_gss4** out);
+void orc_gss4_destroy(orc_gss4* g);
+int64_t orc_gss4_rows(const orc_gss4* g);
+int64_t orc_gss4_nnz(const orc_gss4* g);
+int orc_gss4_set_order(orc_gss4* g, const int32_t* order, int64_t len);
+int orc_gss4_smooth(const orc_gss4* g, int backwards, double* x, const double* b);          /* Smooth / SmoothBack       */
+int orc_gss4_smooth_res(const orc_gss4* g, int backwards, double* x, double* res);          /* SmoothRES / SmoothBackRES */
+int orc_gss4_mult_add(const orc_gss4* g, double s, const double* b, double* x);
 
 #ifdef __cplusplus
 }

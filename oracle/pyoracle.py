@@ -65,6 +65,17 @@ def lib():
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_threads.restype = None
     L.orc_first_touch.argtypes = [vp]
+    L.orc_gss4_create.argtypes = [C.POINTER(orc_matrix), c_u8p, c_f64p, C.POINTER(vp)]
+    L.orc_gss4_destroy.argtypes = [vp]
+    L.orc_gss4_destroy.restype = None
+    L.orc_gss4_rows.argtypes = [vp]
+    L.orc_gss4_rows.restype = C.c_int64
+    L.orc_gss4_nnz.argtypes = [vp]
+    L.orc_gss4_nnz.restype = C.c_int64
+    L.orc_gss4_set_order.argtypes = [vp, c_i32p, C.c_int64]
+    L.orc_gss4_smooth.argtypes = [vp, C.c_int, c_f64p, c_f64p]
+    L.orc_gss4_smooth_res.argtypes = [vp, C.c_int, c_f64p, c_f64p]
+    L.orc_gss4_mult_add.argtypes = [vp, C.c_double, c_f64p, c_f64p]
     _LIB = L
     return L
 
@@ -244,3 +255,46 @@ class Oracle:
         self._ck(lib().orc_pcg(self._h if precond else None, C.byref(_mat(self.levels[0].A)), _p(b, C.c_double),
                                _p(x, C.c_double), float(tol), int(maxit), _p(errs, C.c_double), C.byref(it)))
         return x, it.value, errs[: it.value + 1]
+
+
+class OracleGSS4:
+    """GSS4 restated on the CPU (oracle/gss4.c; reference gssmoother.cpp:407-583).  A: matrix object with n_rows, n_cols, br, bc,
+    rowptr, col, val; subset: [n] mask or None; dinv: [n*bs*bs] inverted (replacement) diagonal blocks.
+    order: visiting order of the compressed rows (e.g. colour-major, what the GPU does); None = ascending = the reference."""
+
+    def __init__(self, A, subset, dinv, order=None):
+        self._L = lib()
+        self._A = A
+        self._md = _mat(A)
+        self._sub = None if subset is None else np.ascontiguousarray(np.asarray(subset).astype(np.uint8))
+        self._dinv = np.ascontiguousarray(np.asarray(dinv, dtype=np.float64).ravel())
+        h = C.c_void_p()
+        if self._L.orc_gss4_create(C.byref(self._md), _p(self._sub, C.c_uint8), _p(self._dinv, C.c_double), C.byref(h)):
+            raise RuntimeError("orc_gss4_create failed")
+        self._h = h
+        if order is not None:
+            o = np.ascontiguousarray(np.asarray(order, dtype=np.int32))
+            if self._L.orc_gss4_set_order(self._h, _p(o, C.c_int32), o.size):
+                raise RuntimeError("orc_gss4_set_order: the order must list every compressed row once")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_gss4_destroy(self._h)
+            self._h = None
+
+    @property
+    def rows(self):
+        return int(self._L.orc_gss4_rows(self._h))
+
+    @property
+    def nnz(self):
+        return int(self._L.orc_gss4_nnz(self._h))
+
+    def smooth(self, x, b, back=False):
+        self._L.orc_gss4_smooth(self._h, int(back), _p(x, C.c_double), _p(np.ascontiguousarray(b), C.c_double))
+
+    def smooth_res(self, x, res, back=False):
+        self._L.orc_gss4_smooth_res(self._h, int(back), _p(x, C.c_double), _p(res, C.c_double))
+
+    def mult_add(self, s, b, x):
+        self._L.orc_gss4_mult_add(self._h, float(s), _p(np.ascontiguousarray(b), C.c_double), _p(x, C.c_double))

@@ -39,14 +39,14 @@ def test_struct_sizes_match_headers(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include "amgx.h"\n#include "amgh.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(amgx_matrix), sizeof(amgx_level_desc),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(amgx_matrix), sizeof(amgx_level_desc),'
         ' sizeof(amgx_hierarchy_desc), sizeof(amgh_matrix), sizeof(amgh_options), sizeof(amgh_level),'
-        ' sizeof(amgx_halo_desc), sizeof(amgx_dist_desc));return 0;}\n')
+        ' sizeof(amgx_halo_desc), sizeof(amgx_dist_desc), sizeof(amgx_gss4_desc));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     mirrors = [_lib.amgx_matrix, _lib.amgx_level_desc, _lib.amgx_hierarchy_desc, _lib.amgh_matrix,
-               _lib.amgh_options, _lib.amgh_level, _lib.amgx_halo_desc, _lib.amgx_dist_desc]
+               _lib.amgh_options, _lib.amgh_level, _lib.amgx_halo_desc, _lib.amgx_dist_desc, _lib.amgx_gss4_desc]
     assert sizes == [C.sizeof(m) for m in mirrors]
 
 
