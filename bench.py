@@ -65,14 +65,20 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
         rot = args.config == "cfg5"
         st = D.assemble_elasticity_owned(rank, pg, (nv, nv, nv), rotations=rot, mu=1.0, lam=0.5, dirichlet="left", jitter=0.2, seed=1)
         t1 = time.time()
+        torch.cuda.synchronize()
+        mem0 = torch.cuda.mem_get_info(device)[0]
         amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=20000, device=device, max_coarse_size=50, max_levels=10,
                                energy=1, regularize_cmats=0 if rot else 1)
     else:
         st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
         t1 = time.time()
+        torch.cuda.synchronize()
+        mem0 = torch.cuda.mem_get_info(device)[0]
         amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=50000, device=device, max_coarse_size=50, max_levels=10,
                                sm_type={"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother])
     bs0 = int(getattr(st, "bs", 1))
+    torch.cuda.synchronize()
+    hier_bytes = int(mem0 - torch.cuda.mem_get_info(device)[0])       # per rank: hierarchy copies, halo buffers, RCCL workspace
     free_s = np.repeat(st.free, bs0).astype(np.float64)
     t2 = time.time()
     lib = _lib.hip()
@@ -166,6 +172,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
                                       f"global_applies_per_s = steps / time",
                        "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(world * st.n * bs0)},
             "x_norm": float(xn.item()) ** 0.5,
+            "device_memory": {"per_rank_bytes": hier_bytes},
             "roofline": {"bound": "hbm", "kernel": k_name,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
@@ -325,8 +332,12 @@ def main():
     n_s = prob.n * bs0
     t2 = time.time()
     dev_sm = {"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother]
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.mem_get_info(device)[0]
     amg = DeviceAMGMatrix(H, sm_type=dev_sm, omega=0.9, mg_cycle="V", clev="inv", device=device,
                           use_graph=not args.no_graph)
+    torch.cuda.synchronize()
+    hier_bytes = int(mem0 - torch.cuda.mem_get_info(device)[0])       # device memory the uploaded hierarchy holds (all copies)
     t3 = time.time()
     if rank == 0:
         log(f"assembly {t1 - t0:.1f}s, hierarchy {t2 - t1:.1f}s, upload {t3 - t2:.1f}s")
@@ -594,6 +605,8 @@ def main():
                                           "(AMGX_NO_FOLD=1 runs the literal kernel sequence)") if folded else "literal",
                        "parallelism": "1 GPU"},
             "x_norm": x_norm,
+            "device_memory": {"hierarchy_bytes": hier_bytes, "level0_csr_bytes": int(matrix_bytes(lv0.A)),
+                              "ratio_to_level0_csr": round(hier_bytes / max(1, matrix_bytes(lv0.A)), 2)},
             "host_ptr_applies_per_s": host_rate,
             "roofline": roofline,
         }

@@ -33,7 +33,7 @@ def gs_block_rows(A):
     mx = int(np.diff(A.rowptr).max()) if A.n_rows else 0
     for G in (1, 2, 4, 8, 16):
         if mx <= 16 * G + (1 if G == 1 else 0):
-            threads = int(os.environ.get("AMGX_GSB_THREADS", "256" if G == 1 else "1024"))
+            threads = int(os.environ.get("AMGX_GSB_THREADS", "256") if G == 1 else os.environ.get("AMGX_GSB_THREADS_MULTI", "1024"))
             threads = threads if threads in (256, 512, 1024) else 1024
             return max(16, threads // G)
     return 0

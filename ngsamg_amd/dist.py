@@ -26,6 +26,7 @@ Communication is abstracted so that the same code runs (a) one rank per process 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -736,7 +737,9 @@ class DistributedAMG:
             raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi only")
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
-        self.fold = bool(fold) and sm_type == "jacobi" and not blocks
+        # (AMGX_NO_FOLD=1, the switch that makes the single-GPU handle run the literal kernel sequence, selects the literal
+        # stages here too: the decision is taken from the environment on every rank alike, before anything is built)
+        self.fold = bool(fold) and sm_type == "jacobi" and not blocks and not os.environ.get("AMGX_NO_FOLD")
         pinv = bool(opts.get("regularize_cmats", self.energy == 1 and all(_bs(s) == dim for s in states0)))
         for s in states0:
             interior_first(s)
