@@ -68,7 +68,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
         torch.cuda.synchronize()
         mem0 = torch.cuda.mem_get_info(device)[0]
         amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=20000, device=device, max_coarse_size=50, max_levels=10,
-                               energy=1, regularize_cmats=0 if rot else 1)
+                               energy=1, regularize_cmats=0 if rot else 1, sm_type="jacobi" if args.smoother == "jacobi" else "gs")
     else:
         st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
         t1 = time.time()
@@ -154,7 +154,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     if rank == 0:
         out = {
             "metric": ("V-cycle applies/sec (3D H1 Poisson ~10M DOF per GPU, %s V(1,1))" % ("Jacobi" if args.smoother == "jacobi" else "Gauss-Seidel")) if not elast
-                      else f"V-cycle applies/sec (3D elasticity {nv}^3 nodes per GPU, block size {bs0}, block-Jacobi V(1,1))",
+                      else f"V-cycle applies/sec (3D elasticity {nv}^3 nodes per GPU, block size {bs0}, block-{args.smoother} V(1,1))",
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "rccl_ranks": int(nr.value),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -162,7 +162,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
             "config": {"workload": (f"cfg4: " if args.config == "cfg4" else f"{args.config} per rank, weak scaling: " if elast else "cfg4-style weak scaling of cfg2: ") +
                                    f"global grid {tuple(pg[d] * nv for d in range(3))} = "
                                    f"{world} x {nv}^3 vertices, hashed jitter (seed 1), " +
-                                   (f"linear elasticity mu=1 lam=0.5, block size {bs0}, clamped left, block-jacobi" if elast else f"Dirichlet right|top, {args.smoother}") +
+                                   (f"linear elasticity mu=1 lam=0.5, block size {bs0}, clamped left, block-{args.smoother}" if elast else f"Dirichlet right|top, {args.smoother}") +
                                    " omega=0.9, V(1,1)",
                        "parallelism": f"{world} ranks (one process per GPU), partition {pg}, {amg.k} rank-partitioned levels "
                                       f"[interior | boundary] with halo pack kernels + ncclSend/ncclRecv on a communication stream behind the C ABI "
@@ -303,8 +303,8 @@ def main():
         os.environ["NGSAMG_PGRID"] = "box"
         if world == 1 and not force_dist:
             raise SystemExit("--config cfg4 is the rank-partitioned configuration: use --gpus 8 (or 2 / 4)")
-    if (world > 1 or force_dist) and args.config in ("cfg3", "cfg5") and args.smoother != "jacobi":
-        raise SystemExit("--config cfg3 / cfg5 on several ranks: block-Jacobi only (--smoother jacobi)")
+    if (world > 1 or force_dist) and args.config in ("cfg3", "cfg5") and args.smoother == "gs_mc":
+        raise SystemExit("--config cfg3 / cfg5 on several ranks: --smoother jacobi | gs (gs = hybrid block Gauss-Seidel in colour order)")
     if world > 1 or force_dist:
         run_distributed(args, torch, dist, world, rank, device, nv)
         return

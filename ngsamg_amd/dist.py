@@ -622,20 +622,29 @@ def _fold(states, omega):
 def _hybrid_gs_data(comm, states):
     """per level: inverse of the modified diagonal md = max(1, 0.51 (1 + ad)) d with ad_k = sum over the off-rank
     couplings |g_kj| / sqrt(d_k d_j)  (reference hybrid_smoother_utils.hpp:35-142), and a colouring of the
-    rank-local (owned x owned) graph for the multicolour sweep"""
+    rank-local (owned x owned) graph for the multicolour sweep.
+    Block levels (hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): ad_k(l) = sum_j sum_m |g_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)),
+    md_k = max(1, max_l 0.51 (1 + ad_k(l))) d_k, so the inverse is the (pseudo-)inverse of _dinv_ext divided by that factor."""
     lib = _lib.host()
-    diags = [np.asarray(s.A[:, :s.n].diagonal()) for s in states]
+    bs = _bs(states[0])
+    diags = [np.asarray(sp.csr_matrix(s.A)[:, :s.n * bs].diagonal()).reshape(s.n, bs) for s in states]
     gdiag = _exchange_ghost_values(comm, states, diags)
     for s, d, gd in zip(states, diags, gdiag):
-        G = sp.csr_matrix(s.A[:, s.n:])
-        free = s.free.astype(bool)
+        d, gd = d.reshape(-1), gd.reshape(-1)
+        A = sp.csr_matrix(s.A)
+        G = sp.csr_matrix(A[:, s.n * bs:])
+        free = np.repeat(s.free.astype(bool), bs)
         sd = np.sqrt(np.where(d > 0, d, 1.0))
         sg = np.sqrt(np.where(gd > 0, gd, 1.0))
-        ad = np.asarray(abs(G).multiply(1.0 / sd[:, None]).multiply(1.0 / sg[None, :]).sum(axis=1)).ravel() if G.shape[1] else np.zeros(s.n)
-        md = np.maximum(1.0, 0.51 * (1.0 + ad)) * d
-        dinv = np.where(free & (md != 0), 1.0 / np.where(md != 0, md, 1.0), 0.0)
-        s.dinv_gs_ext = np.concatenate([dinv, np.zeros(s.ghost_owner.size)])
-        Aoo = _mat(sp.csr_matrix(s.A[:, :s.n]))
+        ad = np.asarray(abs(G).multiply(1.0 / sd[:, None]).multiply(1.0 / sg[None, :]).sum(axis=1)).ravel() if G.shape[1] else np.zeros(s.n * bs)
+        if bs == 1:
+            md = np.maximum(1.0, 0.51 * (1.0 + ad)) * d
+            dinv = np.where(free & (md != 0), 1.0 / np.where(md != 0, md, 1.0), 0.0)
+        else:
+            fac = np.maximum(1.0, (0.51 * (1.0 + np.where(free, ad, 0.0))).reshape(s.n, bs).max(axis=1))
+            dinv = (s.dinv_ext[:s.n * bs * bs].reshape(s.n, bs * bs) / fac[:, None]).reshape(-1)
+        s.dinv_gs_ext = np.concatenate([dinv, np.zeros(s.ghost_owner.size * bs * bs)])
+        Aoo = _mat(sp.csr_matrix(A[:, :s.n * bs]), bs)
         color = np.zeros(s.n, dtype=np.int32)
         nc = C.c_int32()
         dsc = Aoo.desc()
@@ -733,8 +742,8 @@ class DistributedAMG:
         # coarse block size dim + nrot); block levels run block-Jacobi in the literal stage order
         self.energy = int(opts.get("energy", 0))
         blocks = any(_bs(s) > 1 for s in states0) or self.energy == 1
-        if blocks and sm_type != "jacobi":
-            raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi only")
+        if blocks and sm_type not in ("jacobi", "gs"):
+            raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi | gs")
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
         # (AMGX_NO_FOLD=1, the switch that makes the single-GPU handle run the literal kernel sequence, selects the literal
@@ -846,7 +855,7 @@ class DistributedAMG:
                 b["x"].append(ops.zeros(s.n * bsl))
                 b["r"].append(ops.zeros(s.n * bsl))
                 b.setdefault("xext", []).append(ops.zeros(next_) if (self.sm_type in ("gs", "hgs", "bgs") or self.fold) else None)
-                b.setdefault("b", []).append(ops.zeros(s.n) if self.sm_type in ("gs", "hgs", "bgs") else None)
+                b.setdefault("b", []).append(ops.zeros(s.n * bsl) if self.sm_type in ("gs", "hgs", "bgs") else None)
                 # ONE pack per halo: all peers' send lists concatenated; a peer's message is a slice of the buffer
                 peers = sorted(s.send)
                 allidx = _vexp(np.concatenate([s.send[q] for q in peers]), bsl) if peers else np.empty(0, dtype=np.int64)
@@ -982,7 +991,7 @@ class DistributedAMG:
                 ops.residual(l, b["xext"][l], bl, b["r"][l])
                 nxt = b["b"][l + 1] if l + 1 < k else b["bk"][:b["nk"]]
                 ops.restrict(l, b["r"][l], nxt)
-        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], self.counts)
+        self.comm.allgather_tensor([b["bk"] for b in self.buf], [b["bglob"] for b in self.buf], [c * self.buf[0]["bsk"] for c in self.counts])
         for i, ops in enumerate(self.ops):
             b = self.buf[i]
             ops.tail_apply(b["bglob"], b["xglob"])
@@ -990,8 +999,10 @@ class DistributedAMG:
             for i, ops in enumerate(self.ops):
                 s, b = self.dist_levels[l][i], self.buf[i]
                 r = s.rank
-                xc = b["xext"][l + 1][:self.dist_levels[l + 1][i].n] if l + 1 < k else b["xglob"][int(self.offs[r]):int(self.offs[r]) + b["nk"]]
-                xo = b["xext"][l][:s.n]
+                sc = self.dist_levels[l + 1][i] if l + 1 < k else None
+                xc = (b["xext"][l + 1][:sc.n * _bs(sc)] if l + 1 < k else
+                      b["xglob"][int(self.offs[r]) * b["bsk"]:int(self.offs[r]) * b["bsk"] + b["nk"]])
+                xo = b["xext"][l][:s.n * _bs(s)]
                 ops.prolong(l, xo, xc, xo)
             self._halo(l, "xext")
             for i, ops in enumerate(self.ops):
@@ -999,7 +1010,7 @@ class DistributedAMG:
                 bl = bs[i] if l == 0 else b["b"][l]
                 ops.gs_sweep(l, 1, b["xext"][l], bl, b["r"][l])
                 if l == 0:
-                    xs[i].copy_(b["xext"][0][:s.n])
+                    xs[i].copy_(b["xext"][0][:s.n * _bs(s)])
         return xs
 
     # ---- the same hierarchy as ONE global serial hierarchy (for the oracle / tests) -----------------------------
@@ -1044,7 +1055,7 @@ class DistributedAMG:
                       coords=None, color=np.full(n, -1, dtype=np.int32), n_colors=0, agg=None)
             if self.sm_type == "gs":
                 # hybrid GS as ONE serial smoother: every rank is a block, its rows are visited in its colour-major order
-                pg = [(s.rank, s.dinv_gs_ext[:s.n], s.color) for s in lv]
+                pg = [(s.rank, s.dinv_gs_ext[:s.n * bf * bf], s.color) for s in lv]
                 gg = sorted(comm.allgather(pg)[0], key=lambda t: t[0])
                 L.dinv = np.concatenate([t[1] for t in gg])
                 order, block = [], []

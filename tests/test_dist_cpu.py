@@ -228,6 +228,41 @@ def test_loopback_elasticity_matches_serial_oracle(R, box, rot):
     assert np.abs(A @ t.ravel()).max() < 1e-11
 
 
+@pytest.mark.parametrize("R,box,rot", [(2, (6, 5, 5), False), (4, (5, 5, 4), True), (8, (4, 4, 4), False)])
+def test_loopback_elasticity_hybrid_gs_matches_serial_hybrid_oracle(R, box, rot):
+    """rank-partitioned elasticity levels with the HYBRID (block-)Gauss-Seidel smoother: every rank sweeps its block rows,
+    off-rank couplings frozen, block diagonal modified by max_l 0.51 (1 + ad(l)) (hybrid_smoother_utils.hpp:86-141) -- the
+    convergent smoother for the rotational problem (cfg 5), where block-Jacobi stagnates"""
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_elasticity_owned(r, pg, box, rotations=rot) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=10, backend=cpu_backend(sm_type="gs"), max_coarse_size=5, energy=1,
+                           regularize_cmats=0 if rot else 1, sm_type="gs", gs_stage_min_rows=20)
+    assert amg.k >= 1
+    bs0 = states[0].bs
+    # the modified diagonal differs from the plain one exactly where off-rank couplings are strong
+    s0 = amg.dist_levels[0][0]
+    d_plain = s0.dinv_ext[:s0.n * bs0 * bs0].reshape(s0.n, -1)
+    d_mod = s0.dinv_gs_ext[:s0.n * bs0 * bs0].reshape(s0.n, -1)
+    ratio = np.abs(d_plain).sum(axis=1) / np.maximum(np.abs(d_mod).sum(axis=1), 1e-300)
+    fr = s0.free.astype(bool)
+    assert np.all(ratio[fr] >= 1.0 - 1e-12) and ratio[fr].max() > 1.0 + 1e-6
+    assert np.allclose(ratio[:s0.n_interior][fr[:s0.n_interior]], 1.0)       # interior rows have no off-rank couplings
+    rng = np.random.default_rng(0)
+    bs = [torch.from_numpy(rng.standard_normal(s.n * bs0) * np.repeat(s.free, bs0)) for s in states]
+    xs = [torch.zeros(s.n * bs0, dtype=torch.float64) for s in states]
+    amg.Mult(bs, xs)
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg)).apply(np.concatenate([b.numpy() for b in bs]))
+    got = np.concatenate([x.numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-11 * np.linalg.norm(ref)
+    # and it is a convergent preconditioner: PCG on the assembled operator
+    A = glv[0].A
+    bg = np.concatenate([b.numpy() for b in bs])
+    its = Oracle(glv, sm_type=oracle_sm_types(amg)).pcg(bg, tol=1e-8, maxit=60)[1]
+    assert its < 40
+
+
 @pytest.mark.parametrize("R,box,dim,dmin,B", [(2, (12, 12, 12), 3, 100, 64), (4, (10, 10, 10), 3, 50, 32), (8, (8, 8, 8), 3, 20, 64), (4, (24, 24), 2, 50, 128),
                                               (2, (30, 30, 30), 3, 10000, 256)])          # last: block-hybrid levels in the replicated tail too
 def test_loopback_block_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin, B):

@@ -372,6 +372,41 @@ def test_loopback_device_elasticity_matches_serial_oracle(R, box, rot):
     assert np.linalg.norm(got - ref) <= 1e-11 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("R,box,rot,stage_min", [(2, (8, 7, 7), False, 50), (4, (6, 6, 5), True, 50), (2, (9, 8, 8), True, 10 ** 9)])
+def test_loopback_device_elasticity_hybrid_gs(R, box, rot, stage_min):
+    """rank-partitioned elasticity levels with the hybrid block Gauss-Seidel smoother on the device: colour-range stages
+    (local half / boundary / local half) around the halo exchange of x, block diagonal modified as in
+    hybrid_smoother_utils.hpp:86-141; vs the oracle's serial hybrid GS (blocks = ranks)"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_sm_types
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_elasticity_owned(r, pg, box, rotations=rot) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=10, device=0, max_coarse_size=5, energy=1, regularize_cmats=0 if rot else 1,
+                           sm_type="gs", gs_stage_min_rows=stage_min)
+    bs0 = states[0].bs
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n * bs0) * np.repeat(s.free, bs0) for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n * bs0,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg))
+    ref = orc.apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    assert orc.pcg(np.concatenate(bh), tol=1e-8, maxit=60)[1] < 45
+
+
+def test_rccl_world_size_one_elasticity_hybrid_gs():
+    """the same through a real RCCL communicator (world size 1, child process)"""
+    _run_check("--world", "1", "--box", "10", "--elast", "6", "--sm", "gs", "--dmin", "50")
+
+
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (8, (12, 12, 12), 3, 100), (4, (48, 48), 2, 300),
                                             (2, (40, 40, 40), 3, 20000)])          # last: the replicated tail has block-hybrid levels too
 def test_loopback_device_block_hybrid_gs(R, box, dim, dmin):
