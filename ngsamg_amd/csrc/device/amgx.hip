@@ -150,6 +150,9 @@ struct DevGS {                          // colour-major data for multicolour Gau
   // block, preferred: colour-major BSELL copy (bgs_bsell_color_kernel); color_slice_ptr / rowid as in the scalar form
   DevMatrix bcopy;
   bool bsell_ok = false;
+  // block levels, pre-smoothing from x = 0: the couplings to lower / to higher colours only (as `lower` / `upper` above)
+  DevMatrix blower, bupper;
+  bool bsplit = false;
 };
 
 struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_kernel): blocks of B consecutive rows
@@ -877,7 +880,7 @@ struct Handle {
         const int s0 = g.color_slice_ptr[c], s1 = g.color_slice_ptr[c + 1];
         if (s1 == s0) continue;
         const int grid = (s1 - s0 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        const BSellMat BM = g.bcopy.bsell.view();
+        const BSellMat BM = (lower_only && g.bsplit) ? g.blower.bsell.view() : g.bcopy.bsell.view();
         if (L.bs == 6) hipLaunchKernelGGL((bgs_bsell_color_kernel<6>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
         else if (L.bs == 3) hipLaunchKernelGGL((bgs_bsell_color_kernel<3>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
         else hipLaunchKernelGGL((bgs_bsell_color_kernel<2>), dim3(grid), dim3(BLOCK), 0, stream, s0, s1, BM, g.rowid.p, L.dinv.p, b, x);
@@ -1080,6 +1083,19 @@ struct Handle {
         default: LAUNCH_UR(16); break;
       }
 #undef LAUNCH_UR
+      HIPCHK(hipGetLastError());
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gs.bsplit && L.bs > 1) {
+      // block levels, same identity: forward sweep over the lower-colour couplings, then r_B = -(U x)_B in one launch
+      zero(x, L.len());
+      zero(r, L.len());
+      gs_sweep(L, 0, x, b, true);
+      const DevGS& g = L.gs;
+      const int ns = g.bupper.n_slices;
+      const int grid = (ns + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+      const BSellMat UM = g.bupper.bsell.view();
+      if (L.bs == 6) hipLaunchKernelGGL((bgs_bsell_upper_residual_kernel<6>), dim3(grid), dim3(BLOCK), 0, stream, ns, UM, g.rowid.p, x, r);
+      else if (L.bs == 3) hipLaunchKernelGGL((bgs_bsell_upper_residual_kernel<3>), dim3(grid), dim3(BLOCK), 0, stream, ns, UM, g.rowid.p, x, r);
+      else hipLaunchKernelGGL((bgs_bsell_upper_residual_kernel<2>), dim3(grid), dim3(BLOCK), 0, stream, ns, UM, g.rowid.p, x, r);
       HIPCHK(hipGetLastError());
     } else if (plain(L) && L.sm_type == AMGX_SM_GS) {
       zero(x, L.len());
@@ -1410,6 +1426,48 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
         for (int c = 0; c <= nc; ++c) g.color_slice_ptr[c] = (int)(cstart[c] / RB);
         g.rowid.upload(prow);
         g.bsell_ok = true;
+        // split copies (see the scalar case): need x_B = Dinv_B (b - L x)_B to imply (b - L x - D x)_B = 0, i.e. Dinv_B = A_BB^-1
+        bool plain_diag = d.dinv != nullptr && d.A.n_rows == d.A.n_cols && !std::getenv("AMGX_NO_BGS_SPLIT");
+        const int bb = bs * bs;
+        for (int64_t i = 0; i < n && plain_diag; ++i) {
+          if (d.color[i] < 0) continue;
+          const double* aii = nullptr;
+          for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) if (d.A.col[k] == i) aii = d.A.val + k * bb;
+          if (!aii) { plain_diag = false; break; }
+          const double* di = d.dinv + i * bb;
+          for (int r = 0; r < bs && plain_diag; ++r)
+            for (int c = 0; c < bs; ++c) {
+              double v = 0.0;
+              for (int q = 0; q < bs; ++q) v += di[r * bs + q] * aii[q * bs + c];
+              if (!(std::fabs(v - (r == c ? 1.0 : 0.0)) < 1e-10)) { plain_diag = false; break; }
+            }
+        }
+        if (plain_diag) {
+          bool ok = true;
+          for (int part = 0; part < 2 && ok; ++part) {
+            std::vector<int64_t> rp(n + 1, 0);
+            std::vector<int32_t> cc;
+            std::vector<double> vv;
+            for (int64_t i = 0; i < n; ++i) {
+              const int ci = d.color[i];
+              if (ci >= 0)
+                for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+                  const int cj = d.color[d.A.col[k]];
+                  if (cj < 0) continue;
+                  if ((part == 0 && cj < ci) || (part == 1 && cj > ci)) {
+                    cc.push_back(d.A.col[k]);
+                    vv.insert(vv.end(), d.A.val + k * bb, d.A.val + (k + 1) * bb);
+                  }
+                }
+              rp[i + 1] = (int64_t)cc.size();
+            }
+            amgx_matrix F = d.A;
+            F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+            DevMatrix& T = part == 0 ? g.blower : g.bupper;
+            ok = build_bsell(F, T, 1e9, prow.data(), (int64_t)prow.size()) && T.n_slices == g.bcopy.n_slices;
+          }
+          g.bsplit = ok;
+        }
       }
     }
   }

@@ -839,6 +839,39 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_color_kernel(int slice_begin,
   if (active) x[i] += u;
 }
 
+// r_B = -(U x)_B on the colour-major block rows after a forward sweep from x = 0 (see gs_upper_residual_kernel); M holds
+// the couplings to higher colours only, one launch over all colours
+template <int BS>
+__global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_slices, BSellMat M, const int32_t* __restrict__ rowid,
+                                                                         const double* __restrict__ x, double* __restrict__ r) {
+  constexpr int RB = WAVE / BS;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  if (s >= n_slices) return;
+  const int rbl = lane / BS < RB ? lane / BS : RB - 1;
+  const int rr = lane % BS;
+  const int brow = rowid[(int64_t)s * RB + rbl];
+  const bool active = lane < RB * BS && brow >= 0;
+  const int64_t k0 = M.slice_ptr[s];
+  const int w = (int)(M.slice_ptr[s + 1] - k0);
+  const double* __restrict__ vb = M.val + k0 * (BS * WAVE);
+  const int32_t* __restrict__ cb = M.col + k0 * RB;
+  double acc = 0.0;
+#pragma unroll 2
+  for (int k = 0; k < w; ++k) {
+    const int c = cb[k * RB + rbl];
+    const double* xv = x + (int64_t)c * BS;
+    const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) {
+      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+      acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+    }
+    if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+  }
+  if (active) r[(int64_t)brow * BS + rr] = -acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Column-blocked restriction  b_c = P^T r  for large scalar levels (reference ProlMap::TransferF2C,
 // dof_map.cpp:636-654).  The gather form over P^T touches ~40 different cache lines of r per coarse row and is

@@ -94,14 +94,17 @@ def test_hgs_iterations_within_15_percent_of_sequential_gs():
 
 
 @pytest.mark.parametrize("rot", [False, True])
-@pytest.mark.parametrize("cycle", ["V", "W"])
-def test_block_gs_on_colour_major_bsell(rot, cycle, monkeypatch):
+@pytest.mark.parametrize("cycle,split", [("V", True), ("W", True), ("V", False)])
+def test_block_gs_on_colour_major_bsell(rot, cycle, split, monkeypatch):
     """point-block Gauss-Seidel of the elasticity levels through bgs_bsell_color_kernel (colour-major BSELL copy; big
-    levels only in production, forced onto the small test levels here) == the oracle's GS in colour order"""
+    levels only in production, forced onto the small test levels here) == the oracle's GS in colour order.  split: the
+    pre-smoothing from zero reads the lower-colour couplings for the sweep and the higher-colour ones for the residual"""
     from tests.problems import elasticity_case
     from ngsamg_amd.device import DeviceAMGMatrix
     from oracle.pyoracle import Oracle
     monkeypatch.setenv("AMGX_BGS_BSELL_MIN", "1")
+    if not split:
+        monkeypatch.setenv("AMGX_NO_BGS_SPLIT", "1")
     p, H = elasticity_case((9, 8, 7), rot, 10)
     dev = DeviceAMGMatrix(H, sm_type="gs", mg_cycle=cycle, device=0)
     rng = np.random.default_rng(3)
