@@ -888,12 +888,13 @@ struct Handle {
         const int r0 = g.color_row_ptr[c], r1 = g.color_row_ptr[c + 1];
         if (r1 == r0) continue;
         const double avg = L.A.n_rows ? (double)L.A.nnz / (double)L.A.n_rows : 0.0;
-        const int W = avg >= 48.0 ? 4 : (avg >= 20.0 ? 2 : 1);
+        int W = avg >= 48.0 ? 4 : (avg >= 20.0 ? 2 : 1);
+        if (avg >= 32.0 && r1 - r0 <= 4096) W = 8;      // short colours of long rows: latency, not bandwidth -- spread the row further
         const int rpw = WAVE / (L.bs * W);
         const int64_t waves = ((int64_t)(r1 - r0) + rpw - 1) / rpw;
         const int grid = (int)std::max<int64_t>(1, (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 #define LAUNCH_GS(BS, WW) hipLaunchKernelGGL((bgs_color_kernel<BS, WW>), dim3(grid), dim3(BLOCK), 0, stream, r0, r1, g.rowlist.p, L.A.rowptr.p, L.A.col.p, L.A.val.p, L.dinv.p, b, x)
-#define LAUNCH_GSW(BS) { if (W == 4) LAUNCH_GS(BS, 4); else if (W == 2) LAUNCH_GS(BS, 2); else LAUNCH_GS(BS, 1); }
+#define LAUNCH_GSW(BS) { if (W == 8) LAUNCH_GS(BS, 8); else if (W == 4) LAUNCH_GS(BS, 4); else if (W == 2) LAUNCH_GS(BS, 2); else LAUNCH_GS(BS, 1); }
         switch (L.bs) {
           case 2: LAUNCH_GSW(2); break;
           case 3: LAUNCH_GSW(3); break;

@@ -47,15 +47,7 @@ __global__ __launch_bounds__(BLOCK) void gss4_rows_kernel(int q0, int q1, const 
   const int ci = active ? (list ? list[q] : (int)q) : 0;
   double acc = 0.0;
   if (MODE <= 1) {
-    if (active) {
-      const int e = rowptr[ci + 1];
-      for (int k = rowptr[ci] + g; k < e; k += W) {
-        const double* __restrict__ a = vals + (int64_t)k * (BS * BS) + r * BS;
-        const double* xv = xg + (int64_t)cols[k] * BS;
-#pragma unroll
-        for (int c = 0; c < BS; ++c) acc += a[c] * xv[c];
-      }
-    }
+    if (active) acc = bcsr_row_dot<BS, BS, W, (BS >= 6 ? 2 : 4)>(rowptr[ci] + g, rowptr[ci + 1], cols, vals, r, xg);
 #pragma unroll
     for (int o = W >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o * BS, WAVE);
   }

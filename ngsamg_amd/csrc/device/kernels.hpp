@@ -504,6 +504,48 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n
   if (active) y[i] = out;
 }
 
+// scalar row r of a block row in CSR storage (BR x BC blocks) times x, blocks k0, k0 + W, ... < e.  The small levels these
+// kernels serve are pure latency: a rolled loop waits for the column index and then for the gathered x of every block (two
+// dependent round trips per step, 12 steps for a 50-block row at W = 4 = the 15 us such a launch took); here the indices,
+// the matrix rows and the gathers of UN blocks are requested together.
+// UN: same-box A/B at cfg 5 / cfg 3 (6x6 blocks): the Gauss-Seidel colour kernels are fastest with 2 blocks in flight
+// (143 vs 136-140 applications/s with 1 or 4), the transfer / residual kernels with 4 (235 vs 226 with 1 or 2).
+template <int BR, int BC, int W, int UN>
+__device__ __forceinline__ double bcsr_row_dot(int k0, int e, const int32_t* __restrict__ cols, const double* __restrict__ vals, int r,
+                                               const double* x) {
+  double acc = 0.0;
+  int k = k0;
+  for (; k + (UN - 1) * W < e; k += UN * W) {
+    int cc[UN];
+    double av[UN][BC], xv[UN][BC];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cc[u] = cols[k + u * W];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const double* __restrict__ a = vals + (int64_t)(k + u * W) * (BR * BC) + r * BC;
+#pragma unroll
+      for (int c = 0; c < BC; ++c) av[u][c] = a[c];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const double* xp = x + (int64_t)cc[u] * BC;
+#pragma unroll
+      for (int c = 0; c < BC; ++c) xv[u][c] = xp[c];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int c = 0; c < BC; ++c) acc += av[u][c] * xv[u][c];
+  }
+  for (; k < e; k += W) {
+    const double* __restrict__ a = vals + (int64_t)k * (BR * BC) + r * BC;
+    const double* xp = x + (int64_t)cols[k] * BC;
+#pragma unroll
+    for (int c = 0; c < BC; ++c) acc += a[c] * xp[c];
+  }
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Block CSR, ROW-PER-LANE inside the block (BR x BC blocks, BR >= 2): lane (g, r) of a block row's lane group owns
 // scalar row r and the blocks k = g, g+W, ...; it reads its BC contiguous values of each block, so the BR lanes of a
@@ -524,23 +566,7 @@ __global__ __launch_bounds__(BLOCK) void bcsr_rowlane_kernel(int64_t n_rows, con
   const int64_t row = wave * RPW + rloc;
   const bool active = rloc < RPW && row < n_rows;
   double acc = 0.0;
-  if (active) {
-    const int e = rowptr[row + 1];
-    for (int k = rowptr[row] + g; k < e; k += W) {
-      const double* __restrict__ a = vals + (int64_t)k * (BR * BC) + r * BC;
-      const double* __restrict__ xv = x + (int64_t)cols[k] * BC;
-      if ((BC & 1) == 0) {
-        // 16-byte loads: k*BR*BC*8 and r*BC*8 are multiples of 16 for even BC
-        const double2* __restrict__ a2 = reinterpret_cast<const double2*>(a);
-        const double2* __restrict__ x2 = reinterpret_cast<const double2*>(xv);
-#pragma unroll
-        for (int c = 0; c < BC / 2; ++c) { const double2 av = a2[c], xx = x2[c]; acc += av.x * xx.x + av.y * xx.y; }
-      } else {
-#pragma unroll
-        for (int c = 0; c < BC; ++c) acc += a[c] * xv[c];
-      }
-    }
-  }
+  if (active) acc = bcsr_row_dot<BR, BC, W, 4>(rowptr[row] + g, rowptr[row + 1], cols, vals, r, x);
 #pragma unroll
   for (int o = W >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o * BR, WAVE);
   // lanes with g == 0 now hold (A x)_r of their block row
@@ -766,15 +792,7 @@ __global__ __launch_bounds__(BLOCK) void bgs_color_kernel(int list_begin, int li
   const bool active = rloc < RPW && q < list_end;
   const int row = active ? rowlist[q] : 0;
   double acc = 0.0;
-  if (active) {
-    const int e = rowptr[row + 1];
-    for (int k = rowptr[row] + g; k < e; k += W) {
-      const double* __restrict__ a = vals + (int64_t)k * (BS * BS) + r * BS;
-      const double* xv = x + (int64_t)cols[k] * BS;
-#pragma unroll
-      for (int c = 0; c < BS; ++c) acc += a[c] * xv[c];
-    }
-  }
+  if (active) acc = bcsr_row_dot<BS, BS, W, (BS >= 6 ? 2 : 4)>(rowptr[row] + g, rowptr[row + 1], cols, vals, r, x);
 #pragma unroll
   for (int o = W >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o * BS, WAVE);
   const int64_t i = (int64_t)row * BS + r;

@@ -113,3 +113,30 @@ def test_block_gs_on_colour_major_bsell(rot, cycle, split, monkeypatch):
         x = dev.apply(b)
     ref = Oracle(H.levels, sm_type="gs_mc", cycle=cycle).apply(b)
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_in_cycle_kernel_probes():
+    """amgx_time_op op 8 / op 9: HIP events around the dominant kernel while whole cycles run (what bench.py reports as
+    roofline.kernel_ms); the probe must not change the result of later applications"""
+    import torch
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from ngsamg_amd._lib import NgsAMGError
+    p, H = _case((40, 40, 40), mcs=30)
+    rng = np.random.default_rng(1)
+    b = torch.from_numpy(rng.standard_normal(p.n) * p.free).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for sm, op, other in (("hgs", 9, 8), ("jacobi", 8, 9)):
+            dev = DeviceAMGMatrix(H, sm_type=sm, device=0)
+            x0 = torch.empty_like(b); dev.Mult(b, x0)
+            s.synchronize()
+            try:
+                t = dev.time_op(0, op, reps=3)
+                assert 0.0 < t < 50.0
+            except NgsAMGError as e:            # (the fused Jacobi kernel exists on one-thread-per-row levels only: >= 2^20 rows)
+                assert sm == "jacobi" and "no fused" in str(e)
+            with pytest.raises(NgsAMGError):
+                dev.time_op(0, other, reps=2)
+            x1 = torch.empty_like(b); dev.Mult(b, x1)
+            s.synchronize()
+            assert torch.equal(x0, x1)
