@@ -218,10 +218,9 @@ __device__ __forceinline__ void sell_tail(int rem, const SellRegs<K>* last, int 
   } else if constexpr (REM > 1) sell_tail<K, REM - 1, C16>(rem, last, p_last, vb, cpv, cb, r0, p, lane, x, acc0, acc1, xd);
 }
 
-template <bool C16>
+template <bool C16, int K = SELL_BATCH>
 __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb, const void* __restrict__ cpv, const int32_t* __restrict__ cb,
                                            int r0, int lane, const double* __restrict__ x, double& acc0, double& acc1, double* xd) {
-  constexpr int K = SELL_BATCH;
   const int nfull = np / K, rem = np - nfull * K;
 #if SELL_PIPELINE
   if (nfull > 0) {
@@ -250,6 +249,8 @@ __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb
 // xd (optional, 2 doubles): receives the x value gathered for entry 0 of this lane's row and the matrix value of that
 // entry (meaningful when M.diag_first)
 // (xd is always a real local of the caller: a conditionally-null pointer kept the pair in scratch memory)
+// K = pair-steps per batch of the software pipeline (see SELL_BATCH)
+template <int K = SELL_BATCH>
 __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd) {
   const int64_t sp0 = M.slice_ptr[s];
   const int64_t base = sp0 & ~(int64_t)63;
@@ -268,8 +269,8 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
     vs = ld_nt(vb + o);
     cs = c16 ? (int)ld_nt(M.col16 + base + o) : ld_nt(M.col32 + base + o);
   }
-  if (c16) sell_pairs<true>(np, vb, M.col16 + base, cb, r0, lane, x, acc0, acc1, xd);
-  else sell_pairs<false>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
+  if (c16) sell_pairs<true, K>(np, vb, M.col16 + base, cb, r0, lane, x, acc0, acc1, xd);
+  else sell_pairs<false, K>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
   if (w & 1) {
     const double x0 = x[c16 ? r0 + cb[w - 1] + cs : cs];
     if (np == 0) { xd[0] = x0; xd[1] = vs; }
@@ -277,9 +278,10 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
   }
   return acc0 + acc1;
 }
+template <int K = SELL_BATCH>
 __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x) {
   double xd[2];
-  return sell_row_dot(M, s, lane, row, x, xd);
+  return sell_row_dot<K>(M, s, lane, row, x, xd);
 }
 
 // SELL-64-pair, scalar, G lanes per row (G = 1: one thread per row), one wave per slice of 64/G rows
@@ -299,7 +301,12 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int sl
   const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
   EpOps ops{0.0, 0.0, 0.0};
   if (hoist && writer) ops = ep_operands<EP>(row, ep, use_xd, wdiag);
-  double acc = sell_row_dot(M, s, lane, row, x, xd);
+  // levels with several lanes per row are small (latency rather than bandwidth), but deeper batches do not pay there
+  // either: same-box A/B of the whole cycle, batch 2 / 3 / 4 / 6 on those levels: 0.692 / 0.693-0.716 / 0.687-0.692 / 0.736-0.761 ms
+#ifndef SELL_BATCH_MULTI
+#define SELL_BATCH_MULTI SELL_BATCH
+#endif
+  double acc = sell_row_dot<(G > 1 ? SELL_BATCH_MULTI : SELL_BATCH)>(M, s, lane, row, x, xd);
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
   if (writer) {
