@@ -160,6 +160,13 @@ def from_shared_layout(comm, locs):
         st = RankState()
         st.rank, st.n = L.rank, n_own[i]
         st.A = Aown
+        # the hybrid smoother's off-rank weight sums |partial g_kj| over the ranks (CalcHybridSmootherRDG iterates the local G
+        # of every rank and all-reduces, hybrid_smoother_utils.hpp:74-103), which exceeds |assembled g_kj| where partial sums
+        # of opposite sign meet: keep the sum of the absolute partial values of the ghost columns for _hybrid_gs_data
+        if gkeys.shape[0]:
+            Gabs = sp.coo_matrix((np.abs(va[gh]), (tr[gh], col[gh] - n_own[i])), shape=(n_own[i], gkeys.shape[0])).tocsr()
+            Gabs.sort_indices()
+            st.G_abs_partial = Gabs
         mine = np.nonzero(master[i] == L.rank)[0]
         st.free = np.ascontiguousarray(L.free[mine])
         st.coords = None if L.coords is None else np.ascontiguousarray(L.coords[mine])

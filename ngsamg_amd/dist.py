@@ -389,6 +389,8 @@ def interior_first(s):
     A2 = sp.csr_matrix((A2.data, colmap[A2.indices], A2.indptr), shape=A.shape)
     A2.sort_indices()
     s.A = A2
+    if getattr(s, "G_abs_partial", None) is not None:      # rows follow, the ghost columns keep their order
+        s.G_abs_partial = sp.csr_matrix(sp.csr_matrix(s.G_abs_partial)[_vexp(perm, bs)])
     s.free = np.ascontiguousarray(s.free[perm])
     if getattr(s, "coords", None) is not None:
         s.coords = np.ascontiguousarray(s.coords[perm])
@@ -632,11 +634,14 @@ def _hybrid_gs_data(comm, states):
     for s, d, gd in zip(states, diags, gdiag):
         d, gd = d.reshape(-1), gd.reshape(-1)
         A = sp.csr_matrix(s.A)
-        G = sp.csr_matrix(A[:, s.n * bs:])
+        G = abs(sp.csr_matrix(A[:, s.n * bs:]))
+        Gp = getattr(s, "G_abs_partial", None)       # level 0 of a bridged hierarchy: sum over the ranks of |partial g| (bridge.py)
+        if Gp is not None and Gp.shape == G.shape:
+            G = sp.csr_matrix(Gp)
         free = np.repeat(s.free.astype(bool), bs)
         sd = np.sqrt(np.where(d > 0, d, 1.0))
         sg = np.sqrt(np.where(gd > 0, gd, 1.0))
-        ad = np.asarray(abs(G).multiply(1.0 / sd[:, None]).multiply(1.0 / sg[None, :]).sum(axis=1)).ravel() if G.shape[1] else np.zeros(s.n * bs)
+        ad = np.asarray(G.multiply(1.0 / sd[:, None]).multiply(1.0 / sg[None, :]).sum(axis=1)).ravel() if G.shape[1] else np.zeros(s.n * bs)
         if bs == 1:
             md = np.maximum(1.0, 0.51 * (1.0 + ad)) * d
             dinv = np.where(free & (md != 0), 1.0 / np.where(md != 0, md, 1.0), 0.0)

@@ -79,3 +79,42 @@ def test_bridged_partition_runs_the_distributed_cycle():
     ref = Oracle(amg.global_levels(), sm_type="jacobi").apply(np.concatenate([b.numpy() for b in bs]))
     got = np.concatenate([x.numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+def test_hybrid_smoother_weight_uses_partial_sums_on_the_bridged_level():
+    """hybrid_smoother_utils.hpp:74-103: the off-rank weight ad_k adds |g_kj| of the LOCAL matrices of all ranks, i.e. the
+    sum over the ranks of the absolute partial values -- not |assembled g_kj|.  The bridge keeps that sum for level 0."""
+    from tests.dist_cpu_backend import cpu_backend as be
+    comm, locs, gids, states, vmaps = _setup((2, 2, 1), (9, 9, 4))
+    # ground truth from the reference's layout: for every owned dof k and every column owned elsewhere, sum_r |A_r(k, j)|
+    gp = [s.G_abs_partial.copy() for s in states]
+    tot_abs = sum(float(g.sum()) for g in gp)
+    tot_asm = sum(float(abs(sp.csr_matrix(s.A)[:, s.n:]).sum()) for s in states)
+    assert tot_abs >= tot_asm - 1e-12 and tot_abs > 0
+    # independent count on the raw partial matrices: entries (k, j) of rank r with k not interior to r ...
+    R = len(locs)
+    master = [np.array([min([L.rank] + [int(q) for q in p]) for p in L.dist_procs]) for L in locs]
+    raw = 0.0
+    for L, m in zip(locs, master):
+        A = sp.coo_matrix(L.A)
+        raw += float(np.abs(A.data[m[A.row] != m[A.col]]).sum())          # couplings whose ends have different owners
+    assert abs(raw - tot_abs) <= 1e-10 * raw
+    # a partition whose partial sums cancel: flip the sign pattern of one rank's interface couplings artificially
+    locs2 = [B.SharedLocal(L.rank, L.A.copy(), L.dist_procs, L.free, L.coords, getattr(L, "ex_key", None)) for L in locs]
+    A0 = sp.lil_matrix(locs2[0].A)
+    sh = np.array([len(p) > 0 for p in locs2[0].dist_procs])
+    idx = np.flatnonzero(sh)
+    for k in idx[:6]:
+        for j in idx[:6]:
+            if k != j and A0[k, j] != 0:
+                A0[k, j] = -3.0 * A0[k, j]
+    locs2[0].A = sp.csr_matrix(A0)
+    st2, _ = B.from_shared_layout(comm, locs2)
+    d_abs = sum(float(s.G_abs_partial.sum()) for s in st2)
+    d_asm = sum(float(abs(sp.csr_matrix(s.A)[:, s.n:]).sum()) for s in st2)
+    assert d_abs >= d_asm
+    # and the distributed hybrid GS picks it up on level 0 (and only there)
+    amg = D.DistributedAMG(comm, st2, dim=3, dist_min_rows=20, backend=be(sm_type="gs"), max_coarse_size=10, sm_type="gs")
+    s0 = amg.dist_levels[0][0]
+    assert getattr(s0, "G_abs_partial", None) is not None and s0.G_abs_partial.shape == (s0.n, s0.ghost_owner.size)
+    assert getattr(amg.dist_levels[1][0], "G_abs_partial", None) is None
