@@ -250,11 +250,11 @@ __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb
 // entry (meaningful when M.diag_first)
 // (xd is always a real local of the caller: a conditionally-null pointer kept the pair in scratch memory)
 // K = pair-steps per batch of the software pipeline (see SELL_BATCH)
+// (sp0, sp1 = slice_ptr[s], slice_ptr[s + 1]: callers with a long prologue load them first, see sell_pre_restrict_kernel)
 template <int K = SELL_BATCH>
-__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd) {
-  const int64_t sp0 = M.slice_ptr[s];
+__device__ __forceinline__ double sell_row_dot_sp(const SellMat& M, int64_t sp0, int64_t sp1, int lane, int row, const double* x, double* xd) {
   const int64_t base = sp0 & ~(int64_t)63;
-  const int w = (int)(((M.slice_ptr[s + 1] & ~(int64_t)63) - base) >> 6);
+  const int w = (int)(((sp1 & ~(int64_t)63) - base) >> 6);
   const int np = w >> 1;
   const double* __restrict__ vb = M.val + base;
   double acc0 = 0.0, acc1 = 0.0;
@@ -277,6 +277,10 @@ __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane
     acc0 += vs * x0;
   }
   return acc0 + acc1;
+}
+template <int K = SELL_BATCH>
+__device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x, double* xd) {
+  return sell_row_dot_sp<K>(M, M.slice_ptr[s], M.slice_ptr[s + 1], lane, row, x, xd);
 }
 template <int K = SELL_BATCH>
 __device__ __forceinline__ double sell_row_dot(const SellMat& M, int s, int lane, int row, const double* x) {
@@ -961,6 +965,10 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   const int row = s * WAVE + lane;
   // the chunk-local restriction data of this thread is requested FIRST, so that it arrives while the row product
   // streams A'; the epilogue after the barriers then touches LDS only
+  // (nothing in this prologue is CONSUMED before the row product: a subtraction on a freshly loaded slot pointer here made
+  // every wave wait for all of its restriction data -- two full memory round trips -- before it requested a byte of A')
+  const bool has_slice = s < n_slices;
+  const int64_t sp0 = has_slice ? M.slice_ptr[s] : 0, sp1 = has_slice ? M.slice_ptr[s + 1] : 0;
   const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
   const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
   double wq[FUSED_MAX_ENTRIES / FUSED_BLOCK];
@@ -974,15 +982,19 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   const int myslot = s0 + threadIdx.x;
   // dest (optional, AMGX_RSUM_SORT=1): the partials of one coarse row stored next to each other, so that
   // restrict_sum_kernel streams them -- scattered stores here instead of scattered loads there; measured slower overall
-  const int mydest = (dest && myslot < s1) ? dest[myslot] : myslot;
-  const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
-  const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
+  int mydest = myslot, pa_raw = 0, pb_raw = 0;
+  if (myslot < s1) {
+    if (dest) mydest = dest[myslot];
+    pa_raw = slot_ptr[myslot];
+    pb_raw = slot_ptr[myslot + 1];
+  }
   double r = 0.0;
   if (MODE == 1) {
     if (s < n_slices) {
       double ci = 0.0, xi = 0.0;
       if (row < n_rows) { ci = dinv[row]; xi = b[row]; }
-      const double acc = sell_row_dot(M, s, lane, row, b);
+      double xdd[2];
+      const double acc = sell_row_dot_sp(M, sp0, sp1, lane, row, b, xdd);
       if (row < n_rows) { r = ci * xi - acc; if (r_out) r_out[row] = r; }
     }
   } else if (s < n_slices) {
@@ -990,7 +1002,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
     double xd[2] = {0.0, 0.0};
     const bool wdiag = M.wdiag && M.diag_first;
     if (!wdiag && (nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
-    double acc = sell_row_dot(M, s, lane, row, b, xd);
+    double acc = sell_row_dot_sp(M, sp0, sp1, lane, row, b, xd);
     if (row < n_rows) {
       if (wdiag) {
         // diagonal slot = omega*Dinv_i (no dinv stream, b_i from the gather): see sell_spmv_kernel
@@ -1016,6 +1028,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   }
   __syncthreads();
   if (myslot < s1) {
+    const int pa = pa_raw - e0, pb = pb_raw - e0;
     double acc = 0.0;
     for (int k = pa; k < pb; ++k) acc += pr[k];
     part[mydest] = acc;
@@ -1056,9 +1069,12 @@ __global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_ro
     fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
   }
   const int myslot = s0 + threadIdx.x;
-  const int mydest = (dest && myslot < s1) ? dest[myslot] : myslot;
-  const int pa = myslot < s1 ? slot_ptr[myslot] - e0 : 0;
-  const int pb = myslot < s1 ? slot_ptr[myslot + 1] - e0 : 0;
+  int mydest = myslot, pa_raw = 0, pb_raw = 0;               // (consumed after the row product: see sell_pre_restrict_kernel)
+  if (myslot < s1) {
+    if (dest) mydest = dest[myslot];
+    pa_raw = slot_ptr[myslot];
+    pb_raw = slot_ptr[myslot + 1];
+  }
   double ci = 0.0, xi = 0.0;
   if (row < n_rows) { ci = cvec[row]; xi = x[row]; }
   if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, x);
@@ -1073,6 +1089,7 @@ __global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_ro
   }
   __syncthreads();
   if (myslot < s1) {
+    const int pa = pa_raw - e0, pb = pb_raw - e0;
     double acc = 0.0;
     for (int k = pa; k < pb; ++k) acc += pr[k];
     part[mydest] = acc;
