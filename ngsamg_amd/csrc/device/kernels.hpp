@@ -1114,8 +1114,15 @@ __global__ __launch_bounds__(BLOCK) void restrict_sum_kernel(int64_t n_coarse, c
   double acc = 0.0;
   if (J < n_coarse) {
     const int e = optr[J + 1];
-    if (oidx) { for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[oidx[k]]; }
-    else { for (int k = optr[J] + sub; k < e; k += RSUM_G) acc += part[k]; }      // partials stored row by row (dest)
+    int k = optr[J] + sub;
+    if (oidx) {
+      // a row has ~10 partials over RSUM_G lanes: the first two per lane are requested together (index, then value), so
+      // the common case is two dependent round trips instead of four
+      const int i0 = k < e ? oidx[k] : -1, i1 = k + RSUM_G < e ? oidx[k + RSUM_G] : -1;
+      const double p0 = i0 >= 0 ? part[i0] : 0.0, p1 = i1 >= 0 ? part[i1] : 0.0;
+      acc = p0 + p1;
+      for (k += 2 * RSUM_G; k < e; k += RSUM_G) acc += part[oidx[k]];
+    } else { for (; k < e; k += RSUM_G) acc += part[k]; }      // partials stored row by row (dest)
   }
   // fixed combination order: deterministic
 #pragma unroll
