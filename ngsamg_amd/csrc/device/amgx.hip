@@ -203,7 +203,7 @@ struct DevCsr {                         // plain CSR copy for the single-workgro
 
 struct DevLevel {
   DevCsr tA, tApre, tP, tPT;            // only on tail levels
-  DevBuf<int32_t> t_rowlist, t_cptr;    // colour-major row list of a Gauss-Seidel tail level
+  DevBuf<int32_t> t_rowlist, t_cptr, t_rowcolor;    // colour-major row list (and the colour of every row) of a Gauss-Seidel tail level
   DevRestrict R;
   DevRestrict RF;                       // chunk-local P^T for sell_pre_restrict_kernel (fused pre-smoothing + restriction)
   int fused_block = 1024;               // workgroup size = rows per chunk of the fused kernel
@@ -1947,11 +1947,11 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       std::vector<TailOp> prog;
       const EpArgs none{nullptr, nullptr, nullptr, 0.0, nullptr, 0};
       auto spmv = [&](int ep, const DevCsr& M, int n, const double* x, double* y, EpArgs a) {
-        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0, 0});
+        prog.push_back(TailOp{T_SPMV, ep, n, M.rowptr.p, M.col.p, M.val.p, x, y, a, nullptr, nullptr, 0, 0, 0, nullptr});
       };
       auto gs = [&](DevLevel& V, int nc, int backward, int lds_ok) {
         prog.push_back(TailOp{T_GS, 0, (int)V.n, V.tA.rowptr.p, V.tA.col.p, V.tA.val.p, nullptr, V.x.p,
-                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward, lds_ok});
+                              EpArgs{V.rhs.p, nullptr, V.dinv.p, 0.0, nullptr, 0}, V.t_rowlist.p, V.t_cptr.p, nc, backward, lds_ok, V.t_rowcolor.p});
       };
       auto gs_lds_ok = [&](int l) {
         const amgx_matrix& A = levels[l].A;
@@ -1976,6 +1976,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
           std::vector<int32_t> pos(cptr.begin(), cptr.end() - 1);
           for (int64_t i = 0; i < s.A.n_rows; ++i) if (s.color[i] >= 0) rl[pos[s.color[i]]++] = (int32_t)i;
           V.t_rowlist.upload(rl); V.t_cptr.upload(cptr);
+          V.t_rowcolor.upload(s.color, (size_t)s.A.n_rows);
         }
       }
       for (int l = T; l + 1 < L; ++l) {       // down
@@ -1983,14 +1984,14 @@ static Handle* create(const amgx_hierarchy_desc* d) {
         if (V.sm_type == AMGX_SM_JACOBI) {     // r = b - A'b, x = omega*Dinv*b
           spmv(EP_PRE, V.tApre, (int)V.n, V.rhs.p, V.res.p, EpArgs{V.rhs.p, nullptr, V.dinv.p, V.omega, V.x.p, 0});
         } else {                               // x = 0; forward sweep; r = b - A x
-          prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0, 0});
+          prog.push_back(TailOp{T_ZERO, 0, (int)V.n, nullptr, nullptr, nullptr, nullptr, V.x.p, none, nullptr, nullptr, 0, 0, 0, nullptr});
           gs(V, levels[l].n_colors, 0, gs_lds_ok(l));
           spmv(EP_RES, V.tA, (int)V.n, V.x.p, V.res.p, EpArgs{V.rhs.p, nullptr, nullptr, 0.0, nullptr, 0});
         }
         spmv(EP_MULT, V.tPT, (int)h->lev[l + 1].n, V.res.p, h->lev[l + 1].rhs.p, none);   // b_{l+1} = P^T r
       }
       prog.push_back(TailOp{T_DENSE, 0, (int)h->coarse_n, nullptr, nullptr, h->coarse_inv.p, h->lev[L - 1].rhs.p, h->lev[L - 1].x.p,
-                            none, nullptr, nullptr, 0, 0, 0});
+                            none, nullptr, nullptr, 0, 0, 0, nullptr});
       for (int l = L - 2; l >= T; --l) {      // up
         DevLevel& V = h->lev[l];
         if (V.sm_type == AMGX_SM_JACOBI) {     // tmp = x + P x_{l+1} ; x = tmp + omega*Dinv*(b - A tmp)

@@ -1199,26 +1199,51 @@ struct TailOp {
   int n_colors;
   int backward;
   int lds_ok;            // T_GS: n <= TAIL_BLOCK / TAIL_G rows of <= TAIL_G * TAIL_GS_K entries: x in LDS, rows in registers
+  const int32_t* rowcolor;   // T_GS with lds_ok: colour of every row (-1: not swept)
 };
 constexpr int TAIL_GS_K = 8;
 
-__device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, double* y, const EpArgs& a) {
+// own-row operands requested before the row product, consumed after it (one dependent round trip less per operation)
+__device__ __forceinline__ EpOps tail_operands(int ep, int64_t row, const EpArgs& a) {
   switch (ep) {
-    case EP_MULT: store_scalar<EP_MULT>(row, acc, y, a); break;
-    case EP_RES: store_scalar<EP_RES>(row, acc, y, a); break;
-    case EP_AXPY: store_scalar<EP_AXPY>(row, acc, y, a); break;
-    case EP_JAC: store_scalar<EP_JAC>(row, acc, y, a); break;
-    case EP_CRES: store_scalar<EP_CRES>(row, acc, y, a); break;
-    default: store_scalar<EP_PRE>(row, acc, y, a); break;
+    case EP_MULT: return EpOps{0.0, 0.0, 0.0};
+    case EP_RES: return ep_operands<EP_RES>(row, a, false);
+    case EP_AXPY: return ep_operands<EP_AXPY>(row, a, false);
+    case EP_JAC: return ep_operands<EP_JAC>(row, a, false);
+    case EP_CRES: return ep_operands<EP_CRES>(row, a, false);
+    default: return ep_operands<EP_PRE>(row, a, false);
+  }
+}
+__device__ __forceinline__ void tail_store(int ep, int64_t row, double acc, double* y, const EpArgs& a, const EpOps& o) {
+  switch (ep) {
+    case EP_MULT: store_scalar_ops<EP_MULT>(row, acc, y, a, o, false, 0.0); break;
+    case EP_RES: store_scalar_ops<EP_RES>(row, acc, y, a, o, false, 0.0); break;
+    case EP_AXPY: store_scalar_ops<EP_AXPY>(row, acc, y, a, o, false, 0.0); break;
+    case EP_JAC: store_scalar_ops<EP_JAC>(row, acc, y, a, o, false, 0.0); break;
+    case EP_CRES: store_scalar_ops<EP_CRES>(row, acc, y, a, o, false, 0.0); break;
+    default: store_scalar_ops<EP_PRE>(row, acc, y, a, o, false, 0.0); break;
   }
 }
 
+// The kernel is one chain of dependent steps on a single CU, so every memory round trip counts: the operation list is
+// copied to LDS once, an operation requests its row entries (<= TAIL_SP_K per lane in registers) and own-row operands
+// together, then all gathers, and only then starts to add.
+constexpr int TAIL_MAX_OPS = 48;
+constexpr int TAIL_SP_K = 8;
 __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailOp* __restrict__ ops) {
   __shared__ double xs[TAIL_BLOCK / TAIL_G];
-  __shared__ int rc[TAIL_BLOCK / TAIL_G];
+  __shared__ TailOp lops[TAIL_MAX_OPS];
   const int tid = threadIdx.x;
+  {
+    constexpr int WORDS = (int)(sizeof(TailOp) / sizeof(int));
+    const int total = (n_ops < TAIL_MAX_OPS ? n_ops : TAIL_MAX_OPS) * WORDS;
+    const int* src = reinterpret_cast<const int*>(ops);
+    int* dst = reinterpret_cast<int*>(lops);
+    for (int k = tid; k < total; k += TAIL_BLOCK) dst[k] = src[k];
+    __syncthreads();
+  }
   for (int i = 0; i < n_ops; ++i) {
-    const TailOp op = ops[i];
+    const TailOp op = i < TAIL_MAX_OPS ? lops[i] : ops[i];
     if (op.type == T_ZERO) {
       for (int k = tid; k < op.n; k += TAIL_BLOCK) op.y[k] = 0.0;
     } else if (op.type == T_GS && op.lds_ok) {
@@ -1226,13 +1251,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
       // colour phase is LDS reads + one barrier instead of a chain of dependent global loads (2 us per colour)
       const int row = tid / TAIL_G, sub = tid % TAIL_G;
       const bool act = row < op.n;
-      if (tid < TAIL_BLOCK / TAIL_G) rc[tid] = -1;
-      __syncthreads();
-      for (int p = tid; p < op.cptr[op.n_colors]; p += TAIL_BLOCK) {
-        int c = 0;
-        while (op.cptr[c + 1] <= p) ++c;
-        rc[op.rowlist[p]] = c;
-      }
+      const int mycol = act ? op.rowcolor[row] : -1;
       double v[TAIL_GS_K];
       int cl[TAIL_GS_K];
       const int e0 = act ? op.rowptr[row] : 0, e1 = act ? op.rowptr[row + 1] : 0;
@@ -1245,7 +1264,6 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
       double dv = 0.0, bv = 0.0;
       if (act && sub == 0) { dv = op.args.dinv[row]; bv = op.args.b[row]; xs[row] = op.y[row]; }
       __syncthreads();
-      const int mycol = act ? rc[row] : -1;
       for (int q = 0; q < op.n_colors; ++q) {
         const int c = op.backward ? op.n_colors - 1 - q : q;
         if (mycol == c) {                                   // uniform inside a lane group: the shuffles are safe
@@ -1288,12 +1306,26 @@ __global__ __launch_bounds__(TAIL_BLOCK) void tail_kernel(int n_ops, const TailO
       const int sub = tid % TAIL_G;
       // all lanes of a group run the same trip count (row is group-uniform), so the shuffles are safe
       for (int row = tid / TAIL_G; row < op.n; row += TAIL_BLOCK / TAIL_G) {
+        const int e0 = op.rowptr[row], e = op.rowptr[row + 1];
+        EpOps eo{0.0, 0.0, 0.0};
+        if (sub == 0) eo = tail_operands(op.ep, row, op.args);
+        double v[TAIL_SP_K], xv[TAIL_SP_K];
+        int cl[TAIL_SP_K];
+#pragma unroll
+        for (int k = 0; k < TAIL_SP_K; ++k) {
+          const int q = e0 + sub + k * TAIL_G;
+          v[k] = q < e ? op.val[q] : 0.0;
+          cl[k] = q < e ? op.col[q] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < TAIL_SP_K; ++k) xv[k] = cl[k] >= 0 ? op.x[cl[k]] : 0.0;
         double acc = 0.0;
-        const int e = op.rowptr[row + 1];
-        for (int k = op.rowptr[row] + sub; k < e; k += TAIL_G) acc += op.val[k] * op.x[op.col[k]];
+#pragma unroll
+        for (int k = 0; k < TAIL_SP_K; ++k) acc += v[k] * xv[k];
+        for (int q = e0 + sub + TAIL_SP_K * TAIL_G; q < e; q += TAIL_G) acc += op.val[q] * op.x[op.col[q]];    // rows beyond 64 entries
 #pragma unroll
         for (int o = TAIL_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, TAIL_G);
-        if (sub == 0) tail_store(op.ep, row, acc, op.y, op.args);
+        if (sub == 0) tail_store(op.ep, row, acc, op.y, op.args, eo);
       }
     }
     __syncthreads();     // workgroup-scope release/acquire: the next operation reads what this one wrote
