@@ -183,6 +183,35 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     dist.destroy_process_group()
 
 
+def _wait_ranks(procs, limit):
+    """Wait for the rank processes; procs[0].stdout is read to its end.  A rank that dies, or a collective that never
+    completes, must not leave the others waiting forever: on the first non-zero exit code, or after `limit` seconds, the
+    remaining processes (exactly these) are killed.  Returns (exit codes, rank 0's stdout, reason or None)."""
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0 = time.time()
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            why = f"a rank failed (exit codes so far {codes})"
+        elif time.time() - t0 > limit:
+            why = f"no result after {limit:.0f} s"
+        if why:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    return codes, (buf[0] if buf else ""), why
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE anything in this
     process touches the GPU, relay rank 0's JSON line, fail if any rank fails or fewer than N ranks joined RCCL."""
@@ -206,8 +235,9 @@ def self_launch(args):
         env.pop("OMP_NUM_THREADS", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    codes, out, why = _wait_ranks(procs, float(os.environ.get("NGSAMG_BENCH_TIMEOUT", "1700")))
+    if why:
+        log(f"multi-rank run stopped: {why}")
     line = None
     for ln in (out or "").splitlines():
         if ln.startswith("{"):

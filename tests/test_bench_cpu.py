@@ -1,0 +1,43 @@
+"""bench.py's multi-rank launcher logic without GPUs: the watchdog that ends a run when a rank dies or nothing comes back."""
+import importlib.util
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _proc(code, capture):
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE if capture else subprocess.DEVNULL, text=True)
+
+
+def test_wait_ranks_collects_the_result_line():
+    b = _bench()
+    procs = [_proc("print('noise'); print(chr(123) + 'value: 1' + chr(125))", True), _proc("import time; time.sleep(0.3)", False)]
+    codes, out, why = b._wait_ranks(procs, 30.0)
+    assert codes == [0, 0] and why is None and "{value: 1}" in out
+
+
+def test_wait_ranks_stops_the_others_when_a_rank_fails():
+    b = _bench()
+    t0 = time.time()
+    procs = [_proc("import time; time.sleep(60)", True), _proc("import sys; sys.exit(3)", False), _proc("import time; time.sleep(60)", False)]
+    codes, out, why = b._wait_ranks(procs, 30.0)
+    assert time.time() - t0 < 20 and why and "failed" in why
+    assert codes[1] == 3 and codes[0] != 0 and codes[2] != 0
+
+
+def test_wait_ranks_times_out():
+    b = _bench()
+    t0 = time.time()
+    procs = [_proc("import time; time.sleep(60)", True), _proc("import time; time.sleep(60)", False)]
+    codes, out, why = b._wait_ranks(procs, 1.0)
+    assert time.time() - t0 < 20 and why and "no result" in why and all(c != 0 for c in codes)
