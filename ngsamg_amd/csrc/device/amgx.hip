@@ -158,6 +158,7 @@ struct DevGS {                          // colour-major data for multicolour Gau
 struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_kernel): blocks of B consecutive rows
   int B = 0, G = 1, TH = 1024;          // rows per block, lanes per row, workgroup size (B * G == TH)
   int n_blocks = 0, n_colors = 0;
+  int lowin_maxw = 0;                   // widest slice of `lowin` (entries per lane): <= 5 selects the narrow sweep-from-zero kernel
   DevMatrix::Sell full, lowin;          // block-local SELL-G copies (slots colour-sorted inside a block): all entries /
                                         //   only the in-block couplings to LOWER colours (forward sweep from x = 0)
   DevBuf<int32_t> rowid;
@@ -921,8 +922,9 @@ struct Handle {
     GsbArgs a{g.rowid.p, g.slotcolor.p, L.dinv.p, b, g.n_colors, dir};
     const SellMat M = copy.view();
     const bool fz = xin == nullptr;
-#define LAUNCH_GSB3(TT, GG, ZZ) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
-#define LAUNCH_GSB2(TT, GG) { if (fz) LAUNCH_GSB3(TT, GG, true); else LAUNCH_GSB3(TT, GG, false); }
+    const bool narrow = fz && &copy == &g.lowin && g.lowin_maxw > 0 && g.lowin_maxw <= 5 && !std::getenv("AMGX_GSB_NO_NARROW");
+#define LAUNCH_GSB3(TT, GG, ZZ, WW) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ, WW>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
+#define LAUNCH_GSB2(TT, GG) { if (narrow) LAUNCH_GSB3(TT, GG, true, 2); else if (fz) LAUNCH_GSB3(TT, GG, true, GSB_WP); else LAUNCH_GSB3(TT, GG, false, GSB_WP); }
 #define LAUNCH_GSB(TT) switch (g.G) { case 1: LAUNCH_GSB2(TT, 1); break; case 2: LAUNCH_GSB2(TT, 2); break; case 4: LAUNCH_GSB2(TT, 4); break; \
                                       case 8: LAUNCH_GSB2(TT, 8); break; default: LAUNCH_GSB2(TT, 16); break; }
     if (g.TH == 256) LAUNCH_GSB(256) else if (g.TH == 512) LAUNCH_GSB(512) else LAUNCH_GSB(1024)
@@ -1566,6 +1568,9 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
     build_sell(F, rows.data(), slots, false, G, S);
     check_width(S, "lower part");
     upload_sell(S, g.lowin);
+    g.lowin_maxw = 0;
+    for (size_t q = 0; q + 1 < S.slice_ptr.size(); ++q)
+      g.lowin_maxw = std::max(g.lowin_maxw, (int)(((S.slice_ptr[q + 1] & ~(int64_t)63) - (S.slice_ptr[q] & ~(int64_t)63)) / WAVE));
     F.rowptr = rp[1].data(); F.col = cc[1].data(); F.val = vv[1].data();
     upload_matrix(F, g.rest, "A (block-hybrid Gauss-Seidel: rest)", true, false, false, 1.6, SELL_WIN);
     g.cvec.upload(cv);

@@ -654,7 +654,9 @@ struct GsbArgs {
   int backward;
 };
 
-template <int TH, int G, bool FROM_ZERO>
+// WP = pair-steps a lane holds (2 * WP + 1 entries): GSB_WP in general; the sweep from zero reads the short `lowin` rows and
+// is instantiated with WP = 2 where they fit (fewer registers: more resident workgroups to hide each other's colour phases)
+template <int TH, int G, bool FROM_ZERO, int WP = GSB_WP>
 __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
                                                         const double* __restrict__ xin, double* xout) {
   constexpr int B = TH / G;                  // rows per block
@@ -682,11 +684,11 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
   const bool c16 = sp0 & 1;
   const double* __restrict__ vb = M.val + base;
   const int32_t* __restrict__ cb = M.cbase + (base >> 6);
-  double v[2 * GSB_WP + 1];
-  int cl[2 * GSB_WP + 1];
-  uint32_t ra[GSB_WP], rb[GSB_WP];           // raw index words: 16-bit form = one packed pair in ra; 32-bit form = ra, rb
+  double v[2 * WP + 1];
+  int cl[2 * WP + 1];
+  uint32_t ra[WP], rb[WP];           // raw index words: 16-bit form = one packed pair in ra; 32-bit form = ra, rb
 #pragma unroll
-  for (int p = 0; p < GSB_WP; ++p) {
+  for (int p = 0; p < WP; ++p) {
     v[2 * p] = 0.0; v[2 * p + 1] = 0.0; ra[p] = 0; rb[p] = 0;
     if (p < np) {                                            // wave-uniform
       v[2 * p] = ld_nt(vb + (p * WAVE + lane) * 2);
@@ -698,40 +700,40 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
       }
     }
   }
-  int cbv[2 * GSB_WP + 1];                   // column bases of the slice: one group of scalar loads (the array has slack at its end)
+  int cbv[2 * WP + 1];                   // column bases of the slice: one group of scalar loads (the array has slack at its end)
 #pragma unroll
-  for (int j = 0; j < 2 * GSB_WP + 1; ++j) cbv[j] = 0;
+  for (int j = 0; j < 2 * WP + 1; ++j) cbv[j] = 0;
   if (c16) {
 #pragma unroll
-    for (int j = 0; j < 2 * GSB_WP + 1; ++j) cbv[j] = cb[j];
+    for (int j = 0; j < 2 * WP + 1; ++j) cbv[j] = cb[j];
   }
   uint32_t rt = 0;
-  v[2 * GSB_WP] = 0.0;
+  v[2 * WP] = 0.0;
   if (w & 1) {
     const int64_t o = (int64_t)(w - 1) * WAVE + lane;
-    v[2 * GSB_WP] = ld_nt(vb + o);
+    v[2 * WP] = ld_nt(vb + o);
     rt = c16 ? (uint32_t)ld_nt(M.col16 + base + o) : (uint32_t)ld_nt(M.col32 + base + o);
   }
   // ---- phase 2: the column decode (needs the index words)
   const int mycol = row >= 0 ? col_raw : 255;
   const bool writer = mycol != 255 && (lane % G) == 0;
 #pragma unroll
-  for (int p = 0; p < GSB_WP; ++p) {
+  for (int p = 0; p < WP; ++p) {
     cl[2 * p] = (int)r0; cl[2 * p + 1] = (int)r0;
     if (p < np) {
       if (c16) { cl[2 * p] = cbv[2 * p] + (int)(ra[p] & 0xffffu); cl[2 * p + 1] = cbv[2 * p + 1] + (int)(ra[p] >> 16); }
       else { cl[2 * p] = (int)ra[p]; cl[2 * p + 1] = (int)rb[p]; }
     }
   }
-  // (the odd trailing column of a slice of width w <= 2*GSB_WP + 1 is column w - 1: a wave-uniform pick from the group)
+  // (the odd trailing column of a slice of width w <= 2*WP + 1 is column w - 1: a wave-uniform pick from the group)
   int cbt = 0;
 #pragma unroll
-  for (int j = 0; j < 2 * GSB_WP + 1; j += 2) cbt = (w - 1 == j) ? cbv[j] : cbt;
-  cl[2 * GSB_WP] = (w & 1) ? (c16 ? cbt + (int)rt : (int)rt) : (int)r0;
+  for (int j = 0; j < 2 * WP + 1; j += 2) cbt = (w - 1 == j) ? cbv[j] : cbt;
+  cl[2 * WP] = (w & 1) ? (c16 ? cbt + (int)rt : (int)rt) : (int)r0;
   // ---- phase 3: off-block part (frozen values): all gathers requested, then summed; in-block part keeps (value, LDS slot)
-  double xg[2 * GSB_WP + 1];
+  double xg[2 * WP + 1];
 #pragma unroll
-  for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
+  for (int j = 0; j < 2 * WP + 1; ++j) {
     const int loc = cl[j] - (int)r0;
     const bool inb = loc >= 0 && loc < B && cl[j] < n_rows;       // (ghost columns of a rank-partitioned level are never in-block)
     xg[j] = 0.0;
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
   }
   double acc_off = 0.0;
 #pragma unroll
-  for (int j = 0; j < 2 * GSB_WP + 1; ++j) {
+  for (int j = 0; j < 2 * WP + 1; ++j) {
     const bool inb = cl[j] >= 0;
     if (!FROM_ZERO) acc_off += inb ? 0.0 : v[j] * xg[j];
     if (!inb) { v[j] = 0.0; cl[j] = 0; }
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kern
     if (__any(mycol == c)) {                                 // slices hold one or two colours (slots are colour-sorted)
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 2 * GSB_WP + 1; ++j) acc += v[j] * xs[cl[j]];
+      for (int j = 0; j < 2 * WP + 1; ++j) acc += v[j] * xs[cl[j]];
 #pragma unroll
       for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
       if (writer && mycol == c) xs[own] = xs[own] + dv * (bv - acc_off - acc);
