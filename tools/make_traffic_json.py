@@ -21,7 +21,7 @@ def main():
     jobs = [("jacobi", "sell_pre_restrict_kernel<512, 0>", "traffic_pre_restrict_l0.json", "sell_pre_restrict_kernel<512> level 0 (cfg 2)"),
             ("jacobi", "sell_win_spmv_kernel<512, 2>", "traffic_q_l0.json", "sell_win_spmv_kernel<512, EP_AXPY> on Q, level 0 (cfg 2)"),
             ("gs", "sell_spmv_kernel<1, 1>", "traffic_spmv_l0.json", "sell_spmv_kernel<1, EP_RES> level 0 (cfg 2)"),
-            ("gs", "gsb_sweep_kernel<256, 1, false>", "traffic_gsb_sweep_l0.json", "gsb_sweep_kernel<256, 1, false> level 0 (cfg 2)"),
+            ("gs", "gsb_sweep_kernel<256, 1, false", "traffic_gsb_sweep_l0.json", "gsb_sweep_kernel<256, 1, false, 8> level 0 (cfg 2)"),
             ("gs", "sell_win_cres_restrict_kernel<512>", "traffic_gs_res_restrict_l0.json", "sell_win_cres_restrict_kernel<512> level 0 (cfg 2)")]
     for sm, needle, out, label in jobs:
         f, nf = mean(os.path.join(d, f"pmc_{sm}_FETCH_SIZE_by_kernel.csv"), needle)
