@@ -1032,7 +1032,8 @@ struct Handle {
   }
 
   bool plain(const DevLevel& L) const { return L.sm_steps <= 1 && !L.sm_symm; }
-  bool folded(const DevLevel& L) const { return plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.Q.empty() && (L.bs > 1 || !L.Apre.empty()); }
+  // (a level without rows -- a rank that owns nothing -- is trivially folded: every kernel on it is a no-op)
+  bool folded(const DevLevel& L) const { return plain(L) && L.sm_type == AMGX_SM_JACOBI && (L.n == 0 || (!L.Q.empty() && (L.bs > 1 || !L.Apre.empty()))); }
 
   // pre-smoothing step of the cycles: x = 0; r = b; Smooth(x, b, r, 1, 1, 1)   (amg_matrix.cpp:193-206)
   // fold (only with folded(L)): x receives z = x + omega*Dinv*r, to be completed by post_smooth(..., fold = true)
@@ -1487,6 +1488,10 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
   for (int64_t i = 0; i < n; ++i) mx = std::max<int64_t>(mx, d.A.rowptr[i + 1] - d.A.rowptr[i]);
   int G = 1;
   while (G < 16 && mx > 16 * G + (G == 1 ? 1 : 0)) G <<= 1;
+  if (n == 0) {                     // a rank that owns nothing: the form is "on" (the cycle drivers test it) with no block to sweep
+    g.B = B > 0 ? B : 256; g.G = 1; g.TH = 256; g.n_colors = 0; g.n_blocks = 0;
+    return;
+  }
   const int TH = B * G;
   if (B < 16 || (TH != 256 && TH != 512 && TH != 1024))
     throw Err("gs_block_rows = " + std::to_string(B) + " with " + std::to_string(G) + " lanes per row (longest row: " + std::to_string(mx) +

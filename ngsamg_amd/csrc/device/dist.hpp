@@ -624,9 +624,10 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
   std::vector<const double*> b0(M.size());
   for (size_t i = 0; i < M.size(); ++i) {
     Dist* d = M[i];
-    if (!b[i] || !x[i]) throw Err("amgx_dist_apply: null vector");
+    if ((!b[i] || !x[i]) && d->n(0) > 0) throw Err("amgx_dist_apply: null vector");
     const int64_t nb = b_status == 0 ? d->next(0) : d->n(0);
-    if (host) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyHostToDevice, c.compute));
+    if (nb == 0) {}
+    else if (host) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyHostToDevice, c.compute));
     else if (b[i] != d->bext[0].p) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyDeviceToDevice, c.compute));
     b0[i] = d->bext[0].p;
     cy.x.push_back(host ? d->x0.p : x[i]);
@@ -640,7 +641,8 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
   else if (M[0]->gsb) cy.hybrid_gsb(b0);
   else cy.hybrid_gs(b0);
   if (host) {
-    for (size_t i = 0; i < M.size(); ++i) HIPCHK(hipMemcpyAsync(x[i], M[i]->x0.p, M[i]->n(0) * sizeof(double), hipMemcpyDeviceToHost, c.compute));
+    for (size_t i = 0; i < M.size(); ++i)
+      if (M[i]->n(0)) HIPCHK(hipMemcpyAsync(x[i], M[i]->x0.p, M[i]->n(0) * sizeof(double), hipMemcpyDeviceToHost, c.compute));
     HIPCHK(hipStreamSynchronize(c.compute));
   }
 }

@@ -486,6 +486,18 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
     stuck = False
     for s in states:
         bf = _bs(s)
+        if s.n == 0:
+            # a rank without rows (NGSolve's master rank holds no mesh in classic MPI runs; the reference guards its
+            # smoothers with `if (A.Height())`): it takes part in every collective with empty pieces
+            bc = 1 if energy == 0 else (6 if dim == 3 else 3)
+            c = RankState()
+            c.rank, c.n, c.bs, c.n_interior = s.rank, 0, bc, 0
+            c.coords = None if s.coords is None else np.zeros((0, np.asarray(s.coords).shape[1] if np.asarray(s.coords).ndim == 2 else dim))
+            c.free = np.zeros(0, dtype=np.uint8)
+            s.agg = np.zeros(0, dtype=np.int32)
+            P_blk.append((np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros((0, bf, bc)), bf, bc))
+            nxt.append(c)
+            continue
         A_oo = sp.csr_matrix(s.A[:, :s.n * bf])
         kw = dict(o)
         dflt = (0.05 if dim == 3 else 0.1) if energy == 0 else (0.1 if dim == 3 else 0.15)
@@ -670,7 +682,8 @@ def _hybrid_gsb_data(comm, states, block_rows=None):
     for s in states:
         M = _mat(s.A)
         Bs.append(int(block_rows) if block_rows else gs_block_rows(M))
-    B = min(min(x) for x in comm.allgather(Bs))          # (0 if any rank cannot use the block form)
+    votes = [x for lst in comm.allgather([b if s.n > 0 else -1 for b, s in zip(Bs, states)]) for x in lst if x >= 0]
+    B = min(votes) if votes else 0                       # (0 if any non-empty rank cannot use the block form)
     for s, gd in zip(states, gdiag):
         if B <= 0:
             raise NgsAMGError("hgs: a rank-partitioned level cannot use the block-hybrid form (rows too long or level too small); use sm_type = gs")
@@ -761,7 +774,8 @@ class DistributedAMG:
         levels = [states0]
         while len(levels) <= max_dist_levels:
             cur = levels[-1]
-            gmin = min(min(x) for x in comm.allgather([s.n for s in cur]))
+            sizes = [x for lst in comm.allgather([s.n for s in cur]) for x in lst if x > 0]       # (empty ranks do not decide)
+            gmin = min(sizes) if sizes else 0
             if gmin < dist_min_rows:
                 break
             levels.append(coarsen_distributed_level(comm, cur, dim, len(levels) == 1, opts))

@@ -118,3 +118,37 @@ def test_hybrid_smoother_weight_uses_partial_sums_on_the_bridged_level():
     s0 = amg.dist_levels[0][0]
     assert getattr(s0, "G_abs_partial", None) is not None and s0.G_abs_partial.shape == (s0.n, s0.ghost_owner.size)
     assert getattr(amg.dist_levels[1][0], "G_abs_partial", None) is None
+
+
+def _with_empty_master(pgrid, gshape):
+    """the partition of _setup shifted to ranks 1..R with an EMPTY rank 0 in front (NGSolve's classic MPI layout: the master
+    rank holds no part of the mesh; the reference guards its smoothers with `if (A.Height())`)"""
+    R = int(np.prod(pgrid)) + 1
+    comm = D.LoopbackComm(R)
+    locs = []
+    for r in range(R - 1):
+        L, _ = B.shared_poisson_partition(r, pgrid, gshape)
+        L.rank = r + 1
+        L.dist_procs = [np.asarray(p) + 1 for p in L.dist_procs]
+        locs.append(L)
+    empty = B.SharedLocal(0, sp.csr_matrix((0, 0)), [], free=np.zeros(0, dtype=np.uint8), coords=np.zeros((0, len(gshape))))
+    states, vmaps = B.from_shared_layout(comm, [empty] + locs)
+    return comm, states, vmaps
+
+
+@pytest.mark.parametrize("sm", ["jacobi", "gs", "hgs"])
+def test_rank_without_rows_takes_part_in_the_collective_cycle(sm):
+    from tests.dist_oracle import oracle_sm_types
+    comm, states, vmaps = _with_empty_master((2, 2, 1), (13, 13, 6))
+    assert states[0].n == 0 and all(s.n > 0 for s in states[1:])
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=30, backend=cpu_backend(sm_type=sm), max_coarse_size=10, sm_type=sm,
+                           hgs_block_rows=32, gs_stage_min_rows=20)
+    assert amg.k >= 1 and amg.dist_levels[1][0].n == 0
+    rng = np.random.default_rng(1)
+    bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
+    xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
+    amg.Mult(bs, xs)
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg)).apply(np.concatenate([b.numpy() for b in bs]))
+    got = np.concatenate([x.numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)

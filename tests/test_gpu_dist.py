@@ -431,3 +431,38 @@ def test_loopback_device_block_hybrid_gs(R, box, dim, dmin):
     ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("sm", ["jacobi", "gs", "hgs"])
+def test_loopback_device_rank_without_rows(sm):
+    """a rank that owns nothing (NGSolve's classic MPI master) takes part in the native collective cycle with empty pieces:
+    zero-row levels, halo tables without peers, an empty slot in the all-gather of level k"""
+    import scipy.sparse as sp
+    import torch
+    from ngsamg_amd import bridge as B, dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_sm_types
+    pgrid, gshape = (2, 2, 1), (17, 17, 9)
+    R = 5
+    comm = D.LoopbackComm(R)
+    locs = []
+    for r in range(R - 1):
+        L, _ = B.shared_poisson_partition(r, pgrid, gshape)
+        L.rank = r + 1
+        L.dist_procs = [np.asarray(p) + 1 for p in L.dist_procs]
+        locs.append(L)
+    empty = B.SharedLocal(0, sp.csr_matrix((0, 0)), [], free=np.zeros(0, dtype=np.uint8), coords=np.zeros((0, 3)))
+    states, vmaps = B.from_shared_layout(comm, [empty] + locs)
+    assert states[0].n == 0
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=60, device=0, max_coarse_size=10, sm_type=sm, hgs_block_rows=256,
+                           gs_stage_min_rows=50)
+    rng = np.random.default_rng(1)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    ref = Oracle(amg.global_levels(), sm_type=oracle_sm_types(amg)).apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
