@@ -79,6 +79,26 @@ def test_elast_3d_lo(rot):
     assert c.GetBlockSize(0) == (6 if rot else 3) and c.GetBlockSize(1) == 6
 
 
+@pytest.mark.parametrize("rot", [False, True])
+def test_elast_2d_lo(rot):
+    """reference tests/elasticity/mdim/simple/test_2d_lo.py (test_2d_lo, test_2d_lo_R): beam 10 x 1, maxh = 0.1, mu=1, lam=0,
+    max_coarse_size 20, ms 50; 2x2 displacement blocks (3x3 with the rotation) on level 0, 3x3 below"""
+    from ngsamg_amd import NgsAMG
+    from oracle.pyoracle import Oracle
+    p = fem.elasticity_fast((101, 11), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=(10.0, 1.0))
+    c = NgsAMG.elast_2d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=20, ngs_amg_rots=rot)
+    Solve(_mat(p), p.load, c, ms=50, tol=1e-6)           # the reference's budget
+    assert c.GetBlockSize(0) == (3 if rot else 2) and c.GetBlockSize(1) == 3
+    # and the application itself against the oracle on the same hierarchy
+    H = c.GetHierarchy()
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    x = np.zeros_like(b)
+    c.Mult(b, x)
+    ref = Oracle(H.levels, sm_type="gs_mc").apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
 def test_smoother_map_and_cinv_surface():
     from ngsamg_amd import NgsAMG
     from oracle.pyoracle import Oracle
