@@ -405,7 +405,8 @@ def poisson_fast(shape, dirichlet="right|top", jitter=0.2, seed=1, coef=None):
     return _fast(shape, 0, 1, dirichlet, jitter, seed, 1.0, 0.0, coef, None)
 
 
-def elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, jitter=0.2, seed=1, rotations=False, extent=None):
+def elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, jitter=0.2, seed=1, rotations=False, extent=None, coef=None):
+    """coef (optional): callable of the cell centres -> factor on the cell's stiffness (material jumps, as for poisson_fast)"""
     dim = len(shape)
     bs = dim + (dim * (dim - 1)) // 2 if rotations else dim
-    return _fast(shape, 2 if rotations else 1, bs, dirichlet, jitter, seed, mu, lam, None, extent)
+    return _fast(shape, 2 if rotations else 1, bs, dirichlet, jitter, seed, mu, lam, coef, extent)
