@@ -47,6 +47,10 @@ typedef struct amgh_options {
   int32_t enable_multistep;  /* ngs_amg_enable_multistep: reach first_aaf by several concatenated coarsening steps of ~aaf each,   */
                              /*   P = P_1 P_2 ... (reference default for H1: true, h1_impl.hpp:331; default HERE: 0, because the   */
                              /*   concatenated P has ~3x the entries per row: fewer iterations, slower application)    */
+  int32_t robust_soc;        /* own, default 0: every vertex carries the largest edge weight collapsed inside it (through the      */
+                             /*   pairwise rounds AND from level to level) and a connection is judged against that scale too, so a  */
+                             /*   stiff inclusion that has become one vertex does not absorb its soft neighbours (the role of the   */
+                             /*   accumulated vertex weights in the reference's strength of connection, spw_agg_impl.hpp)           */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -30,6 +30,7 @@ struct Graph {
   std::vector<int64_t> ptr;
   std::vector<int32_t> adj;
   std::vector<double> w;
+  std::vector<double> vs;      // robust_soc: per vertex the largest edge weight collapsed inside it (empty = none)
 };
 
 Graph strength_graph(const BCSR& A, const std::vector<uint8_t>& free, int dim, int energy) {
@@ -76,7 +77,7 @@ int64_t pairwise_round(const Graph& G, const std::vector<uint8_t>& active, doubl
   std::vector<double> mx(n, 0.0);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
-    double m = 0;
+    double m = G.vs.empty() ? 0.0 : G.vs[i];
     for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) m = std::max(m, G.w[k]);
     mx[i] = m;
   }
@@ -114,6 +115,16 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
   }
   Graph C;
   C.n = nn;
+  if (!G.vs.empty()) {           // scale of a merged vertex: the scales of its members and the edges that vanish inside it
+    C.vs.assign(nn, 0.0);
+    for (int64_t i = 0; i < G.n; i++) {
+      const int32_t I = map[i];
+      if (I < 0) continue;
+      double m = G.vs[i];
+      for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) if (map[G.adj[k]] == I) m = std::max(m, G.w[k]);
+      C.vs[I] = std::max(C.vs[I], m);
+    }
+  }
   const int nt = std::min(omp_get_max_threads(), 32);   // each thread owns dense markers of size n_cols: bound the memory
   std::vector<std::vector<int32_t>> tadj(nt);
   std::vector<std::vector<double>> tw(nt);
@@ -159,8 +170,9 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
 
 // Aggregation for one level: repeated pairwise rounds until n_agg <= target * n_free.
 // Returns agg (fine vertex -> aggregate or -1) and the number of aggregates.
+// out_scale (robust_soc, G0.vs set): per aggregate the largest edge weight that vanishes inside it (and the members' scales)
 int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double target, const Options& o,
-                  std::vector<int32_t>& agg, int& rounds_done) {
+                  std::vector<int32_t>& agg, int& rounds_done, std::vector<double>* out_scale = nullptr) {
   const int64_t n = G0.n;
   int64_t nfree = 0;
   for (int64_t i = 0; i < n; i++) nfree += free[i] ? 1 : 0;
@@ -199,13 +211,24 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
   for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) size[agg[i]]++;
   std::vector<int32_t> remap(ncur);
   std::iota(remap.begin(), remap.end(), 0);
+  std::vector<double> cmx;
+  if (!cur.vs.empty()) {         // robust_soc: an orphan joins a neighbour only over a connection that counts on both ends' scales
+    cmx = cur.vs;
+    for (int64_t I = 0; I < ncur; I++)
+      for (int64_t k = cur.ptr[I]; k < cur.ptr[I + 1]; k++) cmx[I] = std::max(cmx[I], cur.w[k]);
+  }
   for (int64_t I = 0; I < ncur; I++) {
     if (size[I] != 1 || remap[I] != I) continue;
     int32_t best = -1;
     double bw = 0;
     for (int64_t k = cur.ptr[I]; k < cur.ptr[I + 1]; k++) {
-      int32_t J = remap[cur.adj[k]];
+      const int32_t J0 = cur.adj[k];
+      int32_t J = remap[J0];
       if (J == I) continue;
+      if (!cmx.empty()) {
+        const double dd = cmx[I] * cmx[J0];
+        if (!(dd > 0) || cur.w[k] / std::sqrt(dd) < o.soc_thresh) continue;
+      }
       if (cur.w[k] > bw) { bw = cur.w[k]; best = J; }
     }
     if (best >= 0) { remap[I] = best; size[best] += 1; size[I] = 0; }
@@ -220,6 +243,16 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
   }
   for (int64_t I = 0; I < ncur; I++) if (remap[I] == I) newid[I] = (int32_t)nn++;
   for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = newid[remap[agg[i]]];
+  if (out_scale && !G0.vs.empty()) {
+    out_scale->assign(nn, 0.0);
+    for (int64_t i = 0; i < n; i++) {
+      const int32_t I = agg[i];
+      if (I < 0) continue;
+      double m = G0.vs[i];
+      for (int64_t k = G0.ptr[i]; k < G0.ptr[i + 1]; k++) if (agg[G0.adj[k]] == I) m = std::max(m, G0.w[k]);
+      (*out_scale)[I] = std::max((*out_scale)[I], m);
+    }
+  }
   return nn;
 }
 
@@ -475,17 +508,23 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       BCSR tmpA;
       std::vector<uint8_t> cur_free = F.free;
       std::vector<double> cur_coords = F.coords;
+      std::vector<double> cur_vs = F.vscale;
       BCSR Ptot;
       bool failed = false;
       while (true) {
         Graph G = strength_graph(*curA, cur_free, dim, o.energy);
+        if (o.robust_soc) { G.vs = cur_vs; G.vs.resize(G.n, 0.0); }
         const double step_target = (o.enable_multistep && target < o.aaf) ? std::max(target, o.aaf) : target;
         std::vector<int32_t> sagg;
+        std::vector<double> next_vs;
         int r = 0;
         int64_t cur_free_n = 0;
         for (auto f : cur_free) cur_free_n += f;
-        const int64_t snc = aggregate(G, cur_free, step_target, o, sagg, r);
+        const int64_t snc = aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
         if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }
+        // robust_soc: what is left are vertices that must not be merged; a level that is barely smaller than its parent costs a
+        // smoother and buys nothing (the coarsest-level inverse takes over)
+        if (o.robust_soc && lev > 0 && (double)snc > 0.8 * (double)cur_free_n) { failed = substeps == 0; break; }
         rounds += r;
         BCSR W = prolongation_weights(G, sagg, snc, o);
         const int sbf = curA->br;
@@ -509,6 +548,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         curA = &tmpA;
         cur_free.assign(snc, 1);
         cur_coords = std::move(sxc);
+        cur_vs = std::move(next_vs);
         nc = snc;
         substeps++;
         if (!o.enable_multistep || (double)nc <= 1.3 * target * (double)nfree || substeps >= 4) break;
@@ -519,6 +559,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       F.agg = agg;
       C.A = std::move(tmpA);
       xc = std::move(cur_coords);
+      C.vscale = std::move(cur_vs);
     }
     double t6 = omp_get_wtime();
     log << "  time: coarsening step(s) " << t6 - t0 << " (" << substeps << " sub-step" << (substeps == 1 ? "" : "s") << ")\n";

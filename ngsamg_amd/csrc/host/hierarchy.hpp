@@ -12,6 +12,7 @@ struct Options {
   int64_t max_coarse_size = 50;
   double first_aaf = 0.05;       // target n_1/n_0      (h1_impl.hpp:333)
   double aaf = 0.125;            // target n_{l+1}/n_l  (h1_impl.hpp:334)
+  int robust_soc = 0;            // vertex scales in the strength of connection (amgh.h)
   int enable_multistep = 0;      // concatenate several coarsening steps until a level reaches its target (h1_impl.hpp:331)
   // smoothed prolongation (h1_impl.hpp:320-324, elasticity_pc_impl.hpp:58-62)
   int enable_sp = 1;
@@ -38,6 +39,7 @@ struct Level {
   std::vector<int32_t> color;    // greedy multicolouring of the graph of A (free rows), -1 for non-free
   int n_colors = 0;
   std::vector<int32_t> agg;      // fine vertex -> coarse vertex (or -1); kept for block smoothers / debugging
+  std::vector<double> vscale;    // robust_soc: per vertex the largest edge weight collapsed inside it on the finer levels
 };
 
 struct Hierarchy {

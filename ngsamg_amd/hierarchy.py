@@ -90,7 +90,7 @@ def bgs_data(A, block_ptr, block_rows, pinv=False):
 _OPTION_KEYS = {
     "max_levels": int, "max_coarse_size": int, "first_aaf": float, "aaf": float, "enable_sp": int,
     "sp_omega": float, "sp_max_per_row": int, "sp_min_frac": float, "soc_thresh": float, "max_rounds": int,
-    "regularize_cmats": int, "log_level": int, "enable_multistep": int,
+    "regularize_cmats": int, "log_level": int, "enable_multistep": int, "robust_soc": int,
 }
 
 

@@ -159,3 +159,43 @@ def test_multistep_concatenated_prolongation(shape, dim):
         free = L.free.astype(bool)
         assert np.allclose(rs[free], 1.0, atol=1e-13)
         assert L.agg is not None and L.agg.max() < H.levels[l + 1].n
+
+
+def test_robust_soc_keeps_material_jumps_h_and_jump_independent():
+    """ngs_amg_robust_soc: every vertex carries the largest edge weight collapsed inside it; a connection that is negligible on
+    that scale is not a viable pairing, so stiff inclusions / fibres that have become single vertices do not absorb their
+    soft surroundings (reference: accumulated vertex weights in the strength of connection of the SPW agglomerator)"""
+    from ngsamg_amd import fem
+    from ngsamg_amd._lib import Matrix
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+
+    def its_for(p, dim, energy, rs, **kw):
+        A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+        H = Hierarchy(A, p.free, p.coords, dim=dim, energy=energy, robust_soc=rs, **kw)
+        return Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-6, maxit=200)[1], H
+
+    for jump in (1e2, 1e6):
+        def fibres(X):
+            x, y = X[..., 0], X[..., 1]
+            return np.where((np.floor(y * 10) % 2 == 1) & (np.abs(x - 0.5) < 0.4), jump, 1.0)
+
+        def squares(X):
+            x, y = X[..., 0], X[..., 1]
+            inner = ((np.abs(x - 0.3) < 0.1) | (np.abs(x - 0.7) < 0.1)) & ((np.abs(y - 0.3) < 0.1) | (np.abs(y - 0.7) < 0.1))
+            return np.where(inner, jump, 1.0)
+
+        p = fem.poisson_fast((81, 81), dirichlet="top|bottom", coef=fibres)
+        it1, H1 = its_for(p, 2, 0, 1, max_coarse_size=5)
+        it0, _ = its_for(p, 2, 0, 0, max_coarse_size=5)
+        assert it1 <= 20 and it1 < it0 and H1.coarse_n <= 64
+        for rot in (False, True):
+            e = fem.elasticity_fast((41, 41), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, coef=squares)
+            it1, H1 = its_for(e, 2, 1, 1, max_coarse_size=10, regularize_cmats=0 if rot else 1)
+            it0, _ = its_for(e, 2, 1, 0, max_coarse_size=10, regularize_cmats=0 if rot else 1)
+            assert it1 <= 20 and it1 < it0
+    # a uniform problem is hardly affected
+    p = fem.poisson_fast((33, 33, 33))
+    it1, _ = its_for(p, 3, 0, 1, max_coarse_size=20)
+    it0, _ = its_for(p, 3, 0, 0, max_coarse_size=20)
+    assert abs(it1 - it0) <= 2
