@@ -71,14 +71,19 @@ Graph strength_graph(const BCSR& A, const std::vector<uint8_t>& free, int dim, i
   return G;
 }
 
+constexpr double ROBUST_SCALE_GAP = 8.0;
+
 // One pairwise matching round.  map[i] = new vertex id.  Returns the number of new vertices.
 int64_t pairwise_round(const Graph& G, const std::vector<uint8_t>& active, double thresh, std::vector<int32_t>& map) {
   const int64_t n = G.n;
   std::vector<double> mx(n, 0.0);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
-    double m = G.vs.empty() ? 0.0 : G.vs[i];
+    double m = 0;
     for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) m = std::max(m, G.w[k]);
+    // the collapsed scale only speaks where it is of another order than the vertex's live connections (on a quasi-uniform
+    // mesh the two differ by the spread of the element sizes, and the plain measure must not change there)
+    if (!G.vs.empty() && G.vs[i] > ROBUST_SCALE_GAP * m) m = G.vs[i];
     mx[i] = m;
   }
   map.assign(n, -1);
@@ -213,9 +218,11 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
   std::iota(remap.begin(), remap.end(), 0);
   std::vector<double> cmx;
   if (!cur.vs.empty()) {         // robust_soc: an orphan joins a neighbour only over a connection that counts on both ends' scales
-    cmx = cur.vs;
-    for (int64_t I = 0; I < ncur; I++)
+    cmx.assign(ncur, 0.0);
+    for (int64_t I = 0; I < ncur; I++) {
       for (int64_t k = cur.ptr[I]; k < cur.ptr[I + 1]; k++) cmx[I] = std::max(cmx[I], cur.w[k]);
+      if (cur.vs[I] > ROBUST_SCALE_GAP * cmx[I]) cmx[I] = cur.vs[I];
+    }
   }
   for (int64_t I = 0; I < ncur; I++) {
     if (size[I] != 1 || remap[I] != I) continue;
