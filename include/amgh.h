@@ -49,7 +49,7 @@ typedef struct amgh_options {
                              /*   concatenated P has ~3x the entries per row: fewer iterations, slower application)    */
   int32_t robust_soc;        /* own, default 0: every vertex carries the largest edge weight collapsed inside it (through the      */
                              /*   pairwise rounds AND from level to level) and a connection is judged against that scale too, so a  */
-                             /*   (where it exceeds the vertex's live connections 8-fold: a quasi-uniform mesh is not affected), so a */
+                             /*   (where it exceeds the vertex's live connections 16-fold: quasi-uniform meshes keep their aggregates), so a */
                              /*   stiff inclusion that has become one vertex does not absorb its soft neighbours (the role of the   */
                              /*   accumulated vertex weights in the reference's strength of connection, spw_agg_impl.hpp)           */
 } amgh_options;

@@ -71,7 +71,7 @@ Graph strength_graph(const BCSR& A, const std::vector<uint8_t>& free, int dim, i
   return G;
 }
 
-constexpr double ROBUST_SCALE_GAP = 8.0;
+constexpr double ROBUST_SCALE_GAP = 16.0;
 
 // One pairwise matching round.  map[i] = new vertex id.  Returns the number of new vertices.
 int64_t pairwise_round(const Graph& G, const std::vector<uint8_t>& active, double thresh, std::vector<int32_t>& map) {
@@ -217,11 +217,13 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
   std::vector<int32_t> remap(ncur);
   std::iota(remap.begin(), remap.end(), 0);
   std::vector<double> cmx;
+  std::vector<uint8_t> speaks;
   if (!cur.vs.empty()) {         // robust_soc: an orphan joins a neighbour only over a connection that counts on both ends' scales
     cmx.assign(ncur, 0.0);
+    speaks.assign(ncur, 0);
     for (int64_t I = 0; I < ncur; I++) {
       for (int64_t k = cur.ptr[I]; k < cur.ptr[I + 1]; k++) cmx[I] = std::max(cmx[I], cur.w[k]);
-      if (cur.vs[I] > ROBUST_SCALE_GAP * cmx[I]) cmx[I] = cur.vs[I];
+      if (cur.vs[I] > ROBUST_SCALE_GAP * cmx[I]) { cmx[I] = cur.vs[I]; speaks[I] = 1; }
     }
   }
   for (int64_t I = 0; I < ncur; I++) {
@@ -232,7 +234,7 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
       const int32_t J0 = cur.adj[k];
       int32_t J = remap[J0];
       if (J == I) continue;
-      if (!cmx.empty()) {
+      if (!cmx.empty() && (speaks[I] || speaks[J0])) {       // (elsewhere the orphan joins its strongest neighbour as before)
         const double dd = cmx[I] * cmx[J0];
         if (!(dd > 0) || cur.w[k] / std::sqrt(dd) < o.soc_thresh) continue;
       }
