@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ops", action="store_true", help="print HIP-event timings of the individual kernels per level")
+    ap.add_argument("--multistep", action="store_true", help="cfg2, one GPU: hierarchy with ngs_amg_enable_multistep (the reference's H1 default; "
+                    "not the measured configuration: denser P, fewer iterations)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the result): everything libraries print (RCCL / gloo banners) goes to stderr
@@ -345,7 +347,7 @@ def main():
         prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
         A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
         t1 = time.time()
-        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
+        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10, enable_multistep=int(args.multistep))
         wl = (f"cfg2: 3D P1 Poisson {nv}^3 = {prob.n} DOF, jittered Kuhn tets (seed 1), "
               f"Dirichlet right|top, {args.smoother} omega=0.9, V(1,1), max_coarse_size=50")
     else:
@@ -628,7 +630,7 @@ def main():
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl,
+            "config": {"workload": wl + (" [enable_multistep]" if args.multistep else ""),
                        "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
                        "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
                        "post_smoothing": ("folded into the prolongation: x' = z + (I - w Dinv A) P x_c, same result up to rounding "
