@@ -574,6 +574,20 @@ def main():
             pcg = {"tol": 1e-8, "gpu_iterations": int(cg.iterations), "cpu_iterations": int(c_it),
                    "gpu_rel_residual": g_res, "cpu_rel_residual": c_res,
                    "solution_rel_diff": float(np.linalg.norm(xs.cpu().numpy() - xc) / np.linalg.norm(xc))}
+            try:
+                # time to solution of the whole solve with everything on the device (amgx_pcg: SpMV, cycle and BLAS-1 kernels)
+                from ngsamg_amd.krylov import NativeCGSolver
+                with torch.cuda.stream(stream):
+                    ncg = NativeCGSolver(amg, amg, tol=1e-8, maxsteps=200)
+                    ncg.Solve(b)                               # warm-up (graph capture of the cycle for these vectors)
+                    stream.synchronize()
+                    t_s = time.perf_counter()
+                    ncg.Solve(b)
+                    stream.synchronize()
+                    pcg["native_solve_ms"] = round(1e3 * (time.perf_counter() - t_s), 3)
+                    pcg["native_iterations"] = int(ncg.iterations)
+            except Exception as e:
+                log(f"native PCG timing failed: {e!r}")
             log(f"PCG to 1e-8: GPU {cg.iterations} iterations (|b - A x| / |b| on the free dofs = {g_res:.2e}), CPU oracle {c_it} ({c_res:.2e})")
         except Exception as e:                   # the parity block must never cost the bench line
             log(f"PCG parity block failed: {e!r}")
