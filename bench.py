@@ -586,6 +586,18 @@ def main():
                     stream.synchronize()
                     pcg["native_solve_ms"] = round(1e3 * (time.perf_counter() - t_s), 3)
                     pcg["native_iterations"] = int(ncg.iterations)
+                    # the same system by restarted GMRES(30) (amgx_gmres; criterion |C r_k| <= tol |C r_0|)
+                    from ngsamg_amd.krylov import NativeGMResSolver
+                    ngm = NativeGMResSolver(amg, amg, tol=1e-8, maxsteps=200, restart=30)
+                    ngm.Solve(b)
+                    stream.synchronize()
+                    t_s = time.perf_counter()
+                    xg = ngm.Solve(b)
+                    stream.synchronize()
+                    pcg["native_gmres_ms"] = round(1e3 * (time.perf_counter() - t_s), 3)
+                    pcg["native_gmres_iterations"] = int(ngm.iterations)
+                    amg.MatVec(0, xg, rt)
+                    pcg["native_gmres_rel_residual"] = float((torch.linalg.norm((b - rt) * fm) / torch.linalg.norm(b)).item())
             except Exception as e:
                 log(f"native PCG timing failed: {e!r}")
             log(f"PCG to 1e-8: GPU {cg.iterations} iterations (|b - A x| / |b| on the free dofs = {g_res:.2e}), CPU oracle {c_it} ({c_res:.2e})")
