@@ -218,8 +218,9 @@ def self_launch(args):
     import socket
     import subprocess
     import __graft_entry__ as ge
-    ge.build_host()
-    ge.build_hip()
+    if not os.environ.get("NGSAMG_NO_BUILD"):
+        ge.build_host()
+        ge.build_hip()
     import torch
     ndev = torch.cuda.device_count()               # (does not initialise the GPU)
     if ndev < args.gpus:
@@ -299,7 +300,9 @@ def main():
         os.environ["OMP_NUM_THREADS"] = os.environ.get("NGSAMG_OMP_THREADS", str(max(1, min(32, cpus // world))))
     import torch
     import __graft_entry__ as ge
-    if local_rank == 0 and not os.environ.get("NGSAMG_SELF_LAUNCHED"):
+    # NGSAMG_NO_BUILD=1 (tools/profile_round.sh): under rocprofv3 the profiler's preloaded library has already initialised
+    # the GPU, and a compiler child (hipcc -> clang -> lld exec chain) started from here would be the exec hop the pool refuses
+    if local_rank == 0 and not os.environ.get("NGSAMG_SELF_LAUNCHED") and not os.environ.get("NGSAMG_NO_BUILD"):
         ge.build_host()
         ge.build_hip()
     dist = None
@@ -518,7 +521,8 @@ def main():
     # ---- CPU baseline: the oracle (restatement of the reference's cycle) on this box's cores ----------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        ge.build_oracle()
+        if not os.environ.get("NGSAMG_NO_BUILD"):
+            ge.build_oracle()
         from oracle.pyoracle import Oracle      # measured as the CPU baseline, never part of the product path
         try:
             cores = len(os.sched_getaffinity(0))

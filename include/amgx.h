@@ -159,6 +159,13 @@ int amgx_coarse_solve(amgx_handle h, const double* rhs, double* x, int flags);
 /* GetNLevels / GetNDof / GetBlockSize (python_amg.hpp:15-103) */
 int amgx_n_levels(amgx_handle h);
 int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* nnz);
+/* how the V-cycle of this handle is launched (no reference counterpart; the reference's cycle is a host loop,
+ * amg_matrix.cpp:183-302):  tail_level = first level run inside the single-workgroup tail kernel (-1: none);
+ * dense_level = first level of the COLLAPSED coarse levels (-1: none): the sub-cycle on the levels >= dense_level is a
+ * fixed linear operator, formed once at amgx_create by running the device's own sub-cycle on the unit vectors and applied
+ * as one dense GEMV of dense_n x dense_n doubles (same operator, summation order differs: rounding-level differences).
+ * Environment of amgx_create: AMGX_NO_DENSE_TAIL=1 disables, AMGX_DENSE_MAX=<n> caps dense_n (default 8192). */
+int amgx_cycle_info(amgx_handle h, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n);
 /* device-format report per level matrix: which = 0 A, 1 P, 2 PT, 3 A' = A*omega*Dinv (pre-smoothing image),
  * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation); fmt: -1 not built, 0 CSR-vector,
  * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows; stored_entries counts padding

@@ -228,7 +228,7 @@ AMGX_SYMBOLS = [
     "amgx_apply_add", "amgx_smooth", "amgx_smooth_v_from_level", "amgx_jacobi_pre", "amgx_jacobi_post", "amgx_residual",
     "amgx_cycle_down", "amgx_cycle_up",
     "amgx_prolong", "amgx_matvec", "amgx_transfer_f2c",
-    "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_matrix_info",
+    "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_cycle_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op", "amgx_pcg", "amgx_gmres",
     "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
     "amgx_comm_synchronize", "amgx_comm_info", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply",
@@ -275,6 +275,7 @@ def hip():
     lib.amgx_coarse_solve.argtypes = [vp, dp, dp, C.c_int]
     lib.amgx_n_levels.argtypes = [vp]
     lib.amgx_level_info.argtypes = [vp, C.c_int, c_i64p, c_i32p, c_i64p]
+    lib.amgx_cycle_info.argtypes = [vp, c_i32p, c_i32p, c_i64p]
     lib.amgx_matrix_info.argtypes = [vp, C.c_int, C.c_int, c_i32p, c_i64p, c_i32p]
     lib.amgx_matrix_stream_bytes.argtypes = [vp, C.c_int, C.c_int, c_i64p]
     lib.amgx_time_op.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]

@@ -657,6 +657,11 @@ struct Handle {
   int tail_level = -1;                  // first level executed by tail_kernel (-1: no fused tail)
   int tail_ops = 0;
   DevBuf<TailOp> tail_prog;
+  // collapsed coarse levels (kernels.hpp, dense_op_gemv_kernel): the V-cycle on the levels >= dense_level as ONE dense
+  // operator, formed at create time by the device's own sub-cycle on the unit vectors (build_dense_tail)
+  int dense_level = -1;
+  int dense_n = 0, dense_ld = 0;
+  DevBuf<double> dense_op;
   std::string err;
   struct GraphKey { const double* b; double* x; int kind; bool operator<(const GraphKey& o) const { return std::tie(b, x, kind) < std::tie(o.b, o.x, o.kind); } };
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -1207,25 +1212,33 @@ struct Handle {
   }
 
   // ------------------------------------------------------------------ cycles
-  void cycle_v(double* x, const double* b) {
+  // l0: first level of the (sub-)cycle; x, b are the vectors of that level (l0 > 0: build_dense_tail)
+  void cycle_v(double* x, const double* b, int l0 = 0) {
     const int L = n_levels();
-    if (L == 1) { coarse_solve(b, x); return; }
-    const int T = tail_level > 0 ? tail_level : L - 1;     // levels >= T run inside tail_kernel
-    for (int l = 0; l < T; ++l) {
+    if (l0 == L - 1) { coarse_solve(b, x); return; }
+    const bool dense = dense_level > l0;
+    const bool tail = !dense && tail_level > 0 && l0 == 0;
+    const int T = dense ? dense_level : (tail ? tail_level : L - 1);     // levels >= T: one dense GEMV / tail_kernel
+    for (int l = l0; l < T; ++l) {
       Range rg(level_range_name(l));
-      double* xl = l == 0 ? x : lev[l].x.p;
-      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      double* xl = l == l0 ? x : lev[l].x.p;
+      const double* bl = l == l0 ? b : lev[l].rhs.p;
       pre_smooth_restrict(l, xl, bl, lev[l].res.p, lev[l + 1].rhs.p, folded(lev[l]));
     }
-    if (tail_level > 0) {
+    if (dense) {
+      Range rg("rest");                                    // levels >= dense_level incl. "coarse inv": x_T = B b_T
+      hipLaunchKernelGGL(dense_op_gemv_kernel, dim3((dense_n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, stream,
+                         dense_n, dense_ld, dense_op.p, lev[T].rhs.p, lev[T].x.p);
+      HIPCHK(hipGetLastError());
+    } else if (tail) {
       Range rg("rest");                                    // the coarse tail incl. "coarse inv" in one workgroup
       hipLaunchKernelGGL(tail_kernel, dim3(1), dim3(TAIL_BLOCK), 0, stream, tail_ops, tail_prog.p);
       HIPCHK(hipGetLastError());
     } else coarse_solve(lev[L - 1].rhs.p, lev[L - 1].x.p);
-    for (int l = T - 1; l >= 0; --l) {
+    for (int l = T - 1; l >= l0; --l) {
       Range rg(level_range_name(l));
-      double* xl = l == 0 ? x : lev[l].x.p;
-      const double* bl = l == 0 ? b : lev[l].rhs.p;
+      double* xl = l == l0 ? x : lev[l].x.p;
+      const double* bl = l == l0 ? b : lev[l].rhs.p;
       post_smooth(l, xl, bl, lev[l].res.p, lev[l + 1].x.p, folded(lev[l]));
     }
   }
@@ -1488,6 +1501,9 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
   for (int64_t i = 0; i < n; ++i) mx = std::max<int64_t>(mx, d.A.rowptr[i + 1] - d.A.rowptr[i]);
   int G = 1;
   while (G < 16 && mx > 16 * G + (G == 1 ? 1 : 0)) G <<= 1;
+  // the ranks of a partitioned level agree on ONE block size (the smallest any of them needs, dist.py) while their longest
+  // rows may differ: a rank with shorter rows spreads them over more lanes than it must, so that B * G is a workgroup size
+  while (G < 16 && B >= 16 && B * G < 256) G <<= 1;
   if (n == 0) {                     // a rank that owns nothing: the form is "on" (the cycle drivers test it) with no block to sweep
     g.B = B > 0 ? B : 256; g.G = 1; g.TH = 256; g.n_colors = 0; g.n_blocks = 0;
     return;
@@ -1781,7 +1797,70 @@ static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_lev
   }
 }
 
-static Handle* create(const amgx_hierarchy_desc* d) {
+// ---- collapsed coarse levels (see dense_op_gemv_kernel) -----------------------------------------------------------
+// Picks the first level l_c >= 1 from which the sub-cycle is cheaper as one dense GEMV than as its dependent launches,
+// forms B column by column with the handle's own kernels (so B is exactly the operator the separate launches apply,
+// whatever the smoother form) and stores it row-major.  AMGX_NO_DENSE_TAIL=1 disables, AMGX_DENSE_MAX=<n> caps n.
+static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx_level_desc* levels) {
+  const int L = d->n_levels;
+  if (d->cycle != AMGX_CYCLE_V || L < 3 || std::getenv("AMGX_NO_DENSE_TAIL")) return;
+  int64_t cap = 8192;
+  if (const char* e = std::getenv("AMGX_DENSE_MAX")) cap = std::max<int64_t>(0, std::atoll(e));
+  for (int l = 0; l < L; ++l) if (h.lev[l].ncols != h.lev[l].n) return;       // rank-partitioned levels are driven stage by stage
+  // dependent launches one cycle spends on level m (both directions), ~5 us each
+  auto launches = [&](int m) -> double {
+    const DevLevel& V = h.lev[m];
+    const int k = std::max(1, V.sm_steps) * (V.sm_symm ? 2 : 1);
+    if (V.sm_type == AMGX_SM_JACOBI) return h.folded(V) ? 3.0 : 2.0 + 3.0 * k;
+    if (V.sm_type == AMGX_SM_BGS) return 3.0 + 2.0 * k * std::max(1, V.bgs.n_colors);
+    if (V.gsb.on()) return 2.0 + 3.0 * k;
+    return 3.0 + 2.0 * k * std::max(1, V.gs.n_colors);
+  };
+  int lc = -1;
+  double est = 5.0;                               // the coarse solve
+  std::vector<double> est_from(L, 0.0);
+  for (int m = L - 2; m >= 1; --m) { est += 5.0 * launches(m); est_from[m] = est; }
+  for (int m = 1; m <= L - 2; ++m) {
+    const int64_t N = h.lev[m].len();
+    if (N < 1 || N > cap) continue;
+    const double dense_us = 4.0 + 8.0 * (double)N * (double)N / 4.0e6;      // ~4 TB/s on a few hundred workgroups
+    if (dense_us < 0.8 * est_from[m]) { lc = m; break; }
+  }
+  if (lc < 1) return;
+  const int N = (int)h.lev[lc].len();
+  const int ld = (N + 1) & ~1;
+  DevBuf<double> Bt;
+  Bt.alloc((size_t)N * ld);
+  h.dense_op.alloc((size_t)N * ld);
+  HIPCHK(hipMemsetAsync(Bt.p, 0, (size_t)N * ld * sizeof(double), h.stream));
+  HIPCHK(hipMemsetAsync(h.dense_op.p, 0, (size_t)N * ld * sizeof(double), h.stream));
+  const int saved_tail = h.tail_level;
+  h.tail_level = -1;                              // the sub-cycle runs as separate launches from level lc
+  DevLevel& V = h.lev[lc];
+  try {
+    for (int j = 0; j < N; ++j) {
+      hipLaunchKernelGGL(dense_unit_kernel, dim3(Handle::grid_for(N)), dim3(BLOCK), 0, h.stream, (int64_t)N, (int64_t)j, V.rhs.p);
+      h.cycle_v(V.x.p, V.rhs.p, lc);
+      HIPCHK(hipMemcpyAsync(Bt.p + (size_t)j * ld, V.x.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h.stream));
+      if ((j & 255) == 255) HIPCHK(hipStreamSynchronize(h.stream));          // bound the depth of the launch queue
+    }
+    const int tb = (N + 15) / 16;
+    hipLaunchKernelGGL(dense_transpose_kernel, dim3(tb, tb), dim3(BLOCK), 0, h.stream, N, ld, Bt.p, h.dense_op.p);
+    HIPCHK(hipGetLastError());
+    // leave the work vectors of the collapsed levels as create() made them
+    for (int m = lc; m < L; ++m) {
+      const size_t len = (size_t)std::max<int64_t>(1, h.lev[m].ext_len()) + 1;
+      for (double* v : {h.lev[m].x.p, h.lev[m].rhs.p, h.lev[m].res.p, h.lev[m].tmp.p}) HIPCHK(hipMemsetAsync(v, 0, len * sizeof(double), h.stream));
+    }
+    HIPCHK(hipStreamSynchronize(h.stream));
+  } catch (...) { h.tail_level = saved_tail; throw; }
+  h.tail_level = saved_tail;
+  h.dense_level = lc;
+  h.dense_n = N;
+  h.dense_ld = ld;
+}
+
+static Handle* create(const amgx_hierarchy_desc* d, bool allow_dense = true) {
   if (!d || d->n_levels < 1 || !d->levels) throw Err("amgx_create: empty hierarchy descriptor");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1923,7 +2002,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
       else if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
-    const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
+    const size_t len = (size_t)std::max<int64_t>(1, L.ext_len()) + 1;      // (+1: dense_op_gemv_kernel reads its operand in pairs)
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
     HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));
     HIPCHK(hipMemset(L.rhs.p, 0, len * sizeof(double)));
@@ -2018,6 +2097,7 @@ static Handle* create(const amgx_hierarchy_desc* d) {
     }
   }
   HIPCHK(hipDeviceSynchronize());
+  if (allow_dense) build_dense_tail(*h, d, levels);
   return h.release();
 }
 
@@ -2339,6 +2419,14 @@ int amgx_level_info(amgx_handle hh, int level, int64_t* n, int32_t* bs, int64_t*
     if (n) *n = h.lev[level].n;
     if (bs) *bs = h.lev[level].bs;
     if (nnz) *nnz = h.lev[level].A.nnz;
+  });
+}
+
+int amgx_cycle_info(amgx_handle hh, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n) {
+  return guard(hh, [&](amgx::Handle& h) {
+    if (tail_level) *tail_level = h.dense_level > 0 ? -1 : h.tail_level;
+    if (dense_level) *dense_level = h.dense_level;
+    if (dense_n) *dense_n = h.dense_level > 0 ? h.dense_n : 0;
   });
 }
 

@@ -92,8 +92,9 @@ struct HaloTable {                       // one level of one rank
     if (ns >= (int64_t)2147483647) throw Err("halo table: too many send entries");
     if (ns > 0 && !d.send_idx) throw Err("halo table: send_idx missing");
     for (int64_t i = 0; i < ns; ++i) if (d.send_idx[i] < 0 || d.send_idx[i] >= n) throw Err("halo table: send index out of the owned range");
-    // the boundary-row contract behind the overlap: a sent row may be interior or boundary, but a row that READS a ghost
-    // must not be interior -- that is a property of the matrix and is checked where the matrix is known (Dist::create)
+    // the boundary-row contract behind the overlap: a row that READS a ghost must not be interior -- a property of the matrix,
+    // checked where the matrix is known (dist_create).  A SENT row may be interior for the Jacobi stages (what is sent is
+    // complete before the exchange starts); the Gauss-Seidel stages need more, also checked in dist_create
     if (ns) send_idx.upload(d.send_idx, (size_t)ns);
     sendbuf.alloc((size_t)std::max<int64_t>(1, std::max<int64_t>(ns, 1) * bs));
   }
@@ -101,6 +102,9 @@ struct HaloTable {                       // one level of one rank
 };
 
 struct Dist;
+}  // namespace amgx
+struct amgx_dist_t { amgx::Dist* d; };
+namespace amgx {
 
 struct Comm {
   int kind = AMGX_COMM_LOCAL, nranks = 1, rank = 0, device = 0;
@@ -110,6 +114,10 @@ struct Comm {
   hipEvent_t ev_ready[NEV], ev_done[NEV];
   int ev_next = 0;
   std::vector<Dist*> members;            // local ranks in creation order (RCCL: exactly one)
+  // C-ABI wrappers handed out for this communicator's objects (amgx_dist_create, amgx_dist_handles): owned here, so that
+  // amgx_comm_destroy can null them -- a call through a stale wrapper then returns an error instead of touching freed memory
+  std::vector<amgx_dist_t*> dist_wrappers;
+  std::vector<amgx_handle_t*> handle_views;
   std::string err;
   int64_t n_exchanges = 0;               // statistics: halo exchanges started
   // Cross-stream ordering.  Measured on MI355X (tools/sync_lab.hip, profiles/r02/sync_lab.txt): one exchange-shaped
@@ -285,11 +293,15 @@ struct Dist {
   std::vector<HaloTable> halo;           // [k]
   std::vector<std::array<int, 4>> stage; // [k] colour ranges of the hybrid Gauss-Seidel stages: [s0,s1) first local part,
                                          //     [s1,s2) boundary ("EX") rows, [s2,s3) second local part (gssmoother.cpp:721-782)
+  std::vector<char> send_early;          // [k] block-hybrid levels: every sent row lies in a boundary block, so the exchange of x
+                                         //     may start while the interior blocks are still being swept
   std::vector<DevBuf<double>> bext, xext, text, rl;
   DevBuf<double> bk, bpad, bglob, xglob, xk_ext, x0;
   DevBuf<int64_t> kmap, compact;
   std::vector<int64_t> counts, offs;
   int64_t mcount = 0;                    // longest level-k piece
+  amgx_handle_t* view_top = nullptr;     // see amgx_dist_handles
+  amgx_handle_t* view_tail = nullptr;
 
   int64_t n(int l) const { return top->lev[l].len(); }
   int64_t next(int l) const { return top->lev[l].ext_len(); }
@@ -319,7 +331,7 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   D->overlap = !std::getenv("AMGX_DIST_NO_OVERLAP");
   amgx_hierarchy_desc td = d->top;
   td.device = c->device; td.use_graph = 0; td.clev = AMGX_CLEV_NONE; td.coarse_n = 0; td.coarse_inv = nullptr;
-  D->top.reset(create(&td));
+  D->top.reset(create(&td, false));        // (driven stage by stage: no collapsed coarse levels)
   amgx_hierarchy_desc ld = d->tail;
   ld.device = c->device;
   D->tail.reset(create(&ld));
@@ -353,6 +365,23 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
         for (int64_t e = s.A.rowptr[i]; e < s.A.rowptr[i + 1]; ++e)
           if (s.A.col[e] >= s.A.n_rows) throw Err("amgx_dist_create: a row of a local Gauss-Seidel stage has a ghost column");
       }
+      // send side of the same contract: the exchange of x starts after the colours [s0, s2) and runs beside [s2, s3), so a
+      // SENT row must have been swept by then.  Structurally symmetric matrices give that for free (a sent row reads a
+      // ghost, hence sits in the boundary stage); for anything else the level runs without the overlap.
+      const amgx_halo_desc& hd = d->halo[l];
+      const int64_t ns = hd.n_peers > 0 ? hd.send_ptr[hd.n_peers] : 0;
+      for (int64_t i = 0; i < ns; ++i)
+        if (s.color[hd.send_idx[i]] >= g[2]) { D->stage[l] = {g[0], g[1], nc, nc}; break; }
+    }
+    D->send_early.push_back(1);
+    if (D->top->lev[l].gsb.on()) {
+      // block-hybrid form: the boundary blocks [n_int / B, end) are swept first, then x travels beside the interior blocks
+      const amgx_halo_desc& hd = d->halo[l];
+      const int64_t ns = hd.n_peers > 0 ? hd.send_ptr[hd.n_peers] : 0;
+      const int64_t B = D->top->lev[l].gsb.B;
+      const int64_t first_bnd = (D->halo[l].n_int / B) * B;
+      for (int64_t i = 0; i < ns; ++i)
+        if (hd.send_idx[i] < first_bnd) { D->send_early[l] = 0; break; }
     }
   }
   if (D->fold) {
@@ -524,7 +553,8 @@ struct DistCycle {
   void hybrid_gsb(const std::vector<const double*>& b0) {
     const int k = M[0]->k;
     auto bl = [&](Dist* d, size_t i, int l) { return l == 0 ? b0[i] : (const double*)d->bext[l].p; };
-    auto nbi = [&](Dist* d, int l) { return (int)(d->halo[l].n_int / d->top->lev[l].gsb.B); };
+    // (a level with a sent row inside an interior block sweeps all its blocks before the exchange: see Dist::send_early)
+    auto nbi = [&](Dist* d, int l) { return d->send_early[l] ? (int)(d->halo[l].n_int / d->top->lev[l].gsb.B) : 0; };
     for (int l = 0; l < k; ++l) {
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
@@ -653,7 +683,6 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
 // C ABI (include/amgx.h, "rank-partitioned hierarchies")
 // ---------------------------------------------------------------------------------------------------
 struct amgx_comm_t { amgx::Comm* c; };
-struct amgx_dist_t { amgx::Dist* d; };
 struct amgx_halo_t { amgx::Comm* c; amgx::HaloTable t; };
 
 namespace {
@@ -714,6 +743,9 @@ int amgx_comm_destroy(amgx_comm c) {
   if (c->c) {
     (void)hipSetDevice(c->c->device);
     (void)hipDeviceSynchronize();
+    // wrappers stay allocated (a caller may still hold them) but point nowhere: amgx_dist_* / amgx_* calls through them fail cleanly
+    for (amgx_dist_t* w : c->c->dist_wrappers) w->d = nullptr;
+    for (amgx_handle_t* v : c->c->handle_views) v->h = nullptr;
     for (amgx::Dist* d : c->c->members) delete d;
     delete c->c;
   }
@@ -751,10 +783,12 @@ int amgx_dist_create(amgx_comm cc, const amgx_dist_desc* desc, amgx_dist* out) {
     amgx::Dist* d = amgx::dist_create(&c, desc);
     c.members.push_back(d);
     *out = new amgx_dist_t{d};
+    c.dist_wrappers.push_back(*out);
   });
 }
 
-int amgx_dist_destroy(amgx_dist d) { delete d; return 0; }     // the communicator owns the rank objects
+// the communicator owns the rank objects and their wrappers (freed / nulled by amgx_comm_destroy); nothing to do here
+int amgx_dist_destroy(amgx_dist) { return 0; }
 
 int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_ext) {
   if (!d || !d->d) return 1;
@@ -765,11 +799,14 @@ int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_e
 }
 
 int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail) {
-  // borrowed views for queries / measurement (amgx_matrix_info, amgx_time_op); destroyed with the communicator
+  // borrowed views for queries / measurement (amgx_matrix_info, amgx_time_op): one pair per rank object, owned by the
+  // communicator; after amgx_comm_destroy they are null handles (every amgx_* call on them returns an error)
   if (!d || !d->d) return 1;
-  static thread_local std::vector<std::unique_ptr<amgx_handle_t>> views;
-  if (top) { views.emplace_back(new amgx_handle_t{d->d->top.get()}); *top = views.back().get(); }
-  if (tail) { views.emplace_back(new amgx_handle_t{d->d->tail.get()}); *tail = views.back().get(); }
+  amgx::Comm* c = d->d->comm;
+  if (!d->d->view_top) { d->d->view_top = new amgx_handle_t{d->d->top.get()}; c->handle_views.push_back(d->d->view_top); }
+  if (!d->d->view_tail) { d->d->view_tail = new amgx_handle_t{d->d->tail.get()}; c->handle_views.push_back(d->d->view_tail); }
+  if (top) *top = d->d->view_top;
+  if (tail) *tail = d->d->view_tail;
   return 0;
 }
 

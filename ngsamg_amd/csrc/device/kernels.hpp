@@ -1502,4 +1502,50 @@ __global__ __launch_bounds__(BLOCK) void dense_gemv_kernel(int n, const double* 
   if (lane == 0) y[row] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Collapsed coarse levels.  The V-cycle restricted to the levels >= l_c is a fixed LINEAR operator x_lc = B b_lc
+// (smoothers, transfers and the coarse inverse of amg_matrix.cpp:183-302 are all linear).  Where those levels are
+// launch-latency bound (a few hundred ... thousand unknowns, 3 .. 60 dependent launches of ~5 us) the operator is
+// formed ONCE at amgx_create by running the device's own sub-cycle on the unit vectors, and one application becomes
+// ONE dense GEMV that streams n^2 * 8 bytes (n = 1261 at cfg 2: 12.7 MB, ~6 us) -- 288 GB of HBM buy latency.
+//   dense_unit_kernel      : v = e_j
+//   dense_transpose_kernel : B[i][j] = Bt[j][i]   (Bt row j = B e_j as the sub-cycle delivers it)
+//   dense_op_gemv_kernel   : y = B x, one wave per row, 16-byte loads, rows padded to an even length `ld`
+__global__ __launch_bounds__(BLOCK) void dense_unit_kernel(int64_t n, int64_t j, double* __restrict__ v) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) v[i] = i == j ? 1.0 : 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void dense_transpose_kernel(int n, int ld, const double* __restrict__ src, double* __restrict__ dst) {
+  __shared__ double t[16][17];
+  const int bx = blockIdx.x * 16, by = blockIdx.y * 16;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  if (by + ty < n && bx + tx < n) t[ty][tx] = src[(int64_t)(by + ty) * ld + bx + tx];
+  __syncthreads();
+  if (bx + ty < n && by + tx < n) dst[(int64_t)(bx + ty) * ld + by + tx] = t[tx][ty];
+}
+__global__ __launch_bounds__(BLOCK) void dense_op_gemv_kernel(int n, int ld, const double* __restrict__ M,
+                                                              const double* __restrict__ x, double* __restrict__ y) {
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & (WAVE - 1);
+  if (row >= n) return;
+  const double2* __restrict__ m2 = reinterpret_cast<const double2*>(M + (int64_t)row * ld);
+  const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
+  const int np = ld >> 1;                       // pairs per row (x is allocated with an even length, the pad entry of M is 0)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int c = lane;
+  for (; c + 3 * WAVE < np; c += 4 * WAVE) {    // four independent 16-byte loads in flight per lane
+    const double2 m0 = m2[c], m1 = m2[c + WAVE], mm2 = m2[c + 2 * WAVE], m3 = m2[c + 3 * WAVE];
+    const double2 v0 = x2[c], v1 = x2[c + WAVE], v2 = x2[c + 2 * WAVE], v3 = x2[c + 3 * WAVE];
+    a0 += m0.x * v0.x + m0.y * v0.y;
+    a1 += m1.x * v1.x + m1.y * v1.y;
+    a2 += mm2.x * v2.x + mm2.y * v2.y;
+    a3 += m3.x * v3.x + m3.y * v3.y;
+  }
+  for (; c < np; c += WAVE) { const double2 m0 = m2[c], v0 = x2[c]; a0 += m0.x * v0.x + m0.y * v0.y; }
+  double acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int o = WAVE >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+  if (lane == 0) y[row] = acc;
+}
+
 }  // namespace amgx

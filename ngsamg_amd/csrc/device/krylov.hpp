@@ -159,7 +159,9 @@ struct Krylov {
   // pass (two fused passes over the basis instead of 2 j dependent dot / axpy pairs), Givens rotations on the host.
   // err_k = |C r_k| (the recurrence value), stop at err_k <= tol * err_0.
   int gmres(const double* b, double* x, double tol, int maxit, int restart, bool use_pre, double* errs) {
-    const int m = std::max(1, std::min(restart, 40));
+    // (the basis lives in HBM: (restart + 1) vectors; multi_dot handles up to 48 of them per pass)
+    if (restart > 40) throw Err("amgx_gmres: restart lengths above 40 are not supported (got " + std::to_string(restart) + ")");
+    const int m = std::max(1, restart);
     DevBuf<double> V, w, t, hdev;
     V.alloc((size_t)(m + 1) * n); w.alloc(n); t.alloc(n); hdev.alloc(64);
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), hcol(m + 1), hc2(m + 1), y(m);
@@ -215,7 +217,10 @@ struct Krylov {
       for (int i = k - 1; i >= 0; --i) {
         double sacc = g[i];
         for (int q = i + 1; q < k; ++q) sacc -= H[(size_t)i * m + q] * y[q];
-        y[i] = sacc / H[(size_t)i * m + i];
+        const double piv = H[(size_t)i * m + i];
+        // a zero pivot = the Krylov space stopped growing with a singular projected system (breakdown without convergence,
+        // e.g. a singular operator): that direction gets no update instead of an inf / nan
+        y[i] = piv != 0.0 ? sacc / piv : 0.0;
       }
       if (k > 0) {
         HIPCHK(hipMemcpyAsync(hdev.p, y.data(), k * sizeof(double), hipMemcpyHostToDevice, h.stream));
@@ -257,6 +262,7 @@ int amgx_gmres(amgx_handle hh, const double* b, double* x, double tol, int maxit
     Staged st(h, flags);
     const double* db = st.in(0, b, n, 0);
     double* dx = st.inout(1, x, n, true, 0);
+    if (use_precond && (db == h.lev[0].x.p || dx == h.lev[0].x.p)) throw amgx::Err("amgx_gmres: vectors alias the handle's work vectors");
     amgx::Krylov K(h);
     const int it = K.gmres(db, dx, tol, maxit, restart, use_precond != 0, errs);
     if (iters) *iters = it;

@@ -320,6 +320,13 @@ class DeviceAMGMatrix:
         self._ck(self._lib.amgx_level_info(self._h, level, C.byref(n), C.byref(bs), C.byref(nnz)))
         return n.value, bs.value, nnz.value
 
+    def cycle_info(self):
+        """how the V-cycle is launched: first level of the single-workgroup tail kernel, first level of the collapsed
+        (dense) coarse levels and the size of that dense operator (-1 / 0: not used)"""
+        t, d, n = C.c_int32(), C.c_int32(), C.c_int64()
+        self._ck(self._lib.amgx_cycle_info(self._h, C.byref(t), C.byref(d), C.byref(n)))
+        return {"tail_level": t.value, "dense_level": d.value, "dense_n": n.value}
+
     def matrix_info(self, level, which):
         fmt, stored, lanes = C.c_int32(), C.c_int64(), C.c_int32()
         self._ck(self._lib.amgx_matrix_info(self._h, level, {"A": 0, "P": 1, "PT": 2, "Apre": 3, "Q": 4}[which], C.byref(fmt),

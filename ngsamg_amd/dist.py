@@ -1237,8 +1237,17 @@ class _DeviceDist:
                 keep.append(st)
             keep += [counts, kmap]
             hd = C.c_void_p()
-            if lib.amgx_dist_create(self._comm, C.byref(d), C.byref(hd)) != 0:
-                raise NgsAMGError(lib.amgx_comm_last_error(self._comm).decode())
+            rc = lib.amgx_dist_create(self._comm, C.byref(d), C.byref(hd))
+            msg = lib.amgx_comm_last_error(self._comm).decode() if rc != 0 else ""
+            # amgx_dist_create is not collective: a failure on ONE rank (e.g. a level its kernels cannot take) must stop
+            # every rank here, before the first collective of amgx_dist_apply would leave the others waiting in RCCL
+            if not isinstance(comm, LoopbackComm):
+                msgs = comm.allgather([msg])[0]
+                bad = [(r, m) for r, m in enumerate(msgs) if m]
+                if bad:
+                    raise NgsAMGError("amgx_dist_create failed on rank(s) " + "; ".join(f"{r}: {m}" for r, m in bad))
+            elif rc != 0:
+                raise NgsAMGError(msg)
             self._dists.append(hd)
             self._keep.append(keep)
             ht, hl = C.c_void_p(), C.c_void_p()

@@ -40,17 +40,35 @@ def launch(args):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
+    import signal
+    import bench                       # the rank watchdog is the one bench.py --gpus N uses
     procs = []
-    for r in range(args.world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // args.world)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+
+    def reap(*_):
+        for p in procs:                # exactly the rank processes started here
+            if p.poll() is None:
+                p.kill()
+
+    # a parent that is told to stop (pytest's subprocess timeout sends SIGKILL to us only if we ignore SIGTERM; a driver
+    # usually sends SIGTERM first) must not leave ranks behind that hold the GPUs
+    signal.signal(signal.SIGTERM, lambda *a: (reap(), sys.exit(143)))
+    try:
+        for r in range(args.world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // args.world)))
+            # own session: a rank that outlives this launcher would otherwise keep the caller's process group alive
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        # first non-zero exit code, or no verdict within the limit: the remaining ranks are killed (a rank that died in RCCL /
+        # gloo initialisation or a collective that never completes would otherwise block the others forever)
+        codes, out, why = bench._wait_ranks(procs, float(os.environ.get("NGSAMG_CHECK_TIMEOUT", "600")))
+    finally:
+        reap()
     sys.stdout.write(out or "")
+    if why:
+        print("stopped:", why)
     print("exit codes", codes)
-    sys.exit(0 if all(c == 0 for c in codes) else 1)
+    sys.exit(0 if all(c == 0 for c in codes) and not why else 1)
 
 
 def self_loop_halo(lib, _lib, comm, torch, dev):

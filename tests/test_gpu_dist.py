@@ -115,7 +115,9 @@ def _run_check(*argv, timeout=600):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout)
+    # the launcher's own watchdog (kills exactly its rank processes) fires before this timeout would kill only the launcher
+    env = dict(os.environ, NGSAMG_CHECK_TIMEOUT=str(max(30, timeout - 90)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0 and "RCCL CHECK PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 

@@ -17,7 +17,8 @@ def _ngpu():
 
 
 def _run(*argv, timeout=900):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout)
+    env = dict(os.environ, NGSAMG_CHECK_TIMEOUT=str(max(30, timeout - 90)))     # the launcher's watchdog kills its ranks first
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0 and "RCCL CHECK PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
