@@ -52,6 +52,12 @@ typedef struct amgh_options {
                              /*   (where it exceeds the vertex's live connections 16-fold: quasi-uniform meshes keep their aggregates), so a */
                              /*   stiff inclusion that has become one vertex does not absorb its soft neighbours (the role of the   */
                              /*   accumulated vertex weights in the reference's strength of connection, spw_agg_impl.hpp)           */
+  int32_t spw;               /* 1 (default): the reference's SPW agglomeration with scalar strength of connection (reference            */
+                             /*   spw_agg_impl.hpp:637-775, 943-1263, 424-628): spw_rounds pairing rounds per coarsening step on contracted */
+                             /*   graphs, partner filter soc_ij >= 0.25 max_k soc_ik with soc = w / sqrt(maxTrOD_i maxTrOD_j), maxTrOD      */
+                             /*   carried through the rounds, orphan round.  0: the target-driven pairwise rounds of earlier builds       */
+  int32_t spw_rounds;        /* ngs_amg_spw_rounds           (3, spw_agg.hpp:28)                                                        */
+  int32_t spw_orphan_round;  /* ngs_amg_spw_orphan_treatment (1, spw_agg.hpp:32)                                                        */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -263,6 +263,13 @@ const char* amgx_comm_last_error(amgx_comm c);           /* c may be NULL for cr
 int amgx_comm_set_stream(amgx_comm c, void* hip_stream);
 int amgx_comm_synchronize(amgx_comm c);
 int amgx_comm_info(amgx_comm c, int32_t* kind, int32_t* n_ranks, int32_t* rank, int64_t* n_exchanges);
+/* how amgx_dist_apply launches (no reference counterpart: the reference's cycle is a host loop around MPI calls,
+ * amg_matrix.cpp:160-307 / dcc_map.cpp:76-178): with device vectors the whole collective cycle -- both streams, pack kernels,
+ * ncclSend / ncclRecv / ncclAllGather -- is captured once per (b, x, b_status) into a hipGraph and replayed.  enabled = 0
+ * after AMGX_DIST_GRAPH=0 or a failed capture (note: why; direct launches from then on); n_graphs = captured cycles held,
+ * n_replays = applications served by a graph launch. */
+int amgx_comm_graph_info(amgx_comm c, int32_t* enabled, int64_t* n_graphs, int64_t* n_replays);
+const char* amgx_comm_graph_note(amgx_comm c);
 
 /* halo tables of one level = DCCMap's m_ex_dofs / g_ex_dofs (dcc_map.cpp:480-543) in owner-row form */
 typedef struct amgx_halo_desc {
@@ -301,6 +308,14 @@ int amgx_dist_destroy(amgx_dist d);
  * (b.Distribute() state, amg_matrix.cpp:164; DCCMap DIS2CO).  x: owned entries (CUMULATED on the owners).
  * flags: AMGX_HOST_PTR / AMGX_DEVICE_PTR. */
 int amgx_dist_apply(amgx_comm c, const double* const* b, double* const* x, int b_status, int flags);
+/* Preconditioned CG on the rank-partitioned level-0 operator, collectively (the reference's driver: NGSolve CGSolver on
+ * ParallelVectors, tests/h1/amg_utils.py:337-363, whose inner products are MPI all-reduces): level-0 product with one owner ->
+ * ghost exchange behind the interior rows, preconditioner = amgx_dist_apply (replayed from its graph), the two inner products
+ * per iteration are deterministic local reductions + one ncclAllReduce of a device scalar each, recurrence scalars stay on the
+ * device, every rank reads the same error value and takes the same decision.  b, x: device pointers to the OWNED entries, one
+ * per local rank; x holds the initial guess.  err_k, tol, errs, iters as amgx_pcg. */
+int amgx_dist_pcg(amgx_comm c, const double* const* b, double* const* x, double tol, int maxit, int use_precond, int flags, double* errs,
+                  int32_t* iters);
 /* the level-0 right-hand-side buffer of a rank ([owned | ghost], device): filling it in place saves the copy of b */
 int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_ext);
 /* borrowed handles of the rank-partitioned levels and of the replicated tail, for queries / measurement only */

@@ -1215,6 +1215,13 @@ struct Handle {
   // l0: first level of the (sub-)cycle; x, b are the vectors of that level (l0 > 0: build_dense_tail)
   void cycle_v(double* x, const double* b, int l0 = 0) {
     const int L = n_levels();
+    if (dense_level >= 0 && dense_level == l0) {           // the whole (sub-)cycle is the dense operator: x = B b
+      Range rg("rest");
+      hipLaunchKernelGGL(dense_op_gemv_kernel, dim3((dense_n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(BLOCK), 0, stream,
+                         dense_n, dense_ld, dense_op.p, b, x);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     if (l0 == L - 1) { coarse_solve(b, x); return; }
     const bool dense = dense_level > l0;
     const bool tail = !dense && tail_level > 0 && l0 == 0;
@@ -1801,9 +1808,11 @@ static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_lev
 // Picks the first level l_c >= 1 from which the sub-cycle is cheaper as one dense GEMV than as its dependent launches,
 // forms B column by column with the handle's own kernels (so B is exactly the operator the separate launches apply,
 // whatever the smoother form) and stores it row-major.  AMGX_NO_DENSE_TAIL=1 disables, AMGX_DENSE_MAX=<n> caps n.
-static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx_level_desc* levels) {
+// first_level: 1 for a handle whose level 0 carries the caller's vectors; 0 for the replicated tail of a rank-partitioned
+// hierarchy, where the whole handle may become one GEMV on the gathered vector
+static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx_level_desc* levels, int first_level = 1) {
   const int L = d->n_levels;
-  if (d->cycle != AMGX_CYCLE_V || L < 3 || std::getenv("AMGX_NO_DENSE_TAIL")) return;
+  if (d->cycle != AMGX_CYCLE_V || L < 2 + first_level || std::getenv("AMGX_NO_DENSE_TAIL")) return;
   int64_t cap = 8192;
   if (const char* e = std::getenv("AMGX_DENSE_MAX")) cap = std::max<int64_t>(0, std::atoll(e));
   for (int l = 0; l < L; ++l) if (h.lev[l].ncols != h.lev[l].n) return;       // rank-partitioned levels are driven stage by stage
@@ -1819,14 +1828,14 @@ static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx
   int lc = -1;
   double est = 5.0;                               // the coarse solve
   std::vector<double> est_from(L, 0.0);
-  for (int m = L - 2; m >= 1; --m) { est += 5.0 * launches(m); est_from[m] = est; }
-  for (int m = 1; m <= L - 2; ++m) {
+  for (int m = L - 2; m >= first_level; --m) { est += 5.0 * launches(m); est_from[m] = est; }
+  for (int m = first_level; m <= L - 2; ++m) {
     const int64_t N = h.lev[m].len();
     if (N < 1 || N > cap) continue;
     const double dense_us = 4.0 + 8.0 * (double)N * (double)N / 4.0e6;      // ~4 TB/s on a few hundred workgroups
     if (dense_us < 0.8 * est_from[m]) { lc = m; break; }
   }
-  if (lc < 1) return;
+  if (lc < first_level) return;
   const int N = (int)h.lev[lc].len();
   const int ld = (N + 1) & ~1;
   DevBuf<double> Bt;
@@ -1840,7 +1849,7 @@ static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx
   try {
     for (int j = 0; j < N; ++j) {
       hipLaunchKernelGGL(dense_unit_kernel, dim3(Handle::grid_for(N)), dim3(BLOCK), 0, h.stream, (int64_t)N, (int64_t)j, V.rhs.p);
-      h.cycle_v(V.x.p, V.rhs.p, lc);
+      h.cycle_v(V.x.p, V.rhs.p, lc);                // (dense_level is still -1: separate launches)
       HIPCHK(hipMemcpyAsync(Bt.p + (size_t)j * ld, V.x.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, h.stream));
       if ((j & 255) == 255) HIPCHK(hipStreamSynchronize(h.stream));          // bound the depth of the launch queue
     }
@@ -1849,7 +1858,7 @@ static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx
     HIPCHK(hipGetLastError());
     // leave the work vectors of the collapsed levels as create() made them
     for (int m = lc; m < L; ++m) {
-      const size_t len = (size_t)std::max<int64_t>(1, h.lev[m].ext_len()) + 1;
+      const size_t len = (size_t)std::max<int64_t>(1, h.lev[m].ext_len());
       for (double* v : {h.lev[m].x.p, h.lev[m].rhs.p, h.lev[m].res.p, h.lev[m].tmp.p}) HIPCHK(hipMemsetAsync(v, 0, len * sizeof(double), h.stream));
     }
     HIPCHK(hipStreamSynchronize(h.stream));
@@ -1860,7 +1869,8 @@ static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx
   h.dense_ld = ld;
 }
 
-static Handle* create(const amgx_hierarchy_desc* d, bool allow_dense = true) {
+// dense_first: first level that may be collapsed into the dense operator (see build_dense_tail); < 0: never
+static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
   if (!d || d->n_levels < 1 || !d->levels) throw Err("amgx_create: empty hierarchy descriptor");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -2002,7 +2012,7 @@ static Handle* create(const amgx_hierarchy_desc* d, bool allow_dense = true) {
       else if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
-    const size_t len = (size_t)std::max<int64_t>(1, L.ext_len()) + 1;      // (+1: dense_op_gemv_kernel reads its operand in pairs)
+    const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
     HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));
     HIPCHK(hipMemset(L.rhs.p, 0, len * sizeof(double)));
@@ -2097,7 +2107,7 @@ static Handle* create(const amgx_hierarchy_desc* d, bool allow_dense = true) {
     }
   }
   HIPCHK(hipDeviceSynchronize());
-  if (allow_dense) build_dense_tail(*h, d, levels);
+  if (dense_first >= 0) build_dense_tail(*h, d, levels, dense_first);
   return h.release();
 }
 
@@ -2424,9 +2434,9 @@ int amgx_level_info(amgx_handle hh, int level, int64_t* n, int32_t* bs, int64_t*
 
 int amgx_cycle_info(amgx_handle hh, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n) {
   return guard(hh, [&](amgx::Handle& h) {
-    if (tail_level) *tail_level = h.dense_level > 0 ? -1 : h.tail_level;
+    if (tail_level) *tail_level = h.dense_level >= 0 ? -1 : h.tail_level;
     if (dense_level) *dense_level = h.dense_level;
-    if (dense_n) *dense_n = h.dense_level > 0 ? h.dense_n : 0;
+    if (dense_n) *dense_n = h.dense_level >= 0 ? h.dense_n : 0;
   });
 }
 

@@ -30,6 +30,7 @@ struct Rccl {
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -48,6 +49,7 @@ struct Rccl {
     r.Send = (decltype(r.Send))sym("ncclSend");
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
@@ -126,9 +128,23 @@ struct Comm {
   uint64_t* flags = nullptr;             // 2 * NEV counters, one cache line each
   uint64_t epoch = 0;
   bool use_values = false;
+  // Whole-cycle graph.  At strong-scaling sizes (1.25 M rows per rank and below) one application is ~30 launches, three
+  // RCCL groups and six cross-stream orderings for 100 - 200 us of GPU work: the host cannot enqueue them faster than the
+  // GPU retires them.  The collective cycle -- both streams, pack kernels and ncclSend / ncclRecv / ncclAllGather
+  // included -- is therefore captured ONCE per (b, x, b_status) into a hipGraph (cross-stream orderings become graph edges,
+  // i.e. cost nothing at replay) and replayed with one launch.  AMGX_DIST_GRAPH=0 keeps direct launches; a capture that
+  // fails (a runtime / RCCL build that cannot capture an operation) falls back to direct launches for good.
+  bool graph_ok = true, capturing = false;
+  struct GKey { std::vector<const void*> p; int status; bool operator<(const GKey& o) const { return status != o.status ? status < o.status : p < o.p; } };
+  struct GVal { hipGraphExec_t exec; int64_t exchanges; };
+  std::map<GKey, GVal> graphs;
+  int64_t n_graph_replays = 0;
+  std::string graph_note;
+  void drop_graphs() { for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec); graphs.clear(); }
 
   Comm() { for (int i = 0; i < NEV; ++i) { ev_ready[i] = nullptr; ev_done[i] = nullptr; } }
   ~Comm() {
+    drop_graphs();
     for (int i = 0; i < NEV; ++i) { if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]); if (ev_done[i]) (void)hipEventDestroy(ev_done[i]); }
     if (flags) (void)hipFree(flags);
     if (nccl) (void)Rccl::get().CommDestroy(nccl);
@@ -151,14 +167,16 @@ struct Comm {
     int can = 0;
     if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) can = 0;
     use_values = can && !std::getenv("AMGX_DIST_EVENTS");
+    if (const char* e = std::getenv("AMGX_DIST_GRAPH")) graph_ok = std::atoi(e) != 0;
     if (use_values) {
       HIPCHK(hipMalloc((void**)&flags, 2 * NEV * 64));
       HIPCHK(hipMemset(flags, 0, 2 * NEV * 64));
     }
   }
   // everything enqueued on `from` so far happens before whatever is enqueued on `to` from now on
+  // (while a graph is being captured the event form is used: it turns into a graph edge)
   void order(hipStream_t from, hipStream_t to, int slot, hipEvent_t ev) {
-    if (use_values) {
+    if (use_values && !capturing) {
       uint64_t* f = flags + slot * 8;
       ++epoch;
       HIPCHK(hipStreamWriteValue64(from, f, epoch, 0));
@@ -170,12 +188,12 @@ struct Comm {
   }
   // split form: the signal is enqueued now, the wait later (exchange_end)
   uint64_t signal(hipStream_t from, int slot, hipEvent_t ev) {
-    if (use_values) { ++epoch; HIPCHK(hipStreamWriteValue64(from, flags + slot * 8, epoch, 0)); return epoch; }
+    if (use_values && !capturing) { ++epoch; HIPCHK(hipStreamWriteValue64(from, flags + slot * 8, epoch, 0)); return epoch; }
     HIPCHK(hipEventRecord(ev, from));
     return 0;
   }
   void wait(hipStream_t to, int slot, hipEvent_t ev, uint64_t value) {
-    if (use_values) HIPCHK(hipStreamWaitValue64(to, flags + slot * 8, value, hipStreamWaitValueGte, 0xffffffffffffffffull));
+    if (use_values && !capturing) HIPCHK(hipStreamWaitValue64(to, flags + slot * 8, value, hipStreamWaitValueGte, 0xffffffffffffffffull));
     else HIPCHK(hipStreamWaitEvent(to, ev, 0));
   }
   uint64_t done_value[NEV] = {0};
@@ -300,6 +318,7 @@ struct Dist {
   DevBuf<int64_t> kmap, compact;
   std::vector<int64_t> counts, offs;
   int64_t mcount = 0;                    // longest level-k piece
+  bool force_allgather = false;
   amgx_handle_t* view_top = nullptr;     // see amgx_dist_handles
   amgx_handle_t* view_tail = nullptr;
 
@@ -331,10 +350,10 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   D->overlap = !std::getenv("AMGX_DIST_NO_OVERLAP");
   amgx_hierarchy_desc td = d->top;
   td.device = c->device; td.use_graph = 0; td.clev = AMGX_CLEV_NONE; td.coarse_n = 0; td.coarse_inv = nullptr;
-  D->top.reset(create(&td, false));        // (driven stage by stage: no collapsed coarse levels)
+  D->top.reset(create(&td, -1));           // (driven stage by stage: no collapsed coarse levels)
   amgx_hierarchy_desc ld = d->tail;
   ld.device = c->device;
-  D->tail.reset(create(&ld));
+  D->tail.reset(create(&ld, 0));           // the replicated tail may collapse completely: x_glob = B b_glob in one GEMV
   // both handles work on the communicator's compute stream
   for (Handle* h : {D->top.get(), D->tail.get()}) { HIPCHK(hipStreamSynchronize(h->stream)); h->stream = c->compute; }
   const int k = D->k;
@@ -404,6 +423,13 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   D->counts.assign(d->counts, d->counts + c->nranks);
   D->offs.assign(c->nranks + 1, 0);
   for (int r = 0; r < c->nranks; ++r) { if (D->counts[r] < 0) throw Err("amgx_dist_create: negative count"); D->offs[r + 1] = D->offs[r] + D->counts[r]; D->mcount = std::max(D->mcount, D->counts[r]); }
+  // AMGX_DIST_FORCE_ALLGATHER (tests, one-GPU rehearsals): world size 1 goes through ncclAllGather too instead of the copy
+  // shortcut; "pad" additionally pretends the pieces differ in size (every slot is 5 rows longer than the longest piece), so
+  // that the padded all-gather and the compaction kernel run
+  if (const char* e = std::getenv("AMGX_DIST_FORCE_ALLGATHER")) {
+    D->force_allgather = true;
+    if (std::string(e) == "pad") D->mcount += 5;
+  }
   const int bsk = D->top->lev[k].bs;
   if (D->counts[self] * bsk != D->n(k)) throw Err("amgx_dist_create: counts[rank] does not match level k");
   if (D->offs.back() * bsk != D->tail->lev[0].len()) throw Err("amgx_dist_create: the replicated tail does not match the gathered level");
@@ -451,7 +477,7 @@ struct DistCycle {
       const int bsk = d->top->lev[d->k].bs;
       if (c.kind == AMGX_COMM_RCCL) {
         Rccl& R = Rccl::get();
-        if (c.nranks == 1) d->top->copy(d->bglob.p, d->bk.p, d->n(d->k));
+        if (c.nranks == 1 && !d->force_allgather) d->top->copy(d->bglob.p, d->bk.p, d->n(d->k));
         else if (d->compact.n == 0) NCCLCHK(R.AllGather(d->bk.p, d->bglob.p, (size_t)(d->mcount * bsk), ncclDouble, c.nccl, c.compute));
         else {
           NCCLCHK(R.AllGather(d->bk.p, d->bpad.p, (size_t)(d->mcount * bsk), ncclDouble, c.nccl, c.compute));
@@ -468,7 +494,7 @@ struct DistCycle {
 
   void tail_and_pick() {
     for (Dist* d : M) {
-      d->tail->run_cycle(d->xglob.p, d->bglob.p, tail_graph);
+      d->tail->run_cycle(d->xglob.p, d->bglob.p, tail_graph && !c.capturing);
       const int64_t len = d->next(d->k);
       if (len) hipLaunchKernelGGL(index_gather_kernel, dim3(Handle::grid_for(len)), dim3(BLOCK), 0, c.compute, len, d->kmap.p, d->xglob.p, d->xk_ext.p);
       HIPCHK(hipGetLastError());
@@ -650,6 +676,31 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
   if (c.kind == AMGX_COMM_LOCAL && (int)M.size() != c.nranks) throw Err("amgx_dist_apply: not all local ranks have been created");
   if (!b || !x) throw Err("amgx_dist_apply: null vector list");
   const bool host = !(flags & AMGX_DEVICE_PTR);
+  for (size_t i = 0; i < M.size(); ++i)
+    if ((!b[i] || !x[i]) && M[i]->n(0) > 0) throw Err("amgx_dist_apply: null vector");
+  // ---- replay / capture of the whole collective cycle (see Comm::graphs) ----------------------------------------------
+  const bool want_graph = c.graph_ok && !host && !(flags & AMGX_NO_GRAPH) && c.compute != nullptr;
+  Comm::GKey key;
+  if (want_graph) {
+    key.status = b_status;
+    for (size_t i = 0; i < M.size(); ++i) { key.p.push_back(b[i]); key.p.push_back(x[i]); }
+    auto it = c.graphs.find(key);
+    if (it != c.graphs.end()) {
+      HIPCHK(hipGraphLaunch(it->second.exec, c.compute));
+      c.n_exchanges += it->second.exchanges;
+      ++c.n_graph_replays;
+      return;
+    }
+  }
+  const int64_t ex0 = c.n_exchanges;
+  if (want_graph) {
+    // the communication stream joins the capture through the first cross-stream ordering and is joined back by the last
+    // exchange_end / accumulate, as hipStreamEndCapture requires
+    c.capturing = true;
+    hipError_t e = hipStreamBeginCapture(c.compute, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { c.capturing = false; c.graph_ok = false; (void)hipGetLastError(); }
+  }
+  auto body = [&]() {
   DistCycle cy{c, M, {}};
   std::vector<const double*> b0(M.size());
   for (size_t i = 0; i < M.size(); ++i) {
@@ -670,12 +721,141 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
   if (M[0]->sm_type == AMGX_SM_JACOBI) { if (M[0]->fold) cy.jacobi_folded(); else cy.jacobi_literal(); }
   else if (M[0]->gsb) cy.hybrid_gsb(b0);
   else cy.hybrid_gs(b0);
+  };
+  if (c.capturing) {
+    hipGraph_t g = nullptr;
+    bool ok = true;
+    std::string why;
+    try { body(); } catch (const std::exception& ex) { ok = false; why = ex.what(); }
+    const hipError_t e = hipStreamEndCapture(c.compute, &g);
+    c.capturing = false;
+    hipGraphExec_t ge = nullptr;
+    if (ok && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+      (void)hipGraphDestroy(g);
+      if (c.graphs.size() >= 16) c.drop_graphs();
+      const int64_t nex = c.n_exchanges - ex0;
+      c.graphs.emplace(key, Comm::GVal{ge, nex});
+      HIPCHK(hipGraphLaunch(ge, c.compute));
+      ++c.n_graph_replays;
+      return;
+    }
+    // the capture did not work out: forget it, never try again on this communicator, run this application directly
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    c.graph_ok = false;
+    c.n_exchanges = ex0;
+    c.graph_note = "whole-cycle graph capture failed (" + (why.empty() ? std::string(hipGetErrorString(e)) : why) + "): direct launches";
+  }
+  body();
   if (host) {
     for (size_t i = 0; i < M.size(); ++i)
       if (M[i]->n(0)) HIPCHK(hipMemcpyAsync(x[i], M[i]->x0.p, M[i]->n(0) * sizeof(double), hipMemcpyDeviceToHost, c.compute));
     HIPCHK(hipStreamSynchronize(c.compute));
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Preconditioned CG over the rank-partitioned level-0 operator (SURVEY.md 8f-3 for several ranks).  On the reference side
+// this is NGSolve's CGSolver on ParallelVectors (tests/h1/amg_utils.py:337-363): every rank runs the recurrences on its
+// owned entries, the level-0 product needs the ghost values of the search direction (one owner -> ghost exchange, hidden
+// behind the interior rows), the two inner products per iteration are sums over the ranks (MPI all-reduce there;
+// ncclAllReduce of one device scalar here, deterministic local reductions), the preconditioner is the collective cycle
+// (dist_apply, replayed from its graph).  The residual lives in the level-0 right-hand-side buffer of the cycle, so
+// the preconditioner reads it in place.  err_k = sqrt(|<C r_k, r_k>|); stop at err_k <= tol * err_0.
+struct DistKrylov {
+  Comm& c;
+  std::vector<Dist*>& M;
+  std::vector<DevBuf<double>> sext, w;           // search direction [owned | ghost], work vector (owned)
+  DevBuf<double> partial, sc;
+  explicit DistKrylov(Comm& cc) : c(cc), M(cc.members) {
+    sext.resize(M.size()); w.resize(M.size());
+    for (size_t i = 0; i < M.size(); ++i) {
+      sext[i].alloc((size_t)std::max<int64_t>(1, M[i]->next(0)));
+      w[i].alloc((size_t)std::max<int64_t>(1, M[i]->n(0)));
+      HIPCHK(hipMemsetAsync(sext[i].p, 0, std::max<int64_t>(1, M[i]->next(0)) * sizeof(double), c.compute));
+    }
+    partial.alloc((size_t)KR_BLOCKS * M.size());
+    sc.alloc(64);
+    HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)KR_BLOCKS * M.size() * sizeof(double), c.compute));    // slots a short rank never writes stay 0
+    HIPCHK(hipMemsetAsync(sc.p, 0, 64 * sizeof(double), c.compute));
+  }
+  static int nb(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(KR_BLOCKS, (n + BLOCK - 1) / BLOCK)); }
+  double* d(size_t i) { return M[i]->bext[0].p; }              // residual = right-hand side of the cycle
+  // sc[slot] = sum over all ranks of <a_i, b_i> (owned entries)
+  void dot(const std::vector<const double*>& a, const std::vector<const double*>& b, int slot) {
+    for (size_t i = 0; i < M.size(); ++i) {
+      const int64_t n = M[i]->n(0);
+      if (n) hipLaunchKernelGGL(kr_dot_partial_kernel, dim3(nb(n)), dim3(BLOCK), 0, c.compute, n, a[i], b[i], partial.p + i * KR_BLOCKS);
+    }
+    hipLaunchKernelGGL(kr_dot_final_kernel, dim3(1), dim3(BLOCK), 0, c.compute, (int)(KR_BLOCKS * M.size()), partial.p, sc.p + slot);
+    HIPCHK(hipGetLastError());
+    if (c.kind == AMGX_COMM_RCCL && (c.nranks > 1 || M[0]->force_allgather))      // (world 1: only when the collectives are forced)
+      NCCLCHK(Rccl::get().AllReduce(sc.p + slot, sc.p + slot, 1, ncclDouble, ncclSum, c.nccl, c.compute));
+  }
+  double read(int slot) {
+    double v = 0.0;
+    HIPCHK(hipMemcpyAsync(&v, sc.p + slot, sizeof(double), hipMemcpyDeviceToHost, c.compute));
+    HIPCHK(hipStreamSynchronize(c.compute));
+    return v;
+  }
+  // y_i = A_i [v_i | ghosts of v]: exchange of the ghost part of vext behind the interior rows
+  template <class F>
+  void with_halo(std::vector<DevBuf<double>>& vext, F&& rows) {
+    std::vector<Comm::Item> it;
+    for (size_t i = 0; i < M.size(); ++i) it.push_back({&M[i]->halo[0], vext[i].p});
+    const int tk = c.exchange_begin(it);
+    const bool ov = M[0]->overlap;
+    if (ov) for (size_t i = 0; i < M.size(); ++i) rows(i, Handle::Span{Handle::PART_INT, M[i]->halo[0].n_int});
+    c.exchange_end(tk);
+    for (size_t i = 0; i < M.size(); ++i) rows(i, ov ? Handle::Span{Handle::PART_BND, M[i]->halo[0].n_int} : Handle::Span());
+  }
+  void precond(bool use_pre) {                   // w = C d
+    if (!use_pre) { for (size_t i = 0; i < M.size(); ++i) M[i]->top->copy(w[i].p, d(i), M[i]->n(0)); return; }
+    std::vector<const double*> bp(M.size());
+    std::vector<double*> xp(M.size());
+    for (size_t i = 0; i < M.size(); ++i) { bp[i] = d(i); xp[i] = w[i].p; }
+    dist_apply(c, bp.data(), xp.data(), 1, AMGX_DEVICE_PTR);
+  }
+  int pcg(const double* const* b, double* const* x, double tol, int maxit, bool use_pre, double* errs) {
+    const size_t R = M.size();
+    std::vector<const double*> wv(R), dv(R), sv(R);
+    for (size_t i = 0; i < R; ++i) { wv[i] = w[i].p; dv[i] = d(i); sv[i] = sext[i].p; }
+    // d = b - A x
+    for (size_t i = 0; i < R; ++i) M[i]->top->copy(sext[i].p, x[i], M[i]->n(0));
+    with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->residual(M[i]->top->lev[0].A, sext[i].p, b[i], d(i), sp); });
+    precond(use_pre);
+    for (size_t i = 0; i < R; ++i) M[i]->top->copy(sext[i].p, w[i].p, M[i]->n(0));
+    constexpr int SAS = 2;
+    int cur = 1;
+    dot(wv, dv, cur);
+    const double err0 = std::sqrt(std::fabs(read(cur)));
+    if (errs) errs[0] = err0;
+    if (err0 == 0.0) return 0;
+    int it = 0;
+    for (it = 1; it <= maxit; ++it) {
+      with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->mult(M[i]->top->lev[0].A, sext[i].p, w[i].p, sp); });     // w = A s
+      const int old = cur;
+      cur = 1 - cur;
+      dot(sv, wv, SAS);
+      for (size_t i = 0; i < R; ++i) {
+        const int64_t n = M[i]->n(0);
+        if (n) hipLaunchKernelGGL(kr_cg_update_kernel, dim3(Handle::grid_for(n)), dim3(BLOCK), 0, c.compute, n, sc.p, old, SAS, sext[i].p, w[i].p, x[i], d(i));
+      }
+      precond(use_pre);
+      dot(wv, dv, cur);
+      for (size_t i = 0; i < R; ++i) {
+        const int64_t n = M[i]->n(0);
+        if (n) hipLaunchKernelGGL(kr_xpby_kernel, dim3(Handle::grid_for(n)), dim3(BLOCK), 0, c.compute, n, sc.p, cur, old, w[i].p, sext[i].p);
+      }
+      HIPCHK(hipGetLastError());
+      const double err = std::sqrt(std::fabs(read(cur)));
+      if (errs) errs[it] = err;
+      if (err <= tol * err0) break;
+    }
+    if (it > maxit) it = maxit;
+    return it;
+  }
+};
 
 }  // namespace amgx
 
@@ -760,6 +940,7 @@ int amgx_comm_set_stream(amgx_comm cc, void* s) {
     HIPCHK(hipStreamSynchronize(c.compute));
     HIPCHK(hipStreamSynchronize(c.comm_stream));
     c.compute = ns;
+    c.drop_graphs();
     for (amgx::Dist* d : c.members) { d->top->drop_graphs(); d->tail->drop_graphs(); d->top->stream = ns; d->tail->stream = ns; }
   });
 }
@@ -776,6 +957,15 @@ int amgx_comm_info(amgx_comm cc, int32_t* kind, int32_t* n_ranks, int32_t* rank,
     if (n_exchanges) *n_exchanges = c.n_exchanges;
   });
 }
+
+int amgx_comm_graph_info(amgx_comm cc, int32_t* enabled, int64_t* n_graphs, int64_t* n_replays) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (enabled) *enabled = c.graph_ok ? 1 : 0;
+    if (n_graphs) *n_graphs = (int64_t)c.graphs.size();
+    if (n_replays) *n_replays = c.n_graph_replays;
+  });
+}
+const char* amgx_comm_graph_note(amgx_comm c) { return (c && c->c) ? c->c->graph_note.c_str() : ""; }
 
 int amgx_dist_create(amgx_comm cc, const amgx_dist_desc* desc, amgx_dist* out) {
   return cguard(cc, [&](amgx::Comm& c) {
@@ -812,6 +1002,23 @@ int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail) {
 
 int amgx_dist_apply(amgx_comm cc, const double* const* b, double* const* x, int b_status, int flags) {
   return cguard(cc, [&](amgx::Comm& c) { amgx::dist_apply(c, b, x, b_status, flags); });
+}
+
+int amgx_dist_pcg(amgx_comm cc, const double* const* b, double* const* x, double tol, int maxit, int use_precond, int flags, double* errs,
+                  int32_t* iters) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (!b || !x || maxit < 0) throw amgx::Err("amgx_dist_pcg: bad arguments");
+    if (!(flags & AMGX_DEVICE_PTR)) throw amgx::Err("amgx_dist_pcg: device vectors only (AMGX_DEVICE_PTR)");
+    if (c.members.empty() || (c.kind == AMGX_COMM_LOCAL && (int)c.members.size() != c.nranks)) throw amgx::Err("amgx_dist_pcg: not all ranks have a hierarchy");
+    for (size_t i = 0; i < c.members.size(); ++i) {
+      amgx::Dist* d = c.members[i];
+      if ((!b[i] || !x[i]) && d->n(0) > 0) throw amgx::Err("amgx_dist_pcg: null vector");
+      if (b[i] == d->bext[0].p || x[i] == d->bext[0].p) throw amgx::Err("amgx_dist_pcg: b / x alias the cycle's right-hand-side buffer (it holds the residual)");
+    }
+    amgx::DistKrylov K(c);
+    const int it = K.pcg(b, x, tol, maxit, use_precond != 0, errs);
+    if (iters) *iters = it;
+  });
 }
 
 // ---- stand-alone halo maps (the DCCMap surface: python_smoothers / tests use it without a hierarchy) -----------------

@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(BLOCK) void dense_gemv_kernel(int n, const double* 
 // ONE dense GEMV that streams n^2 * 8 bytes (n = 1261 at cfg 2: 12.7 MB, ~6 us) -- 288 GB of HBM buy latency.
 //   dense_unit_kernel      : v = e_j
 //   dense_transpose_kernel : B[i][j] = Bt[j][i]   (Bt row j = B e_j as the sub-cycle delivers it)
-//   dense_op_gemv_kernel   : y = B x, one wave per row, 16-byte loads, rows padded to an even length `ld`
+//   dense_op_gemv_kernel   : y = B x, one wave per row, 16-byte loads, rows padded to an even length `ld` (x needs 16-byte alignment)
 __global__ __launch_bounds__(BLOCK) void dense_unit_kernel(int64_t n, int64_t j, double* __restrict__ v) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < n) v[i] = i == j ? 1.0 : 0.0;
@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(BLOCK) void dense_op_gemv_kernel(int n, int ld, con
   if (row >= n) return;
   const double2* __restrict__ m2 = reinterpret_cast<const double2*>(M + (int64_t)row * ld);
   const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
-  const int np = ld >> 1;                       // pairs per row (x is allocated with an even length, the pad entry of M is 0)
+  const int np = n >> 1;                        // full pairs per row; an odd last entry is added by lane 0 (x has exactly n entries)
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int c = lane;
   for (; c + 3 * WAVE < np; c += 4 * WAVE) {    // four independent 16-byte loads in flight per lane
@@ -1542,6 +1542,7 @@ __global__ __launch_bounds__(BLOCK) void dense_op_gemv_kernel(int n, int ld, con
     a3 += m3.x * v3.x + m3.y * v3.y;
   }
   for (; c < np; c += WAVE) { const double2 m0 = m2[c], v0 = x2[c]; a0 += m0.x * v0.x + m0.y * v0.y; }
+  if ((n & 1) && lane == 0) a1 += M[(int64_t)row * ld + (n - 1)] * x[n - 1];
   double acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
   for (int o = WAVE >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);

@@ -265,6 +265,131 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
   return nn;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SPW agglomeration with the scalar strength of connection, as the reference runs it for H1 (and for elasticity with
+// crs_robust = false): src/base/coarsening/spw_agg_impl.hpp
+//   FormAgglomerates_impl (:1436-1830): numRounds (3) pairing rounds on successively contracted graphs + one orphan round
+//   PairingIteration / IterateVertsRev (:943-1014, 1072-1263): vertices in REVERSE index order; in the first round the
+//       unhandled neighbours of lower degree are visited before the vertex itself (fewer orphans)
+//   FindNeib3Step (:637-775) with the scalar weights of FindNeighborToMatch (:778-867) and CalcApproxSOC
+//       (agglomerator_utils.hpp:243-266): soc_ij = w_ij / sqrt(maxTrOD_i maxTrOD_j) (GEOM average), computed for ALL
+//       neighbours, partner = an unhandled neighbour with soc_ij >= 0.25 max_k soc_ik.  For scalar data the reference's
+//       "robust" weights are all 1, i.e. any neighbour that passes the filter is acceptable; the strongest one is taken here.
+//   SPWAggData::Map (:424-628): coarse edge weight = sum of the fine edge weights between two aggregates; maxTrOD of a coarse
+//       vertex = max over its coarse edges AND over the maxTrOD of all its members -- a stiff region that has collapsed into
+//       one vertex keeps the scale of what it swallowed, so its remaining soft connections stay weak
+//   JoiningIteration / FindNeighborToJoin (:870-940, 1265-1365; CalcApproxJoinSOC agglomerator_utils.hpp:1011-1032):
+//       aggregates that still consist of ONE base vertex ("orphans") join a neighbouring real aggregate over the connection
+//       with soc = w_Oj / maxTrOD_O >= 0.25 of the orphan's largest
+// maxTrOD is computed afresh from the edge weights of every level (VertexAgglomerator::InitializeAggData,
+// agglomerator_impl.hpp:66-200); not restated: fixed aggregates, L2-dominant vertex collapse (vert_thresh = 0 by default),
+// the MPI equivalence-class rules, the energy (robust) SOC of matrix-valued vertex data.
+constexpr double SPW_REL_THRESH = 0.25;     // cfg.scalRelThresh (spw_agg_impl.hpp:1410)
+
+static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, const std::vector<uint8_t>& handled, int64_t v, bool join,
+                                const std::vector<uint8_t>* joinable) {
+  double mx = 0.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+    const int32_t j = g.adj[k];
+    const double den = join ? mt[v] : std::sqrt(mt[v] * mt[j]);
+    if (den > 0.0) mx = std::max(mx, g.w[k] / den);
+  }
+  if (!(mx > 0.0)) return -1;
+  const double th = SPW_REL_THRESH * mx;
+  int32_t best = -1;
+  double bw = -1.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+    const int32_t j = g.adj[k];
+    if (join ? !(*joinable)[j] : handled[j]) continue;
+    const double den = join ? mt[v] : std::sqrt(mt[v] * mt[j]);
+    if (!(den > 0.0)) continue;
+    const double soc = g.w[k] / den;
+    if (soc >= th && soc > bw) { bw = soc; best = j; }
+  }
+  return best;
+}
+
+int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const Options& o, std::vector<int32_t>& agg, int& rounds_done) {
+  const int64_t n = G0.n;
+  agg.assign(n, -1);
+  rounds_done = 0;
+  int64_t nfree = 0;
+  for (int64_t i = 0; i < n; i++) nfree += free[i] ? 1 : 0;
+  if (nfree == 0) return 0;
+  const int num_rounds = std::max(1, o.spw_rounds);
+  Graph cur;
+  const Graph* g = &G0;
+  std::vector<double> mt(n, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) { double m = 0; for (int64_t k = G0.ptr[i]; k < G0.ptr[i + 1]; k++) m = std::max(m, G0.w[k]); mt[i] = m; }
+  std::vector<int32_t> size;               // base vertices per current vertex
+  std::vector<int32_t> map;
+  int64_t ncur = 0;
+  for (int round = 0; round < num_rounds; round++) {
+    const int64_t m = g->n;
+    std::vector<uint8_t> handled(m, 0);
+    if (round == 0) for (int64_t i = 0; i < m; i++) handled[i] = free[i] ? 0 : 1;
+    map.assign(m, -1);
+    int64_t nn = 0;
+    auto make_pair = [&](int64_t v) {
+      const int32_t nb = spw_find_partner(*g, mt, handled, v, false, nullptr);
+      const int32_t cv = (int32_t)nn++;
+      if (nb >= 0) { map[nb] = cv; handled[nb] = 1; }
+      map[v] = cv;
+      handled[v] = 1;
+    };
+    std::vector<int32_t> ld;
+    for (int64_t v = m - 1; v >= 0; v--) {
+      if (handled[v]) continue;
+      if (round == 0) {
+        // neighbours of lower degree first, by ascending degree (IterateVertsRev<PREFER_LDEG = true>)
+        const int64_t deg = g->ptr[v + 1] - g->ptr[v];
+        ld.clear();
+        for (int64_t k = g->ptr[v]; k < g->ptr[v + 1]; k++) {
+          const int32_t j = g->adj[k];
+          if (!handled[j] && g->ptr[j + 1] - g->ptr[j] < deg) ld.push_back(j);
+        }
+        std::stable_sort(ld.begin(), ld.end(), [&](int32_t a, int32_t b) { return g->ptr[a + 1] - g->ptr[a] < g->ptr[b + 1] - g->ptr[b]; });
+        for (int32_t j : ld) if (!handled[j]) make_pair(j);
+      }
+      if (!handled[v]) make_pair(v);
+    }
+    if (nn == 0) break;
+    // compose with the base-level map, contract the graph, carry the scales
+    if (round == 0) { for (int64_t i = 0; i < n; i++) agg[i] = free[i] ? map[i] : -1; }
+    else for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = map[agg[i]];
+    Graph next = contract(*g, map, nn);
+    std::vector<double> nmt(nn, 0.0);
+    for (int64_t I = 0; I < nn; I++) for (int64_t k = next.ptr[I]; k < next.ptr[I + 1]; k++) nmt[I] = std::max(nmt[I], next.w[k]);
+    for (int64_t i = 0; i < m; i++) if (map[i] >= 0) nmt[map[i]] = std::max(nmt[map[i]], mt[i]);
+    mt = std::move(nmt);
+    cur = std::move(next);
+    g = &cur;
+    ncur = nn;
+    rounds_done++;
+  }
+  if (rounds_done == 0) return 0;
+  // orphan round
+  size.assign(ncur, 0);
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) size[agg[i]]++;
+  std::vector<int32_t> fin(ncur, -1);
+  int64_t nn = 0;
+  bool any_orphan = false;
+  std::vector<uint8_t> joinable(ncur, 0);
+  for (int64_t I = 0; I < ncur; I++) { if (size[I] > 1) { joinable[I] = 1; fin[I] = (int32_t)nn++; } else any_orphan = true; }
+  if (o.spw_orphan_round && any_orphan) {
+    for (int64_t I = ncur - 1; I >= 0; I--) {
+      if (joinable[I]) continue;
+      const int32_t J = spw_find_partner(cur, mt, joinable, I, true, &joinable);
+      fin[I] = J >= 0 ? fin[J] : (int32_t)nn++;
+    }
+  } else {
+    for (int64_t I = 0; I < ncur; I++) if (fin[I] < 0) fin[I] = (int32_t)nn++;
+  }
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = fin[agg[i]];
+  return nn;
+}
+
 // scalar prolongation weights (n_f x n_c CSR): aux-matrix smoothed piecewise prolongation
 BCSR prolongation_weights(const Graph& G0, const std::vector<int32_t>& agg, int64_t nc, const Options& o) {
   const int64_t n = G0.n;
@@ -529,7 +654,8 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         int r = 0;
         int64_t cur_free_n = 0;
         for (auto f : cur_free) cur_free_n += f;
-        const int64_t snc = aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
+        const int64_t snc = o.spw ? aggregate_spw(G, cur_free, o, sagg, r)
+                                  : aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
         if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }
         // robust_soc: what is left are vertices that must not be merged; a level that is barely smaller than its parent costs a
         // smoother and buys nothing (the coarsest-level inverse takes over)

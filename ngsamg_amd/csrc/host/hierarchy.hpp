@@ -19,7 +19,11 @@ struct Options {
   double sp_omega = 1.0;
   int sp_max_per_row = 3;
   double sp_min_frac = 0.08;
-  // pairwise aggregation
+  // agglomeration: spw = 1: the reference's SPW rule with scalar strength (spw_agg_impl.hpp; hierarchy.cpp aggregate_spw):
+  // spw_rounds pairing rounds per coarsening step + orphan round; 0: target-driven pairwise rounds (rounds 1 - 2 of this build)
+  int spw = 1;
+  int spw_rounds = 3;            // ngs_amg_spw_rounds (spw_agg.hpp:28)
+  int spw_orphan_round = 1;      // ngs_amg_spw_orphan_treatment (spw_agg.hpp:32)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level
   // smoother diagonals

@@ -243,18 +243,36 @@ def _vexp(idx, bs):
     return (idx[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)
 
 
-def _assemble_owned(rank, pgrid, box, kind, bs, mu, lam, dirichlet, jitter, seed, extent=None):
-    """Rows of the global P1 matrix (kind 0: Poisson, 1: elasticity, 2: elasticity with rotations) owned by `rank` (box of
-    `box` vertices per rank), columns [owned | ghost].  Block problems are held as scalar CSR with AoS numbering."""
+def grid_cuts(pgrid, gshape):
+    """balanced split of a global vertex grid over a box of ranks: cuts[d][i] = first vertex of rank coordinate i along axis d
+    (rank coordinate i owns [cuts[d][i], cuts[d][i + 1])); equal boxes when gshape[d] is a multiple of pgrid[d]"""
+    return [np.asarray([(i * int(gshape[d])) // int(pgrid[d]) for i in range(int(pgrid[d]) + 1)], dtype=np.int64) for d in range(len(pgrid))]
+
+
+def _assemble_owned(rank, pgrid, box, kind, bs, mu, lam, dirichlet, jitter, seed, extent=None, gshape=None, coords="hash"):
+    """Rows of the global P1 matrix (kind 0: Poisson, 1: elasticity, 2: elasticity with rotations) owned by `rank`, columns
+    [owned | ghost].  Either every rank holds a box of `box` vertices (global grid = pgrid * box: weak scaling), or the
+    global grid `gshape` is given and split into balanced, possibly unequal boxes (grid_cuts: strong scaling of ONE problem).
+    coords: "hash" = counter-based jitter (hashed_coords: no rank needs more than its own box); "rng" = the positions of
+    fem.poisson_fast / elasticity_fast for the same (gshape, jitter, seed), i.e. exactly the single-GPU problem, cut into
+    pieces.  Block problems are held as scalar CSR with AoS numbering."""
     dim = len(pgrid)
-    gshape = tuple(pgrid[d] * box[d] for d in range(dim))
+    if gshape is None:
+        gshape = tuple(int(pgrid[d]) * int(box[d]) for d in range(dim))
+    gshape = tuple(int(g) for g in gshape)
+    cuts = grid_cuts(pgrid, gshape)
     pc = np.unravel_index(rank, pgrid)
-    lo = [pc[d] * box[d] for d in range(dim)]
-    hi = [lo[d] + box[d] for d in range(dim)]
+    lo = [int(cuts[d][pc[d]]) for d in range(dim)]
+    hi = [int(cuts[d][pc[d] + 1]) for d in range(dim)]
+    box = tuple(hi[d] - lo[d] for d in range(dim))
     elo = [max(0, lo[d] - 1) for d in range(dim)]
     ehi = [min(gshape[d], hi[d] + 1) for d in range(dim)]
     eshape = tuple(ehi[d] - elo[d] for d in range(dim))
-    X = hashed_coords(elo, ehi, gshape, jitter, seed)
+    if coords == "rng":
+        from .fem import _jittered_coords
+        X = np.ascontiguousarray(_jittered_coords(gshape, jitter, seed)[tuple(slice(elo[d], ehi[d]) for d in range(dim))])
+    else:
+        X = hashed_coords(elo, ehi, gshape, jitter, seed)
     if extent is not None:
         X = X * np.asarray(extent, dtype=float)
     ne = int(np.prod(eshape))
@@ -282,11 +300,14 @@ def _assemble_owned(rank, pgrid, box, kind, bs, mu, lam, dirichlet, jitter, seed
     is_owned = np.zeros(ne, dtype=bool)
     is_owned[owned_e] = True
     ghost_e = used[~is_owned[used]]
-    # owner and owner-local index of every ghost
+    # owner and owner-local (lexicographic in the owner's own box) index of every ghost
     gcoord = np.stack(np.unravel_index(ghost_e, eshape), axis=1) + np.asarray(elo)
-    gpc = gcoord // np.asarray(box)
-    g_owner = np.ravel_multi_index(tuple(gpc.T), pgrid)
-    g_rindex = np.ravel_multi_index(tuple((gcoord - gpc * np.asarray(box)).T), box)
+    gpc = np.stack([np.searchsorted(cuts[d], gcoord[:, d], side="right") - 1 for d in range(dim)], axis=1) if ghost_e.size else np.zeros((0, dim), dtype=np.int64)
+    g_owner = np.ravel_multi_index(tuple(gpc.T), pgrid) if ghost_e.size else np.zeros(0, dtype=np.int64)
+    g_rindex = np.zeros(ghost_e.size, dtype=np.int64)
+    for d in range(dim):
+        olo, ohi = cuts[d][gpc[:, d]], cuts[d][gpc[:, d] + 1]
+        g_rindex = g_rindex * (ohi - olo) + (gcoord[:, d] - olo)
     order = np.lexsort((g_rindex, g_owner))
     ghost_e, g_owner, g_rindex = ghost_e[order], g_owner[order], g_rindex[order]
     newidx = np.full(ne, -1, dtype=np.int64)
@@ -314,17 +335,19 @@ def _assemble_owned(rank, pgrid, box, kind, bs, mu, lam, dirichlet, jitter, seed
     return st
 
 
-def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, seed=1):
-    """Rows of the global P1 Poisson matrix owned by `rank` (box of `box` vertices per rank), columns [owned | ghost]."""
-    return _assemble_owned(rank, pgrid, box, 0, 1, 1.0, 0.0, dirichlet, jitter, seed)
+def assemble_poisson_owned(rank, pgrid, box, dirichlet="right|top", jitter=0.2, seed=1, gshape=None, coords="hash"):
+    """Rows of the global P1 Poisson matrix owned by `rank`, columns [owned | ghost]: a box of `box` vertices per rank, or
+    (gshape given, box ignored) this rank's piece of the balanced split of ONE global grid"""
+    return _assemble_owned(rank, pgrid, box, 0, 1, 1.0, 0.0, dirichlet, jitter, seed, gshape=gshape, coords=coords)
 
 
-def assemble_elasticity_owned(rank, pgrid, box, rotations=False, mu=1.0, lam=0.5, dirichlet="left", jitter=0.2, seed=1, extent=None):
+def assemble_elasticity_owned(rank, pgrid, box, rotations=False, mu=1.0, lam=0.5, dirichlet="left", jitter=0.2, seed=1, extent=None,
+                              gshape=None, coords="hash"):
     """The same for 3D / 2D linear elasticity: dim x dim blocks, or (dim + nrot)^2 blocks with rotational dofs
     (the model problems of ngsamg_amd.fem.elasticity_fast); the state carries bs and is used with energy = 1"""
     dim = len(pgrid)
     bs = dim + (dim * (dim - 1) // 2 if rotations else 0)
-    return _assemble_owned(rank, pgrid, box, 2 if rotations else 1, bs, mu, lam, dirichlet, jitter, seed, extent)
+    return _assemble_owned(rank, pgrid, box, 2 if rotations else 1, bs, mu, lam, dirichlet, jitter, seed, extent, gshape=gshape, coords=coords)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -854,6 +877,14 @@ class DistributedAMG:
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
         self._alloc()
 
+    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True):
+        """collective preconditioned CG on the rank-partitioned level-0 operator with this cycle as preconditioner
+        (amgx_dist_pcg; the reference's driver is NGSolve's CGSolver on ParallelVectors, tests/h1/amg_utils.py:337-363).
+        bs[i], xs[i]: owned level-0 CUDA tensors of local rank i; xs hold the initial guess.  Returns (iterations, errs)."""
+        if self._dev is None:
+            raise NgsAMGError("pcg: needs the device driver (no CPU path)")
+        return self._dev.pcg(bs, xs, tol=tol, maxsteps=maxsteps, use_pre=use_pre)
+
     def level_k_map(self, i):
         """level k of local rank i in its [owned | ghost] layout -> index in the gathered (replicated) vector"""
         sk = self.dist_levels[self.k][i]
@@ -1309,6 +1340,35 @@ class _DeviceDist:
         ne = C.c_int64()
         self._ck(self._lib.amgx_comm_info(self._comm, None, None, None, C.byref(ne)))
         return ne.value
+
+    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True):
+        """amgx_dist_pcg: collective PCG with the rank-partitioned cycle as preconditioner; xs hold the initial guess and
+        receive the solution.  Returns (iterations, err_0 .. err_iterations)."""
+        import torch
+        st = int(torch.cuda.current_stream().cuda_stream)
+        if st != self._stream:
+            self._ck(self._lib.amgx_comm_set_stream(self._comm, C.c_void_p(st)))
+            self._stream = st
+        n = len(self._dists)
+        for i, (b, x) in enumerate(zip(bs, xs)):
+            m = self.amg.dist_levels[0][i].n * _bs(self.amg.dist_levels[0][i])
+            for v, nm in ((b, "b"), (x, "x")):
+                if not (v.is_cuda and v.dtype == torch.float64 and v.is_contiguous() and v.numel() == m):
+                    raise NgsAMGError(f"{nm}[{i}]: need a contiguous float64 CUDA tensor with {m} entries")
+        pb = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        errs = np.zeros(int(maxsteps) + 1)
+        it = C.c_int32()
+        self._ck(self._lib.amgx_dist_pcg(self._comm, pb, px, float(tol), int(maxsteps), int(bool(use_pre)), _lib.AMGX_DEVICE_PTR,
+                                         _lib.ptr(errs, C.c_double), C.byref(it)))
+        return it.value, errs[:it.value + 1]
+
+    def graph_info(self):
+        """whole-cycle graph of amgx_dist_apply: enabled?, captured cycles, applications served by a graph launch, note"""
+        en, ng, nr = C.c_int32(), C.c_int64(), C.c_int64()
+        self._ck(self._lib.amgx_comm_graph_info(self._comm, C.byref(en), C.byref(ng), C.byref(nr)))
+        return {"enabled": bool(en.value), "graphs": ng.value, "replays": nr.value,
+                "note": (self._lib.amgx_comm_graph_note(self._comm) or b"").decode()}
 
     def synchronize(self):
         self._ck(self._lib.amgx_comm_synchronize(self._comm))

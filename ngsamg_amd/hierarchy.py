@@ -91,7 +91,9 @@ _OPTION_KEYS = {
     "max_levels": int, "max_coarse_size": int, "first_aaf": float, "aaf": float, "enable_sp": int,
     "sp_omega": float, "sp_max_per_row": int, "sp_min_frac": float, "soc_thresh": float, "max_rounds": int,
     "regularize_cmats": int, "log_level": int, "enable_multistep": int, "robust_soc": int,
+    "spw": int, "spw_rounds": int, "spw_orphan_round": int,
 }
+_OPTION_ALIASES = {"spw_orphan_treatment": "spw_orphan_round"}        # the reference's flag name (spw_agg.hpp:60)
 
 
 def make_options(dim, energy, **kw):
@@ -100,6 +102,7 @@ def make_options(dim, energy, **kw):
     lib.amgh_default_options(C.byref(o), int(dim), int(energy))
     for k, v in kw.items():
         key = k[len("ngs_amg_"):] if k.startswith("ngs_amg_") else k
+        key = _OPTION_ALIASES.get(key, key)
         if key in _OPTION_KEYS and v is not None:
             if key == "log_level" and isinstance(v, str):
                 v = {"none": 0, "basic": 1, "normal": 2, "extra": 3, "debug": 4}.get(v, 0)

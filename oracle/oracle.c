@@ -702,3 +702,78 @@ int orc_pcg(orc_handle* h, const orc_matrix* Ain, const double* b, double* x, do
   free(d); free(w); free(s);
   return 0;
 }
+
+int orc_gmres(orc_handle* h, const orc_matrix* Ain, const double* b, double* x, double tol, int maxit, int restart,
+              double* errs, int* iters) {
+  /* stand-in for ngsolve.krylovspace.GMRes as a caller of the preconditioner: restarted GMRES(m),
+   * left-preconditioned (minimises |C (b - A x)| over the Krylov space of C A), MODIFIED Gram-Schmidt, Givens rotations;
+   * err_k = |C r_k| (the recurrence value), stop at err_k <= tol * err_0.  Written independently of the device solver
+   * (which orthogonalises by classical Gram-Schmidt with one re-orthogonalisation pass): equal histories up to rounding. */
+  const orc_matrix* A = Ain ? Ain : (h ? &h->lev[0].A : NULL);
+  if (!A || restart < 1) return fail("orc_gmres: bad arguments");
+  g_cur = h;
+  const int64_t n = A->n_rows * A->br;
+  const int m = restart;
+  double* V = (double*)malloc(sizeof(double) * n * (size_t)(m + 1));
+  double* t = (double*)malloc(sizeof(double) * n);
+  double* H = (double*)calloc((size_t)(m + 1) * m, sizeof(double));
+  double* cs = (double*)calloc(m, sizeof(double));
+  double* sn = (double*)calloc(m, sizeof(double));
+  double* g = (double*)calloc(m + 1, sizeof(double));
+  double* y = (double*)calloc(m, sizeof(double));
+  int it = 0;
+  double err0 = -1.0;
+  while (it < maxit) {
+    spmv(A, x, t, 1, 0.0, b);                                   /* t = b - A x */
+    if (h) do_cycle(h, V, t); else memcpy(V, t, sizeof(double) * n);
+    const double beta = sqrt(dot(V, V, n));
+    if (err0 < 0.0) { err0 = beta; if (errs) errs[0] = err0; }
+    if (beta == 0.0 || beta <= tol * err0) break;
+    for (int64_t i = 0; i < n; i++) V[i] /= beta;
+    for (int i = 0; i <= m; i++) g[i] = 0.0;
+    g[0] = beta;
+    int k = 0, done = 0;
+    for (int j = 0; j < m && it < maxit; j++) {
+      it++;
+      double* vj = V + (size_t)j * n;
+      double* w = V + (size_t)(j + 1) * n;
+      spmv(A, vj, t, 0, 0.0, NULL);
+      if (h) do_cycle(h, w, t); else memcpy(w, t, sizeof(double) * n);
+      for (int i = 0; i <= j; i++) {                            /* modified Gram-Schmidt */
+        const double* vi = V + (size_t)i * n;
+        const double hij = dot(w, vi, n);
+        H[(size_t)i * m + j] = hij;
+        for (int64_t q = 0; q < n; q++) w[q] -= hij * vi[q];
+      }
+      const double hn = sqrt(dot(w, w, n));
+      if (hn > 0.0) for (int64_t q = 0; q < n; q++) w[q] /= hn;
+      double hj1 = hn;
+      for (int i = 0; i < j; i++) {
+        const double a = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = a;
+      }
+      const double den = hypot(H[(size_t)j * m + j], hj1);
+      cs[j] = den > 0 ? H[(size_t)j * m + j] / den : 1.0;
+      sn[j] = den > 0 ? hj1 / den : 0.0;
+      H[(size_t)j * m + j] = den;
+      if (j + 1 < m) H[(size_t)(j + 1) * m + j] = 0.0;
+      g[j + 1] = -sn[j] * g[j];
+      g[j] = cs[j] * g[j];
+      k = j + 1;
+      const double err = fabs(g[j + 1]);
+      if (errs) errs[it] = err;
+      if (err <= tol * err0 || hn == 0.0) { done = 1; break; }
+    }
+    for (int i = k - 1; i >= 0; i--) {
+      double s = g[i];
+      for (int q = i + 1; q < k; q++) s -= H[(size_t)i * m + q] * y[q];
+      y[i] = H[(size_t)i * m + i] != 0.0 ? s / H[(size_t)i * m + i] : 0.0;
+    }
+    for (int i = 0; i < k; i++) { const double* vi = V + (size_t)i * n; for (int64_t q = 0; q < n; q++) x[q] += y[i] * vi[q]; }
+    if (done) break;
+  }
+  if (iters) *iters = it;
+  free(V); free(t); free(H); free(cs); free(sn); free(g); free(y);
+  return 0;
+}

@@ -101,6 +101,10 @@ int orc_matvec(orc_handle* h, int level, const double* x, double* y);
  *   Returns the iteration count in *iters.  h may be NULL (no preconditioner) if A is given. */
 int orc_pcg(orc_handle* h, const orc_matrix* A, const double* b, double* x, double tol, int maxit,
             double* errs, int* iters);
+/* restarted GMRES(restart), left-preconditioned, modified Gram-Schmidt (NGSolve GMRes stand-in): err_k = |C r_k|, stops at
+ * err_k <= tol * err_0; errs has room for maxit+1 entries */
+int orc_gmres(orc_handle* h, const orc_matrix* A, const double* b, double* x, double tol, int maxit, int restart,
+              double* errs, int* iters);
 /* number of OpenMP threads used for Jacobi / SpMV / transfers (GS stays sequential) */
 void orc_set_threads(int n);
 /* multi-threaded CPU baseline only: replace the borrowed level arrays by private copies whose pages are first written

@@ -62,6 +62,7 @@ def lib():
     L.orc_coarse_solve.argtypes = [vp, c_f64p, c_f64p]
     L.orc_matvec.argtypes = [vp, C.c_int, c_f64p, c_f64p]
     L.orc_pcg.argtypes = [vp, C.POINTER(orc_matrix), c_f64p, c_f64p, C.c_double, C.c_int, c_f64p, C.POINTER(C.c_int)]
+    L.orc_gmres.argtypes = [vp, C.POINTER(orc_matrix), c_f64p, c_f64p, C.c_double, C.c_int, C.c_int, c_f64p, C.POINTER(C.c_int)]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_threads.restype = None
     L.orc_first_touch.argtypes = [vp]
@@ -254,6 +255,17 @@ class Oracle:
         it = C.c_int()
         self._ck(lib().orc_pcg(self._h if precond else None, C.byref(_mat(self.levels[0].A)), _p(b, C.c_double),
                                _p(x, C.c_double), float(tol), int(maxit), _p(errs, C.c_double), C.byref(it)))
+        return x, it.value, errs[: it.value + 1]
+
+
+    def gmres(self, b, x0=None, tol=1e-8, maxit=200, restart=30, precond=True):
+        """restarted GMRES(restart), left-preconditioned with this hierarchy's cycle (oracle.c orc_gmres, modified Gram-Schmidt)"""
+        b = _vec(b)
+        x = np.zeros_like(b) if x0 is None else np.array(x0, dtype=np.float64)
+        errs = np.zeros(maxit + 1)
+        it = C.c_int()
+        self._ck(lib().orc_gmres(self._h if precond else None, C.byref(_mat(self.levels[0].A)), _p(b, C.c_double),
+                                 _p(x, C.c_double), float(tol), int(maxit), int(restart), _p(errs, C.c_double), C.byref(it)))
         return x, it.value, errs[: it.value + 1]
 
 

@@ -148,6 +148,7 @@ def main():
             for _ in range(3):
                 amg.Mult([b], [x])
         torch.cuda.synchronize()
+        gi = amg._dev.graph_info()
         loop_ok = self_loop_halo(lib, _lib, amg._dev._comm, torch, f"cuda:{dev}") if world == 1 else True
         glv = amg.global_levels()
         allb, allx = [None] * world, [None] * world
@@ -159,7 +160,9 @@ def main():
             err = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
             tol = (1e-12 if args.sm == "jacobi" else 1e-10) if not args.elast else (1e-11 if args.sm == "jacobi" else 1e-10)
             print(f"world={world} pgrid={pg} box={args.box}^3 sm={args.sm} elast={args.elast or 'no'} fold={amg.fold} distributed levels={amg.k} "
-                  f"exchanges per cycle={amg._dev.n_exchanges() // 3} rel.err vs serial oracle = {err:.3e} self-loop halo ok = {loop_ok}")
+                  f"exchanges per cycle={amg._dev.n_exchanges() // 3} rel.err vs serial oracle = {err:.3e} self-loop halo ok = {loop_ok} "
+                  f"graph enabled = {gi['enabled']} graphs = {gi['graphs']} replays = {gi['replays']} note = '{gi['note']}' "
+                  f"allgather = {os.environ.get('AMGX_DIST_FORCE_ALLGATHER', 'default')}")
             ok = err < tol and loop_ok
             print("RCCL CHECK", "PASSED" if ok else "FAILED")
             code = 0 if ok else 1

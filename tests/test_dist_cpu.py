@@ -276,3 +276,55 @@ def test_loopback_block_hybrid_gs_matches_serial_hybrid_oracle(R, box, dim, dmin
     b = rng.standard_normal(glv[0].A.n_rows) * glv[0].free
     _, it, errs = orc.pcg(b, tol=1e-8, maxit=80)
     assert errs[-1] < 1e-8 * errs[0] and it < 60
+
+
+# ---- strong scaling: ONE global grid cut into balanced, unequal pieces (bench.py --gpus N) ------------------------------
+
+def _strong_states(pg, gshape, coords="rng"):
+    R = int(np.prod(pg))
+    return [D.assemble_poisson_owned(r, pg, None, gshape=gshape, coords=coords) for r in range(R)]
+
+
+@pytest.mark.parametrize("pg,gshape", [((3, 1, 1), (11, 9, 10)), ((2, 3, 2), (11, 9, 10)), ((8, 1, 1), (27, 6, 5)), ((3, 2), (14, 11))])
+def test_strong_split_is_the_single_gpu_matrix(pg, gshape):
+    """the pieces of the balanced split, glued together, are the matrix fem.poisson_fast assembles for the whole grid
+    (same vertex positions, same assembly): N > 1 of bench.py solves the problem N = 1 solves"""
+    import scipy.sparse as sp
+    from ngsamg_amd import fem
+    p = fem.poisson_fast(gshape, dirichlet="right|top", jitter=0.2, seed=1)
+    Ag = sp.csr_matrix((p.val, p.col, p.rowptr), shape=(p.n, p.n))
+    dim = len(gshape)
+    cuts = D.grid_cuts(pg, gshape)
+    assert all(c[0] == 0 and c[-1] == g and np.all(np.diff(c) >= g // q) for c, g, q in zip(cuts, gshape, pg))
+    sts = _strong_states(pg, gshape)
+    assert sum(s.n for s in sts) == p.n
+    gids = []
+    for s in sts:
+        pc = np.unravel_index(s.rank, pg)
+        I = np.meshgrid(*[np.arange(cuts[d][pc[d]], cuts[d][pc[d] + 1]) for d in range(dim)], indexing="ij")
+        gids.append(np.ravel_multi_index([i.reshape(-1) for i in I], gshape))
+    for s in sts:
+        gcol = np.concatenate([gids[s.rank], np.asarray([gids[o][ri] for o, ri in zip(s.ghost_owner, s.ghost_rindex)], dtype=np.int64)])
+        A = sp.csr_matrix(s.A).tocoo()
+        Ar = sp.csr_matrix((A.data, (A.row, gcol[A.col])), shape=(s.n, p.n))
+        assert abs(Ar - Ag[gids[s.rank]]).max() < 1e-14
+        assert np.array_equal(s.free, p.free[gids[s.rank]])
+
+
+@pytest.mark.parametrize("pg,gshape,dmin", [((3, 1, 1), (20, 12, 12), 100), ((5, 1, 1), (23, 9, 10), 50), ((2, 2, 2), (15, 13, 11), 20)])
+@pytest.mark.parametrize("sm", ["jacobi", "gs"])
+def test_strong_split_cycle_matches_serial_oracle(pg, gshape, dmin, sm):
+    """unequal pieces through the whole distributed setup and cycle (CPU stage backend) == serial oracle"""
+    R = int(np.prod(pg))
+    comm = D.LoopbackComm(R)
+    states = _strong_states(pg, gshape)
+    assert len({s.n for s in states}) > 1          # the pieces really differ in size
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=dmin, backend=cpu_backend(sm_type=sm), max_coarse_size=10, sm_type=sm)
+    rng = np.random.default_rng(1)
+    bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free) for s in states]
+    xs = [torch.zeros(s.n, dtype=torch.float64) for s in states]
+    amg.Mult(bs, xs)
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg)).apply(np.concatenate([b.numpy() for b in bs]))
+    got = np.concatenate([x.numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= (1e-12 if sm == "jacobi" else 1e-10) * np.linalg.norm(ref)

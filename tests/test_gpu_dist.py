@@ -110,13 +110,13 @@ def test_loopback_device_reproduces_hybrid_fixture(name, R, box, dim, dmin, sm, 
     assert np.linalg.norm(got - ref) <= tol * np.linalg.norm(ref)
 
 
-def _run_check(*argv, timeout=600):
+def _run_check(*argv, timeout=600, extra_env=None):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # the launcher's own watchdog (kills exactly its rank processes) fires before this timeout would kill only the launcher
-    env = dict(os.environ, NGSAMG_CHECK_TIMEOUT=str(max(30, timeout - 90)))
+    env = dict(os.environ, NGSAMG_CHECK_TIMEOUT=str(max(30, timeout - 90)), **(extra_env or {}))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_rccl_check.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0 and "RCCL CHECK PASSED" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
@@ -134,6 +134,19 @@ def test_rccl_world_size_one(sm):
     straight into the ghost segment, and the add direction.  More ranks need more GPUs: tests/test_gpu_multi.py."""
     out = _run_check("--world", "1", "--box", "20", "--sm", sm)
     assert "self-loop halo ok = True" in out
+    # the whole collective cycle (RCCL operations included) was captured into a hipGraph and replayed
+    assert "graph enabled = True graphs = 1 replays = 3" in out, out
+
+
+@pytest.mark.parametrize("mode", ["1", "pad"])
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_rccl_world_size_one_runs_the_allgather_branch(mode, graph):
+    """CtrMap's role (dof_contract.cpp:68-223): level k is gathered by ncclAllGather.  World size 1 normally takes a copy
+    shortcut; AMGX_DIST_FORCE_ALLGATHER sends it through ncclAllGather ("1") and through the padded all-gather + compaction
+    kernel of unequal pieces ("pad"), captured in the cycle's graph and with direct launches."""
+    out = _run_check("--world", "1", "--box", "20", "--sm", "jacobi", extra_env={"AMGX_DIST_FORCE_ALLGATHER": mode, "AMGX_DIST_GRAPH": graph})
+    assert f"allgather = {mode}" in out
+    assert ("graph enabled = True graphs = 1 replays = 3" in out) == (graph == "1"), out
 
 
 def _halo_tables(R, n, rng):
@@ -468,3 +481,70 @@ def test_loopback_device_rank_without_rows(sm):
     ref = Oracle(amg.global_levels(), sm_type=oracle_sm_types(amg)).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("R,box,dmin,sm", [(2, (14, 12, 12), 100, "jacobi"), (4, (10, 10, 10), 50, "jacobi"), (2, (14, 12, 12), 100, "gs"), (4, (10, 10, 10), 50, "hgs")])
+def test_whole_cycle_graph_equals_direct_launches(R, box, dmin, sm, monkeypatch):
+    """amgx_dist_apply captures the collective cycle (both streams, pack kernels, the wire) once per (b, x) and replays it:
+    same result as direct launches, also for new contents of the same vectors and for a second pair of vectors"""
+    import torch
+    from ngsamg_amd import dist as D
+    pg = D.proc_grid(R, 3)
+    states = lambda: [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    rng = np.random.default_rng(3)
+
+    def build(graph):
+        monkeypatch.setenv("AMGX_DIST_GRAPH", "1" if graph else "0")
+        return D.DistributedAMG(D.LoopbackComm(R), states(), dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm,
+                                **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    ag, ad = build(True), build(False)
+    sts = ag.dist_levels[0]
+    for rep in range(2):
+        bs = [torch.from_numpy(rng.standard_normal(s.n) * s.free).cuda() for s in sts]
+        xg = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in sts]
+        xd = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in sts]
+        for it in range(3):
+            if it == 2:       # new right-hand side in the same storage: the captured graph must see it
+                for b, s in zip(bs, sts):
+                    b.copy_(torch.from_numpy(rng.standard_normal(s.n) * s.free))
+            ag.Mult(bs, xg)
+            ad.Mult(bs, xd)
+            torch.cuda.synchronize()
+            for a, b_ in zip(xg, xd):
+                assert torch.equal(a, b_)
+    gi, di = ag._dev.graph_info(), ad._dev.graph_info()
+    assert gi["enabled"] and gi["graphs"] == 2 and gi["replays"] == 6, gi
+    assert not di["enabled"] and di["replays"] == 0
+    assert ag._dev.n_exchanges() == ad._dev.n_exchanges()
+
+
+@pytest.mark.parametrize("R,box,dmin,sm", [(2, (14, 12, 12), 100, "jacobi"), (4, (10, 10, 10), 50, "jacobi"), (3, (9, 12, 12), 80, "gs"), (2, (14, 12, 12), 100, "hgs")])
+def test_distributed_pcg_history_equals_serial_oracle(R, box, dmin, sm):
+    """amgx_dist_pcg (virtual ranks): owner-row SpMV with halo exchange, the collective cycle as preconditioner, global inner
+    products; the error history equals the serial oracle's PCG on the assembled global hierarchy to 1e-6"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    pg = (R, 1, 1)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(D.LoopbackComm(R), states, dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm,
+                           **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    rng = np.random.default_rng(7)
+    sts = amg.dist_levels[0]
+    bh = [rng.standard_normal(s.n) * s.free for s in sts]
+    bs = [torch.from_numpy(v).cuda() for v in bh]
+    xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in sts]
+    it, errs = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
+    xo, ito, erro = orc.pcg(np.concatenate(bh), tol=1e-8, maxit=100)
+    assert it == ito and it < 60
+    erro = np.asarray(erro)[:it + 1]
+    assert np.all(np.abs(errs - erro) <= 1e-6 * erro[0]) and np.allclose(errs[:5], erro[:5], rtol=1e-9)
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - xo) <= 1e-8 * np.linalg.norm(xo)
+    # a second solve from the solution as initial guess stops immediately
+    it2, errs2 = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
+    assert errs2[0] <= 1e-7 * errs[0]

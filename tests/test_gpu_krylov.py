@@ -71,3 +71,23 @@ def test_native_gmres_converges_like_pcg(restart):
     f = p.free.astype(bool)
     assert np.linalg.norm((A @ x - b)[f]) <= 1e-7 * np.linalg.norm(b)
     assert np.linalg.norm(x - xc) <= 1e-6 * np.linalg.norm(xc)
+
+
+@pytest.mark.parametrize("restart,sm", [(5, "jacobi"), (30, "jacobi"), (12, "gs")])
+def test_native_gmres_history_equals_oracle_gmres(restart, sm):
+    """amgx_gmres against the oracle's GMRES (plain C, modified Gram-Schmidt, written independently): same iteration count,
+    error history equal to 1e-6 of the initial error, same solution"""
+    import torch
+    from ngsamg_amd.krylov import NativeGMResSolver
+    from oracle.pyoracle import Oracle
+    p, H, dev = _case((25, 25, 25), sm)
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal(p.n) * p.free
+    gm = NativeGMResSolver(dev, dev, tol=1e-9, maxsteps=150, restart=restart)
+    x = gm.Solve(torch.from_numpy(b).cuda()).cpu().numpy()
+    xo, ito, erro = Oracle(H.levels, sm_type="jacobi" if sm == "jacobi" else "gs_mc").gmres(b, tol=1e-9, maxit=150, restart=restart)
+    assert gm.iterations == ito
+    errs = np.asarray(gm.errors)
+    assert errs.shape == erro.shape and np.all(np.abs(errs - erro) <= 1e-6 * erro[0])
+    assert np.allclose(errs[:4], erro[:4], rtol=1e-9)
+    assert np.linalg.norm(x - xo) <= 1e-7 * np.linalg.norm(xo)

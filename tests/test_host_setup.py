@@ -161,20 +161,23 @@ def test_multistep_concatenated_prolongation(shape, dim):
         assert L.agg is not None and L.agg.max() < H.levels[l + 1].n
 
 
-def test_robust_soc_keeps_material_jumps_h_and_jump_independent():
-    """ngs_amg_robust_soc: every vertex carries the largest edge weight collapsed inside it; a connection that is negligible on
-    that scale is not a viable pairing, so stiff inclusions / fibres that have become single vertices do not absorb their
-    soft surroundings (reference: accumulated vertex weights in the strength of connection of the SPW agglomerator)"""
+def test_spw_agglomeration_is_robust_for_material_jumps():
+    """The reference's SPW agglomeration (default, amgh_options.spw; spw_agg_impl.hpp): maxTrOD of a merged vertex keeps the
+    scale of everything collapsed inside it (SPWAggData::Map, :600-626), so a stiff inclusion / fibre that has become one
+    vertex does not absorb its soft surroundings: iteration counts stay bounded for every jump, where the target-driven
+    pairwise rounds of the earlier builds (spw = 0, plain max of the live edges) degrade.  The reference's own tests for
+    this: tests/elasticity/mdim/jump/test_2d_jump_lo.py, tests/h1/ jump cases (budgets 50)."""
     from ngsamg_amd import fem
     from ngsamg_amd._lib import Matrix
     from ngsamg_amd.hierarchy import Hierarchy
     from oracle.pyoracle import Oracle
 
-    def its_for(p, dim, energy, rs, **kw):
+    def its_for(p, dim, energy, spw, **kw):
         A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
-        H = Hierarchy(A, p.free, p.coords, dim=dim, energy=energy, robust_soc=rs, **kw)
+        H = Hierarchy(A, p.free, p.coords, dim=dim, energy=energy, spw=spw, **kw)
         return Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-6, maxit=200)[1], H
 
+    worst_old = 0
     for jump in (1e2, 1e6):
         def fibres(X):
             x, y = X[..., 0], X[..., 1]
@@ -188,14 +191,62 @@ def test_robust_soc_keeps_material_jumps_h_and_jump_independent():
         p = fem.poisson_fast((81, 81), dirichlet="top|bottom", coef=fibres)
         it1, H1 = its_for(p, 2, 0, 1, max_coarse_size=5)
         it0, _ = its_for(p, 2, 0, 0, max_coarse_size=5)
-        assert it1 <= 20 and it1 < it0 and H1.coarse_n <= 64
+        assert it1 <= 20 and H1.coarse_n <= 64
+        worst_old = max(worst_old, it0)
         for rot in (False, True):
             e = fem.elasticity_fast((41, 41), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, coef=squares)
             it1, H1 = its_for(e, 2, 1, 1, max_coarse_size=10, regularize_cmats=0 if rot else 1)
             it0, _ = its_for(e, 2, 1, 0, max_coarse_size=10, regularize_cmats=0 if rot else 1)
-            assert it1 <= 20 and it1 < it0
-    # a uniform problem is hardly affected
-    p = fem.poisson_fast((33, 33, 33))
-    it1, _ = its_for(p, 3, 0, 1, max_coarse_size=20)
-    it0, _ = its_for(p, 3, 0, 0, max_coarse_size=20)
-    assert abs(it1 - it0) <= 2
+            assert it1 <= 35                  # (the reference's budget for these cases is 50)
+            worst_old = max(worst_old, it0)
+    assert worst_old > 40                     # what the rule is there for
+    # the private option of the earlier builds (vertex scales on top of the pairwise rounds) still does its job
+    p = fem.poisson_fast((81, 81), dirichlet="top|bottom", coef=lambda X: np.where((np.floor(X[..., 1] * 10) % 2 == 1) & (np.abs(X[..., 0] - 0.5) < 0.4), 1e6, 1.0))
+    A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
+    H = Hierarchy(A, p.free, p.coords, dim=2, energy=0, spw=0, robust_soc=1, max_coarse_size=5)
+    assert Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-6, maxit=200)[1] <= 20
+
+
+def test_spw_pairing_rule_properties():
+    """aggregate_spw restates the reference's pairing rule (FindNeib3Step, spw_agg_impl.hpp:637-775): spw_rounds pairing
+    rounds => aggregates of at most 2^rounds vertices (+ orphans that joined them, JoiningIteration :1265-1365); a pair is
+    only formed over a connection with soc >= 0.25 of the vertex's strongest; spw_rounds and the orphan round are options
+    (spw_agg.hpp:28-32); the reference's 2D Poisson budget (tests/h1/test_2d_poisson.py: < 30 iterations at tol 1e-12 with
+    Gauss-Seidel) holds at the size of BASELINE.json's configs[0] (224^2)"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    p = fem.poisson_fast((40, 40), dirichlet="left|top")
+    for rounds, orphan in ((1, 0), (2, 1), (3, 1), (3, 0)):
+        H = Hierarchy(to_matrix(p), p.free, p.coords, dim=2, energy=0, max_levels=2, spw_rounds=rounds, spw_orphan_treatment=orphan)
+        agg = H.levels[0].agg
+        sizes = np.bincount(agg[agg >= 0])
+        assert np.all(agg[~p.free.astype(bool)] == -1) and np.all(agg[p.free.astype(bool)] >= 0)
+        # pairs of pairs: 2^rounds; an orphan round can add single vertices to a real aggregate
+        assert sizes.max() <= 2 ** rounds + (6 if orphan else 0)
+        if not orphan:
+            assert sizes.max() <= 2 ** rounds
+        if rounds == 3:
+            assert 5.0 <= sizes.mean() <= 9.0
+            if orphan:
+                assert (sizes == 1).sum() <= (np.bincount(Hierarchy(to_matrix(p), p.free, p.coords, dim=2, energy=0, max_levels=2, spw_rounds=3,
+                                                                    spw_orphan_treatment=0).levels[0].agg.clip(0)) == 1).sum()
+    # a chain with one weak link: the weak link is never inside an aggregate
+    import scipy.sparse as sp
+    from ngsamg_amd._lib import Matrix
+    n = 16
+    w = np.ones(n - 1)
+    w[7] = 1e-3
+    L = sp.diags([-w, -w], [-1, 1]).tolil()
+    L.setdiag(np.asarray(-L.sum(axis=1)).ravel() + 1e-3)
+    Lc = sp.csr_matrix(L)
+    Lc.sort_indices()
+    A = Matrix(n, n, 1, 1, Lc.indptr.astype(np.int64), Lc.indices.astype(np.int32), Lc.data.copy())
+    H = Hierarchy(A, np.ones(n, dtype=np.uint8), np.stack([np.arange(n) / n, np.zeros(n)], axis=1), dim=2, energy=0, max_levels=2, max_coarse_size=1)
+    agg = H.levels[0].agg
+    assert agg[7] != agg[8]
+    # the reference's budget at the size of configs[0]
+    p = fem.poisson_fast((224, 224), dirichlet="left|top")
+    H = Hierarchy(to_matrix(p), p.free, p.coords, dim=2, energy=0, max_coarse_size=20)
+    rng = np.random.default_rng(0)
+    it = Oracle(H.levels, sm_type="gs", threads=8).pcg(rng.standard_normal(p.n) * p.free, tol=1e-12, maxit=100)[1]
+    assert it < 30

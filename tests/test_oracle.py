@@ -197,3 +197,27 @@ def test_bgs_cycle_is_symmetric_and_beats_point_gs(kind):
     _, it_b, e_b = Oracle(H.levels, sm_type="bgs", bgs=bgs).pcg(b, tol=1e-8, maxit=100)
     _, it_g, _ = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=100)
     assert e_b[-1] <= 1e-8 * e_b[0] and it_b <= it_g + 1
+
+
+def test_oracle_gmres_minimises_the_preconditioned_residual():
+    """orc_gmres (test infrastructure for the GMRES parity test): the recurrence value equals the true |C (b - A x)|, it is
+    monotone inside a restart cycle, full GMRES needs no more iterations than PCG, and both reach the same solution"""
+    from oracle.pyoracle import Oracle
+    from tests.problems import poisson_case, rhs
+    p, H = poisson_case((13, 13, 13), "right|top", 20)
+    orc = Oracle(H.levels, sm_type="jacobi")
+    b = rhs(p, 3)
+    x, it, errs = orc.gmres(b, tol=1e-10, maxit=100, restart=40)
+    xc, itc, _ = orc.pcg(b, tol=1e-10, maxit=100)
+    assert errs[-1] <= 1e-10 * errs[0] and it <= itc + 1
+    assert all(e2 <= e1 * (1 + 1e-12) for e1, e2 in zip(errs[:-1], errs[1:]))
+    A = H.levels[0].A.to_scipy()
+    assert abs(np.linalg.norm(orc.apply(b - A @ x)) - errs[-1]) <= 1e-6 * errs[0]
+    assert np.linalg.norm(x - xc) <= 1e-7 * np.linalg.norm(xc)
+    # restarted: same fixed point, more iterations
+    x5, it5, errs5 = orc.gmres(b, tol=1e-10, maxit=300, restart=5)
+    assert it5 >= it and np.linalg.norm(x5 - xc) <= 1e-7 * np.linalg.norm(xc)
+    # without a preconditioner the first step minimises |b - alpha A b|
+    _, _, e = orc.gmres(b, tol=0.0, maxit=1, restart=5, precond=False)
+    Ab = A @ b
+    assert abs(e[1] - np.linalg.norm(b - (Ab @ b) / (Ab @ Ab) * Ab)) <= 1e-10 * e[0]
