@@ -99,6 +99,9 @@ int amgh_hybrid_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int64_t 
  * n_cols - n_rows ghost rows as their owners hold them (the reference sums the shares of all ranks, hybrid_smoother_utils.hpp:35-110) */
 int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, const double* ghost_diag_or_null,
                          double* dinv_out);
+/* square-block matrices (hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): dinv_k = (pseudo-)inverse(A_kk) / max(1, max_l 0.51 (1 + ad_k(l))),
+ * ad_k(l) = sum over the couplings leaving the block of rows of sum_m |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)); dinv_out: [n * bs * bs] */
+int amgh_hybrid_dinv_block(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int pinv, double* dinv_out);
 
 /* Block Gauss-Seidel data (reference BSmoother, src/base/smoothers/block_gssmoother.cpp:17-150).  Blocks are sets of
  * block rows -- the aggregates of the level, as GetGSBlocks builds them (amg_pc_vertex_impl.hpp:1171-1269); block k owns

@@ -91,7 +91,10 @@ typedef struct amgx_hierarchy_desc {
   int32_t cycle;              /* AMGX_CYCLE_*                                                        */
   int32_t clev;               /* AMGX_CLEV_*                                                         */
   int64_t coarse_n;           /* scalar size of the coarsest level                                   */
-  const double* coarse_inv;   /* dense [coarse_n^2] inverse on the free dofs (crs_inv, amg_pc.cpp:843-928) */
+  const double* coarse_inv;   /* dense [coarse_n^2] inverse on the free dofs (crs_inv, amg_pc.cpp:843-928); NULL with clev = INV:    */
+                              /*   amgx_create inverts the coarsest level matrix on its free dofs itself, on the device (blocked     */
+                              /*   Gauss-Jordan, trailing updates as f64 MFMA tiles; SPD required; up to AMGX_COARSE_DENSE_MAX =     */
+                              /*   16384 unknowns) -- what the host setup leaves to the device beyond 4096 unknowns                  */
   int32_t device;             /* HIP device ordinal                                                  */
   int32_t use_graph;          /* 1: capture each distinct (b, x) cycle into a hipGraph and replay it */
 } amgx_hierarchy_desc;

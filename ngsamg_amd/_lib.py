@@ -85,6 +85,7 @@ def host():
     lib.amgh_coloring_blocked.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_i32p, c_i32p]
     lib.amgh_hybrid_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p]
     lib.amgh_hybrid_dinv_ext.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p, c_f64p]
+    lib.amgh_hybrid_dinv_block.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, C.c_int, c_f64p]
     lib.amgh_bgs_dinv.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, C.c_int, c_i64p, c_f64p]
     lib.amgh_bgs_coloring.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p]
     lib.amgh_transpose_count.argtypes = [C.POINTER(amgh_matrix), c_i64p]
@@ -242,7 +243,7 @@ AMGH_SYMBOLS = [
     "amgh_last_error", "amgh_default_options", "amgh_setup", "amgh_n_levels", "amgh_level_get",
     "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
     "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble", "amgh_bgs_dinv", "amgh_bgs_coloring",
-    "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext",
+    "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext", "amgh_hybrid_dinv_block",
 ]
 
 

@@ -169,6 +169,15 @@ struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_
   bool on() const { return B > 0; }
 };
 
+struct DevBGSB {                        // block-hybrid Gauss-Seidel on square-block levels (bgsb_sweep_kernel)
+  int BB = 0;                           // block rows per workgroup
+  int n_blocks = 0, n_colors = 0;
+  DevMatrix off, in;                    // BSELL images: couplings that leave a workgroup's rows (global block columns, natural row
+                                        //   order) / couplings inside them (LOCAL block columns, rows sorted by colour inside the block)
+  DevBuf<int32_t> off_ptr, in_ptr, in_row;   // slice ranges per block / per (block, colour); local block row of every `in` slot (-1: padding)
+  bool on() const { return BB > 0; }
+};
+
 struct DevBGS {                         // block Gauss-Seidel over aggregate blocks (bgs_block_kernel)
   int n_colors = 0;
   int max_m = 0;                        // largest block (scalar dofs)
@@ -214,6 +223,7 @@ struct DevLevel {
   DevBuf<double> dinv;
   DevGS gs;
   DevGSB gsb;
+  DevBGSB bgsb;
   DevRestrict RG;                       // chunk-local P^T for the fused residual + restriction after a block-hybrid sweep
   DevBGS bgs;
   int sm_type = AMGX_SM_JACOBI;
@@ -230,6 +240,31 @@ struct DevLevel {
 // ---------------------------------------------------------------------------------------------------
 // host-side format construction
 // ---------------------------------------------------------------------------------------------------
+
+// Host threads for the format builders of amgx_create (cold path, but 10^8 entries at cfg 2: serial loops were 7.5 s of
+// "upload"): contiguous index ranges, one per thread; f(begin, end, thread).  AMGX_SETUP_THREADS overrides the count.
+static int setup_threads() {
+  static int T = [] {
+    int t = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    if (const char* e = std::getenv("AMGX_SETUP_THREADS")) t = std::max(1, std::atoi(e));
+    return t;
+  }();
+  return T;
+}
+template <class F>
+static void par_for(int64_t n, F&& f, int64_t min_per_thread = 4096) {
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / std::max<int64_t>(1, min_per_thread)));
+  if (T <= 1) { f((int64_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err = nullptr;
+  std::vector<std::exception_ptr> errs(T);
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      try { f(n * t / T, n * (t + 1) / T, t); } catch (...) { errs[t] = std::current_exception(); }
+    });
+  for (auto& q : th) q.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
 
 // lanes per row of the CSR-vector kernels: the widest group that still keeps >= 80 % of its lanes busy
 // (a row of length L costs ceil(L/G) steps of G lanes), else the most efficient one
@@ -266,13 +301,20 @@ struct HostSell {
 // set; the G partial sums are combined by a wave shuffle reduction in the kernel.
 static int64_t sell_stored(const amgx_matrix& A, int G) {
   const int R = WAVE / G;
+  const int64_t ns = (A.n_rows + R - 1) / R;
+  std::vector<int64_t> part(setup_threads(), 0);
+  par_for(ns, [&](int64_t s0, int64_t s1, int t) {
+    int64_t stored = 0;
+    for (int64_t s = s0; s < s1; ++s) {
+      int mx = 0;
+      for (int64_t r = s * R; r < std::min<int64_t>(A.n_rows, (s + 1) * R); ++r) mx = std::max<int>(mx, (int)(A.rowptr[r + 1] - A.rowptr[r]));
+      const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
+      stored += (int64_t)w * WAVE;
+    }
+    part[t] += stored;
+  });
   int64_t stored = 0;
-  for (int64_t r0 = 0; r0 < A.n_rows; r0 += R) {
-    int mx = 0;
-    for (int64_t r = r0; r < std::min<int64_t>(A.n_rows, r0 + R); ++r) mx = std::max<int>(mx, (int)(A.rowptr[r + 1] - A.rowptr[r]));
-    const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
-    stored += (int64_t)w * WAVE;
-  }
+  for (int64_t v : part) stored += v;
   return stored;
 }
 
@@ -286,26 +328,33 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
   bool diag_first = want_diag_first && G == 1 && !rows && A.n_rows <= A.n_cols && !std::getenv("AMGX_NO_DIAG_FIRST");
   if (diag_first) {
     dpos.assign(A.n_rows, -1);
-    for (int64_t i = 0; i < A.n_rows && diag_first; ++i) {
-      for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) if (A.col[k] == i) { dpos[i] = (int32_t)(k - A.rowptr[i]); break; }
-      if (dpos[i] < 0) diag_first = false;
-    }
+    std::vector<char> bad(setup_threads(), 0);
+    par_for(A.n_rows, [&](int64_t i0, int64_t i1, int t) {
+      for (int64_t i = i0; i < i1; ++i) {
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) if (A.col[k] == i) { dpos[i] = (int32_t)(k - A.rowptr[i]); break; }
+        if (dpos[i] < 0) { bad[t] = 1; break; }
+      }
+    });
+    for (char b : bad) if (b) diag_first = false;
   }
   S.diag_first = diag_first ? 1 : 0;
   // CSR position (relative to the row start) of entry e in the device order
   auto src = [&](int64_t r, int e) -> int { if (!diag_first) return e; const int dp = dpos[r]; return e == 0 ? dp : (e <= dp ? e - 1 : e); };
   S.slice_ptr.assign(ns + 1, 0);
   auto row_of = [&](int64_t q) -> int64_t { return (q < m) ? (rows ? rows[q] : q) : -1; };
-  for (int64_t s = 0; s < ns; ++s) {
-    int mx = 0;
-    for (int r = 0; r < R; ++r) {
-      const int64_t rr = row_of(s * R + r);
-      if (rr < 0) continue;
-      mx = std::max<int>(mx, (int)(A.rowptr[rr + 1] - A.rowptr[rr]));
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s) {
+      int mx = 0;
+      for (int r = 0; r < R; ++r) {
+        const int64_t rr = row_of(s * R + r);
+        if (rr < 0) continue;
+        mx = std::max<int>(mx, (int)(A.rowptr[rr + 1] - A.rowptr[rr]));
+      }
+      const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
+      S.slice_ptr[s + 1] = (int64_t)w * WAVE;            // widths first, offsets by the prefix sum below
     }
-    const int w = (G == 1) ? mx : 2 * (((mx + 1) / 2 + G - 1) / G);
-    S.slice_ptr[s + 1] = S.slice_ptr[s] + (int64_t)w * WAVE;
-  }
+  });
+  for (int64_t s = 0; s < ns; ++s) S.slice_ptr[s + 1] += S.slice_ptr[s];
   const int64_t stored = S.slice_ptr[ns];
   S.col32.assign(stored, 0);
   S.col16.assign(stored, 0);
@@ -313,7 +362,10 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
   S.val.assign(stored, 0.0);
   S.n_comp_slices = 0;
   S.stream_bytes = 8 * (ns + 1);
-  for (int64_t s = 0; s < ns; ++s) {
+  std::vector<int64_t> t_comp(setup_threads(), 0), t_bytes(setup_threads(), 0);
+  std::vector<uint8_t> comp_flag((size_t)ns, 0);           // (the flag goes into bit 0 of slice_ptr[s] after all slices are filled)
+  par_for(ns, [&](int64_t sl0, int64_t sl1, int tid) {
+  for (int64_t s = sl0; s < sl1; ++s) {
     const int64_t base = S.slice_ptr[s];
     const int w = (int)((S.slice_ptr[s + 1] - base) / WAVE);
     const int wp = w & ~1;
@@ -370,24 +422,30 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
         }
       }
     }
-    if (comp && w > 0) { S.slice_ptr[s] |= 1; S.n_comp_slices++; S.stream_bytes += (int64_t)w * WAVE * 10 + 4 * w; }
-    else S.stream_bytes += (int64_t)w * WAVE * 12;
+    if (comp && w > 0) { comp_flag[s] = 1; t_comp[tid]++; t_bytes[tid] += (int64_t)w * WAVE * 10 + 4 * w; }
+    else t_bytes[tid] += (int64_t)w * WAVE * 12;
   }
+  }, 64);
+  for (int64_t s = 0; s < ns; ++s) if (comp_flag[s]) S.slice_ptr[s] |= 1;
+  for (int64_t v : t_comp) S.n_comp_slices += v;
+  for (int64_t v : t_bytes) S.stream_bytes += v;
 }
 
 // G == 1, diagonal-first SELL: overwrite the diagonal slot (entry 0) of every row (see SellMat::wdiag)
 static void patch_sell_diag(HostSell& S, int64_t n_rows, const double* dval) {
   const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
-  for (int64_t s = 0; s < ns; ++s) {
-    const int64_t base = S.slice_ptr[s] & ~(int64_t)63;
-    const int w = (int)(((S.slice_ptr[s + 1] & ~(int64_t)63) - base) / WAVE);
-    if (w == 0) continue;
-    for (int l = 0; l < WAVE; ++l) {
-      const int64_t row = s * WAVE + l;
-      if (row >= n_rows) break;
-      S.val[w >= 2 ? base + l * 2 : base + l] = dval[row];
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s) {
+      const int64_t base = S.slice_ptr[s] & ~(int64_t)63;
+      const int w = (int)(((S.slice_ptr[s + 1] & ~(int64_t)63) - base) / WAVE);
+      if (w == 0) continue;
+      for (int l = 0; l < WAVE; ++l) {
+        const int64_t row = s * WAVE + l;
+        if (row >= n_rows) break;
+        S.val[w >= 2 ? base + l * 2 : base + l] = dval[row];
+      }
     }
-  }
+  }, 64);
 }
 
 static void upload_sell(const HostSell& S, DevMatrix::Sell& D) {
@@ -462,10 +520,14 @@ static void check_matrix(const amgx_matrix& A, const char* what) {
   if (nnz > 0 && (!A.col || !A.val)) throw Err(std::string(what) + ": col / val missing");
   if (nnz >= (int64_t)2147483647) throw Err(std::string(what) + ": more than 2^31-1 stored blocks are not supported on the device");
   if (A.n_cols >= (int64_t)2147483647 / 8) throw Err(std::string(what) + ": too many columns for int32 indices");
-  for (int64_t i = 0; i < A.n_rows; ++i)
-    if (A.rowptr[i + 1] < A.rowptr[i]) throw Err(std::string(what) + ": rowptr is not monotone");
-  for (int64_t k = 0; k < nnz; ++k)
-    if (A.col[k] < 0 || A.col[k] >= A.n_cols) throw Err(std::string(what) + ": column index out of range");
+  par_for(A.n_rows, [&](int64_t i0, int64_t i1, int) {
+    for (int64_t i = i0; i < i1; ++i)
+      if (A.rowptr[i + 1] < A.rowptr[i]) throw Err(std::string(what) + ": rowptr is not monotone");
+  });
+  par_for(nnz, [&](int64_t k0, int64_t k1, int) {
+    for (int64_t k = k0; k < k1; ++k)
+      if (A.col[k] < 0 || A.col[k] >= A.n_cols) throw Err(std::string(what) + ": column index out of range");
+  }, 1 << 16);
 }
 
 static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true, bool rowrel_ok = false, bool keep_csr = false,
@@ -490,13 +552,15 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   if (windowed) {
     std::vector<int32_t> rows((size_t)A.n_rows);
     std::vector<uint16_t> rowloc((size_t)A.n_rows);
-    for (int64_t w0 = 0; w0 < A.n_rows; w0 += win) {
-      const int64_t w1 = std::min<int64_t>(A.n_rows, w0 + win);
-      for (int64_t i = w0; i < w1; ++i) rows[i] = (int32_t)i;
-      std::stable_sort(rows.begin() + w0, rows.begin() + w1, [&](int32_t a, int32_t b) {
-        return A.rowptr[a + 1] - A.rowptr[a] > A.rowptr[b + 1] - A.rowptr[b]; });
-      for (int64_t i = w0; i < w1; ++i) rowloc[i] = (uint16_t)(rows[i] - w0);
-    }
+    par_for((A.n_rows + win - 1) / win, [&](int64_t q0, int64_t q1, int) {
+      for (int64_t q = q0; q < q1; ++q) {
+        const int64_t w0 = q * win, w1 = std::min<int64_t>(A.n_rows, w0 + win);
+        for (int64_t i = w0; i < w1; ++i) rows[i] = (int32_t)i;
+        std::stable_sort(rows.begin() + w0, rows.begin() + w1, [&](int32_t a, int32_t b) {
+          return A.rowptr[a + 1] - A.rowptr[a] > A.rowptr[b + 1] - A.rowptr[b]; });
+        for (int64_t i = w0; i < w1; ++i) rowloc[i] = (uint16_t)(rows[i] - w0);
+      }
+    }, 8);
     HostSell S;
     build_sell(A, rows.data(), A.n_rows, false, 1, S, false);
     D.fmt = FMT_SELL;
@@ -592,26 +656,47 @@ static void build_bgs(const amgx_level_desc& d, DevLevel& L) {
 static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES) {
   const int64_t nf = P.n_rows, nc = P.n_cols;
   const int64_t nch = (nf + CH - 1) / CH;
-  std::vector<int32_t> chunk_slot(nch + 1, 0), slot_ptr(1, 0), slot_col;
-  std::vector<double> w;
-  std::vector<uint16_t> fi;
-  w.reserve(P.rowptr[nf]); fi.reserve(P.rowptr[nf]);
+  // pass 1 (parallel over chunks): slots (= distinct coarse columns) per chunk; a chunk's entries are the P entries of its rows
+  std::vector<int32_t> chunk_slot(nch + 1, 0);
+  std::vector<char> too_long(setup_threads(), 0);
   struct Trip { int32_t J; uint16_t i; double w; };
-  std::vector<Trip> t;
-  for (int64_t c = 0; c < nch; ++c) {
+  auto chunk_trips = [&](int64_t c, std::vector<Trip>& t) {
     t.clear();
     const int64_t r0 = c * CH, r1 = std::min<int64_t>(nf, r0 + CH);
     for (int64_t i = r0; i < r1; ++i)
       for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) t.push_back({P.col[k], (uint16_t)(i - r0), P.val[k]});
     std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.J < b.J; });
-    for (size_t q = 0; q < t.size(); ++q) {
-      if (q == 0 || t[q].J != t[q - 1].J) { if (q) slot_ptr.push_back((int32_t)w.size()); slot_col.push_back(t[q].J); }
-      w.push_back(t[q].w); fi.push_back(t[q].i);
+  };
+  par_for(nch, [&](int64_t c0, int64_t c1, int tid) {
+    std::vector<Trip> t;
+    for (int64_t c = c0; c < c1; ++c) {
+      chunk_trips(c, t);
+      if ((int64_t)t.size() > max_entries) { too_long[tid] = 1; return; }
+      int32_t nsl = 0;
+      for (size_t q = 0; q < t.size(); ++q) if (q == 0 || t[q].J != t[q - 1].J) nsl++;
+      chunk_slot[c + 1] = nsl;
     }
-    if (!t.empty()) slot_ptr.push_back((int32_t)w.size());
-    if ((int64_t)t.size() > max_entries) return;      // rows too long for the LDS product buffer: keep the P^T form
-    chunk_slot[c + 1] = (int32_t)slot_col.size();
-  }
+  }, 8);
+  for (char c : too_long) if (c) return;             // rows too long for the LDS product buffer: keep the P^T form
+  for (int64_t c = 0; c < nch; ++c) chunk_slot[c + 1] += chunk_slot[c];
+  const int64_t n_slots = chunk_slot[nch], n_ent = P.rowptr[nf];
+  std::vector<int32_t> slot_ptr((size_t)n_slots + 1, 0), slot_col((size_t)n_slots);
+  std::vector<double> w((size_t)n_ent);
+  std::vector<uint16_t> fi((size_t)n_ent);
+  // pass 2: fill (entries of chunk c start at rowptr[c * CH]: the chunk's rows are consecutive)
+  par_for(nch, [&](int64_t c0, int64_t c1, int) {
+    std::vector<Trip> t;
+    for (int64_t c = c0; c < c1; ++c) {
+      chunk_trips(c, t);
+      int64_t e = P.rowptr[c * CH];
+      int64_t sl = chunk_slot[c];
+      for (size_t q = 0; q < t.size(); ++q) {
+        if (q == 0 || t[q].J != t[q - 1].J) { slot_ptr[sl] = (int32_t)e; slot_col[sl] = t[q].J; sl++; }
+        w[e] = t[q].w; fi[e] = t[q].i; e++;
+      }
+    }
+  }, 8);
+  slot_ptr[n_slots] = (int32_t)n_ent;
   const int64_t ns = (int64_t)slot_col.size();
   if ((int64_t)slot_ptr.size() != ns + 1) throw Err("build_restrict: internal slot count mismatch");
   std::vector<int32_t> optr(nc + 1, 0), oidx(ns);
@@ -645,6 +730,8 @@ struct Handle {
   std::vector<DevLevel> lev;
   int cycle = AMGX_CYCLE_V, clev = AMGX_CLEV_INV;
   int64_t coarse_n = 0;
+  int64_t coarse_ld = 0;                // row stride of coarse_inv (== coarse_n for an inverse handed over by the host)
+  double coarse_pivot = 0.0;            // device-side inversion: smallest pivot ratio met (dense_spd.hpp)
   DevBuf<double> coarse_inv;
   hipStream_t own_stream = nullptr, stream = nullptr;
   bool use_graph = true;
@@ -864,7 +951,7 @@ struct Handle {
     Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
     const DevGS& g = L.gs;
     const DevMatrix::Sell& copy = (lower_only && g.has_split) ? g.lower : g.sell;
-    if (L.gsb.on()) throw Err("gs_sweep: the level uses the block-hybrid form");
+    if (L.gsb.on() || L.bgsb.on()) throw Err("gs_sweep: the level uses the block-hybrid form");
     if (g.n_colors == 0 && L.n > 0) throw Err("Gauss-Seidel requested but the level has no colouring");
     if (cend < 0 || cend > g.n_colors) cend = g.n_colors;
     for (int q = cbeg; q < cend; ++q) {
@@ -939,6 +1026,27 @@ struct Handle {
     HIPCHK(hipGetLastError());
   }
 
+  // one block-hybrid Gauss-Seidel sweep on a square-block level (bgsb_sweep_kernel): ONE launch; xin == nullptr: from x = 0
+  void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b) {
+    Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
+    const DevBGSB& g = L.bgsb;
+    if (g.n_blocks == 0) return;
+    if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
+    const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double);
+    const BSellMat OFF = g.off.bsell.view(), IN = g.in.bsell.view();
+#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(g.n_blocks), dim3(BLOCK), lds, stream, L.n, g.BB, 0, OFF, g.off_ptr.p, IN, \
+                                               g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, xin, xout)
+    const bool fz = xin == nullptr;
+    switch (L.bs) {
+      case 2: if (fz) LAUNCH_BGSB(2, true); else LAUNCH_BGSB(2, false); break;
+      case 3: if (fz) LAUNCH_BGSB(3, true); else LAUNCH_BGSB(3, false); break;
+      case 6: if (fz) LAUNCH_BGSB(6, true); else LAUNCH_BGSB(6, false); break;
+      default: throw Err("block-hybrid Gauss-Seidel: unsupported block size");
+    }
+#undef LAUNCH_BGSB
+    HIPCHK(hipGetLastError());
+  }
+
   // one block Gauss-Seidel sweep: colours of the block graph ascending (forward) or descending (backward)
   void bgs_sweep(const DevLevel& L, int dir, double* x, const double* b, int cbeg = 0, int cend = -1) {
     const DevBGS& g = L.bgs;
@@ -973,7 +1081,8 @@ struct Handle {
     const DevLevel& L = lev.back();
     if (clev != AMGX_CLEV_INV || coarse_n == 0) { zero(x, L.len()); return; }   // amg_matrix.cpp:242-246
     const int grid = (int)((coarse_n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(BLOCK), 0, stream, (int)coarse_n, coarse_inv.p, rhs, x);
+    if (coarse_ld != coarse_n) hipLaunchKernelGGL(dense_op_gemv_kernel, dim3(grid), dim3(BLOCK), 0, stream, (int)coarse_n, (int)coarse_ld, coarse_inv.p, rhs, x);
+    else hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(BLOCK), 0, stream, (int)coarse_n, coarse_inv.p, rhs, x);
     HIPCHK(hipGetLastError());
   }
 
@@ -1003,6 +1112,10 @@ struct Handle {
       // BSmoother::Smooth / SmoothBack (block_gssmoother.cpp:434-498): like GSS3 the reference updates the residual by
       // row-transpose scatters when asked for it; here: gather (RHS) form + one residual SpMV, same x and res
       bgs_sweep(L, dir, x, b);
+      if (update_res) residual(L.A, x, b, res);
+    } else if (L.bgsb.on()) {
+      copy(L.tmp.p, x, L.ext_len());
+      bgsb_sweep(L, dir, L.tmp.p, x, b);
       if (update_res) residual(L.A, x, b, res);
     } else if (L.gsb.on()) {
       // block-hybrid sweep (out of place: the off-block values are those from the start of the sweep)
@@ -1064,6 +1177,10 @@ struct Handle {
         residual(L.A, x, b, r);              // r = b - A x
         if (fold) diag_apply(L, r, x, true); // z = x + omega * Dinv * r  (folded post-smoothing, see fold_prolongation)
       }
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.bgsb.on()) {
+      // forward block-hybrid sweep from x = 0 (nothing outside the workgroup's rows is read), then the residual
+      bgsb_sweep(L, 0, nullptr, x, b);
+      residual(L.A, x, b, r);
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on()) {
       // forward block-hybrid sweep from x = 0: inside a block only couplings to lower colours contribute (all other
       // values are still 0); afterwards (b - L_in x)_k = x_k / dinv_k on every swept row, hence
@@ -1199,6 +1316,9 @@ struct Handle {
     } else if (plain(L) && L.sm_type == AMGX_SM_JACOBI) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
+    } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.bgsb.on()) {
+      mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
+      bgsb_sweep(L, 1, L.tmp.p, x, b);     // backward block-hybrid sweep, tmp -> x
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
@@ -1617,6 +1737,121 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
 // and the whole post-smoothing is ONE SpMV-AXPY with Q = (I - omega*Dinv*A) P, built once here (host, threads over row
 // ranges).  Q has about half the entries of A (cfg 2: 7.8 vs 14.8 per row), and the pass over P and the round trip of
 // t through HBM disappear.  Same result up to rounding; AMGX_NO_FOLD=1 runs the literal sequence.
+// BSELL image of selected entries of a square-block matrix: `rows` lists block rows in storage order (-1 = padding slot),
+// slices of RB = 64 / bs consecutive list entries; keep(i, j) selects entries, mapcol(i, j) gives the stored block column,
+// padcol = column of padding steps (any valid index of the gathered vector).
+template <class Keep, class MapCol>
+static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& rows, Keep keep, MapCol mapcol, int32_t padcol, DevMatrix& D) {
+  const int bs = A.br;
+  const int RB = WAVE / bs;
+  const int64_t m = (int64_t)rows.size();
+  if (m % RB) throw Err("build_bsell_sel: the row list must be padded to whole slices");
+  const int64_t ns = m / RB;
+  std::vector<int64_t> sp(ns + 1, 0);
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s) {
+      int w = 0;
+      for (int rb = 0; rb < RB; ++rb) {
+        const int32_t i = rows[s * RB + rb];
+        if (i < 0) continue;
+        int c = 0;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) if (keep(i, A.col[k])) ++c;
+        w = std::max(w, c);
+      }
+      sp[s + 1] = w;
+    }
+  }, 16);
+  for (int64_t s = 0; s < ns; ++s) sp[s + 1] += sp[s];
+  const int64_t steps = sp[ns];
+  std::vector<int32_t> col((size_t)std::max<int64_t>(1, steps * RB), padcol);
+  std::vector<double> val((size_t)std::max<int64_t>(1, steps * bs * WAVE), 0.0);
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s)
+      for (int rb = 0; rb < RB; ++rb) {
+        const int32_t i = rows[s * RB + rb];
+        if (i < 0) continue;
+        int64_t kk = sp[s];
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+          const int32_t j = A.col[k];
+          if (!keep(i, j)) continue;
+          col[kk * RB + rb] = mapcol(i, j);
+          const double* blk = A.val + k * bs * bs;
+          double* vk = val.data() + kk * (bs * WAVE);
+          for (int rr = 0; rr < bs; ++rr) {
+            const int lane = rb * bs + rr;
+            for (int c = 0; c < bs; ++c) {
+              if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = blk[rr * bs + c];
+              else vk[(c / 2) * (2 * WAVE) + lane * 2 + (c & 1)] = blk[rr * bs + c];
+            }
+          }
+          ++kk;
+        }
+      }
+  }, 16);
+  D.fmt = FMT_BSELL; D.br = D.bc = bs;
+  D.n_rows = A.n_rows; D.n_cols = A.n_cols;
+  D.n_slices = (int)ns;
+  D.stored = steps * RB;
+  D.stream_bytes = steps * ((int64_t)bs * WAVE * 8 + RB * 4) + 8 * (ns + 1);
+  D.bsell.slice_ptr.upload(sp); D.bsell.col.upload(col); D.bsell.val.upload(val);
+}
+
+// Block-hybrid Gauss-Seidel data of a square-block level (bgsb_sweep_kernel); the blocked colouring is validated (two coupled
+// rows of one workgroup block sharing a colour would be a data race)
+static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
+  const int64_t n = d.A.n_rows;
+  const int bs = d.A.br, RB = WAVE / bs;
+  DevBGSB& g = L.bgsb;
+  const int BB = d.gs_block_rows;
+  if (bs != 2 && bs != 3 && bs != 6) throw Err("block-hybrid Gauss-Seidel: block sizes 2, 3, 6");
+  if (d.A.n_cols != n) throw Err("block-hybrid Gauss-Seidel on block levels: square levels only");
+  if (BB < RB || BB > 2048 || (int64_t)2 * BB * bs * 8 > 96 * 1024) throw Err("block-hybrid Gauss-Seidel: gs_block_rows out of range for this block size");
+  if (n == 0) { g.BB = BB; return; }
+  if (!d.color || d.n_colors <= 0) throw Err("block-hybrid Gauss-Seidel needs a blocked colouring");
+  if (!d.dinv) throw Err("dinv missing");
+  const int nc = d.n_colors;
+  std::vector<char> bad(setup_threads(), 0);
+  par_for(n, [&](int64_t i0, int64_t i1, int t) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const int ci = d.color[i];
+      if (ci >= nc) { bad[t] = 1; return; }
+      if (ci < 0) continue;
+      const int64_t b0 = (i / BB) * BB, b1 = b0 + BB;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+        const int64_t j = d.A.col[k];
+        if (j != i && j >= b0 && j < b1 && d.color[j] == ci) { bad[t] = 2; return; }
+      }
+    }
+  });
+  for (char c : bad) { if (c == 1) throw Err("colour index out of range"); if (c == 2) throw Err("invalid blocked colouring: two coupled block rows of one block share a colour"); }
+  const int nblk = (int)((n + BB - 1) / BB);
+  g.BB = BB; g.n_blocks = nblk; g.n_colors = nc;
+  // off: natural order, every block padded to whole slices
+  std::vector<int32_t> rows_off, off_ptr(nblk + 1, 0);
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t b0 = (int64_t)blk * BB, b1 = std::min<int64_t>(n, b0 + BB);
+    for (int64_t i = b0; i < b1; ++i) rows_off.push_back((int32_t)i);
+    while (rows_off.size() % RB) rows_off.push_back(-1);
+    off_ptr[blk + 1] = (int32_t)(rows_off.size() / RB);
+  }
+  auto same_block = [BB](int64_t i, int64_t j) { return i / BB == j / BB; };
+  build_bsell_sel(d.A, rows_off, [&](int32_t i, int32_t j) { return !same_block(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.off);
+  // in: per block the swept rows by colour, every (block, colour) group padded to whole slices
+  std::vector<int32_t> rows_in, in_ptr((size_t)nblk * nc + 1, 0), in_row;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int64_t b0 = (int64_t)blk * BB, b1 = std::min<int64_t>(n, b0 + BB);
+    for (int c = 0; c < nc; ++c) {
+      for (int64_t i = b0; i < b1; ++i) if (d.color[i] == c) rows_in.push_back((int32_t)i);
+      while (rows_in.size() % RB) rows_in.push_back(-1);
+      in_ptr[(size_t)blk * nc + c + 1] = (int32_t)(rows_in.size() / RB);
+    }
+  }
+  in_row.resize(rows_in.size());
+  for (size_t q = 0; q < rows_in.size(); ++q) in_row[q] = rows_in[q] < 0 ? -1 : (int32_t)(rows_in[q] % BB);
+  build_bsell_sel(d.A, rows_in, [&](int32_t i, int32_t j) { return same_block(i, j); }, [BB](int32_t, int32_t j) { return (int32_t)(j % BB); }, 0, g.in);
+  g.off_ptr.upload(off_ptr); g.in_ptr.upload(in_ptr); g.in_row.upload(in_row);
+}
+
 struct HostCsr {
   std::vector<int64_t> rowptr;
   std::vector<int32_t> col;
@@ -1804,6 +2039,10 @@ static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_lev
   }
 }
 
+}  // namespace amgx
+#include "dense_spd.hpp"
+namespace amgx {
+
 // ---- collapsed coarse levels (see dense_op_gemv_kernel) -----------------------------------------------------------
 // Picks the first level l_c >= 1 from which the sub-cycle is cheaper as one dense GEMV than as its dependent launches,
 // forms B column by column with the handle's own kernels (so B is exactly the operator the separate launches apply,
@@ -1822,7 +2061,7 @@ static void build_dense_tail(Handle& h, const amgx_hierarchy_desc* d, const amgx
     const int k = std::max(1, V.sm_steps) * (V.sm_symm ? 2 : 1);
     if (V.sm_type == AMGX_SM_JACOBI) return h.folded(V) ? 3.0 : 2.0 + 3.0 * k;
     if (V.sm_type == AMGX_SM_BGS) return 3.0 + 2.0 * k * std::max(1, V.bgs.n_colors);
-    if (V.gsb.on()) return 2.0 + 3.0 * k;
+    if (V.gsb.on() || V.bgsb.on()) return 2.0 + 3.0 * k;
     return 3.0 + 2.0 * k * std::max(1, V.gs.n_colors);
   };
   int lc = -1;
@@ -1904,7 +2143,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS && s.sm_type != AMGX_SM_BGS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
     // block GS walks the CSR arrays of A, so keep A in CSR there
-    upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1);
+    upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0);
     if (!last) {
       const amgx_level_desc& c = levels[l + 1];
       if (s.P.n_rows != s.A.n_rows || s.P.n_cols > c.A.n_cols || s.P.n_cols < c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
@@ -1924,7 +2163,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       }
       if (!s.dinv) throw Err("dinv missing");
       L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
-      if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
+      if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
+      else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
       else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
@@ -1932,7 +2172,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
         std::vector<double> sv((size_t)nnz);
         // (rank-partitioned levels: dinv must cover the ghost columns too, i.e. n_cols entries)
-        for (int64_t k = 0; k < nnz; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]);
+        par_for(nnz, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
         amgx_matrix As = s.A;
         As.val = sv.data();
         // one-thread-per-row form: the diagonal slot carries omega*Dinv_i (SellMat::wdiag), the epilogue then needs no
@@ -1940,13 +2180,17 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         std::vector<double> wdv;
         if (s.omega != 0.0 && !std::getenv("AMGX_NO_WDIAG")) {
           // the epilogue re-inserts A'_ii b_i as omega*b_i (or 0 where dinv_i = 0): valid iff dinv is the plain inverse diagonal
+          std::vector<char> notplain(setup_threads(), 0);
+          par_for(s.A.n_rows, [&](int64_t i0, int64_t i1, int t) {
+            for (int64_t i = i0; i < i1; ++i) {
+              if (s.dinv[i] == 0.0) continue;
+              double aii = 0.0;
+              for (int64_t k = s.A.rowptr[i]; k < s.A.rowptr[i + 1]; ++k) if (s.A.col[k] == i) { aii = s.A.val[k]; break; }
+              if (!(std::fabs(s.dinv[i] * aii - 1.0) < 1e-13)) { notplain[t] = 1; break; }
+            }
+          });
           bool plain = true;
-          for (int64_t i = 0; i < s.A.n_rows && plain; ++i) {
-            if (s.dinv[i] == 0.0) continue;
-            double aii = 0.0;
-            for (int64_t k = s.A.rowptr[i]; k < s.A.rowptr[i + 1]; ++k) if (s.A.col[k] == i) { aii = s.A.val[k]; break; }
-            if (!(std::fabs(s.dinv[i] * aii - 1.0) < 1e-13)) plain = false;
-          }
+          for (char c : notplain) if (c) plain = false;
           if (plain) {
             wdv.resize((size_t)s.A.n_rows);
             for (int64_t i = 0; i < s.A.n_rows; ++i) wdv[i] = s.omega * s.dinv[i];
@@ -2008,7 +2252,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       }
     } else if (s.dinv) {
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
-      if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0) build_gsb(s, L, nullptr);
+      if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
+      else if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0) build_gsb(s, L, nullptr);
       else if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
@@ -2021,9 +2266,46 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
   }
   if (d->clev == AMGX_CLEV_INV) {
     const DevLevel& L = h->lev.back();
-    if (d->coarse_n != L.len() || !d->coarse_inv) throw Err("clev = inv needs the dense coarse inverse of matching size");
+    if (d->coarse_n != L.len()) throw Err("clev = inv: coarse_n does not match the coarsest level");
     h->coarse_n = d->coarse_n;
-    h->coarse_inv.upload(d->coarse_inv, (size_t)d->coarse_n * d->coarse_n);
+    if (d->coarse_inv) {
+      h->coarse_ld = d->coarse_n;
+      h->coarse_inv.upload(d->coarse_inv, (size_t)d->coarse_n * d->coarse_n);
+    } else {
+      // no inverse handed over (the host setup stops at 4096 unknowns): invert the coarsest matrix on its free dofs here
+      // (dense_spd.hpp: blocked Gauss-Jordan, trailing updates on the matrix cores)
+      const amgx_level_desc& s = levels[d->n_levels - 1];
+      int64_t cap = 16384;
+      if (const char* e = std::getenv("AMGX_COARSE_DENSE_MAX")) cap = std::atoll(e);
+      if (s.A.n_rows != s.A.n_cols) throw Err("clev = inv: the coarsest level of a rank-partitioned hierarchy cannot be inverted locally");
+      if (d->coarse_n > cap) throw Err("clev = inv: coarsest level has " + std::to_string(d->coarse_n) + " unknowns, more than AMGX_COARSE_DENSE_MAX = " +
+                                       std::to_string(cap) + " (a dense inverse would stream " + std::to_string(8 * d->coarse_n * d->coarse_n / 1000000) + " MB per application)");
+      const int64_t n = d->coarse_n, npad = (n + GJ_T - 1) / GJ_T * GJ_T;
+      const int bs = s.A.br;
+      struct { DevBuf<int32_t> rowptr, col; DevBuf<double> val; } cA;       // (DevCsr holds scalar matrices only)
+      {
+        const int64_t nnzc = s.A.rowptr[s.A.n_rows];
+        std::vector<int32_t> rp((size_t)s.A.n_rows + 1);
+        for (int64_t i = 0; i <= s.A.n_rows; ++i) rp[i] = (int32_t)s.A.rowptr[i];
+        cA.rowptr.upload(rp);
+        cA.col.upload(s.A.col, (size_t)nnzc);
+        cA.val.upload(s.A.val, (size_t)nnzc * bs * bs);
+      }
+      DevBuf<uint8_t> fr;
+      if (s.free_dofs) fr.upload(s.free_dofs, (size_t)s.A.n_rows);
+      h->coarse_inv.alloc((size_t)npad * npad);
+      h->coarse_ld = npad;
+      hipLaunchKernelGGL(gj_zero_kernel, dim3(Handle::grid_for(npad * npad)), dim3(BLOCK), 0, h->stream, npad * npad, h->coarse_inv.p);
+      hipLaunchKernelGGL(gj_scatter_kernel, dim3(Handle::grid_for(s.A.n_rows)), dim3(BLOCK), 0, h->stream, s.A.n_rows, bs, cA.rowptr.p, cA.col.p, cA.val.p,
+                         fr.p, npad, h->coarse_inv.p);
+      hipLaunchKernelGGL(gj_fix_diag_kernel, dim3(Handle::grid_for(npad)), dim3(BLOCK), 0, h->stream, npad, n, bs, fr.p, npad, 1.0, h->coarse_inv.p);
+      HIPCHK(hipGetLastError());
+      h->coarse_pivot = dense_spd_inverse(h->coarse_inv.p, npad, npad, h->stream);
+      if (!(h->coarse_pivot > 1e-14)) throw Err("clev = inv: the coarsest matrix is not positive definite on its free dofs (pivot ratio " +
+                                                std::to_string(h->coarse_pivot) + "); use clev = none or a smaller coarsest level");
+      hipLaunchKernelGGL(gj_fix_diag_kernel, dim3(Handle::grid_for(npad)), dim3(BLOCK), 0, h->stream, npad, n, bs, fr.p, npad, 0.0, h->coarse_inv.p);
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
   }
   // ---- single-workgroup coarse tail (V-cycle, plain scalar smoothers, exact coarse solve, square levels) ----------
   {
@@ -2036,7 +2318,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         const int64_t cap = s.sm_type == AMGX_SM_GS ? TAIL_MAX_ROWS_GS : TAIL_MAX_ROWS;
         const bool ok = s.A.br == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows <= cap &&
                         (s.sm_type == AMGX_SM_JACOBI || (s.sm_type == AMGX_SM_GS && s.color && s.n_colors > 0 && s.gs_block_rows == 0)) &&
-                        s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= 512;
+                        s.sm_steps <= 1 && !s.sm_symm && s.P.br == 1 && s.P.bc == 1 && h->coarse_n <= 512 && h->coarse_ld == h->coarse_n;
         if (!ok) break;
         --T;
       }

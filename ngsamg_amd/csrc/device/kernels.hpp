@@ -904,6 +904,102 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_s
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Block-hybrid Gauss-Seidel for SQUARE-BLOCK levels (BS = 2, 3, 6): ONE launch per sweep instead of one per colour.
+// The reference's hybrid smoother with workgroups in the role of the ranks (HybridGSSmoother<Mat<BS,BS>>,
+// gssmoother.cpp:709-861, 891-896), like gsb_sweep_kernel for scalar levels: a workgroup owns BB consecutive block rows;
+//   phase 0: b' = b - A_off x_old   -- the couplings that leave the block read the sweep-start vector (frozen); A_off
+//            streams as BSELL slices exactly like bsell_spmv_kernel, b' stays in LDS
+//   colour phases: x_B += Dinv_B (b'_B - A_in,B: x) on the in-block couplings (BSELL slices sorted by colour inside the block,
+//            LOCAL block columns), x in LDS, one workgroup barrier per colour; Dinv = inverse of the l1-modified block
+//            diagonal (amgh_hybrid_dinv_block, hybrid_smoother_utils.hpp:86-141)
+// Every entry of A is read once per sweep.  Out of place (other workgroups read the old values), except from zero where
+// nothing outside the block is read.
+template <int BS, bool FROM_ZERO>
+__global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int64_t n_rows, int BB, int block0, BSellMat OFF, const int32_t* __restrict__ off_ptr,
+                                                           BSellMat IN, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_row,
+                                                           int n_colors, int dir, const double* __restrict__ dinv, const double* __restrict__ b,
+                                                           const double* __restrict__ xin, double* __restrict__ xout) {
+  extern __shared__ double bgsb_sh[];
+  constexpr int RB = WAVE / BS;
+  double* xs = bgsb_sh;
+  double* bsh = bgsb_sh + (size_t)BB * BS;
+  const int blk = block0 + blockIdx.x;
+  const int64_t b0 = (int64_t)blk * BB;
+  const int nb = (int)((n_rows - b0) < BB ? (n_rows - b0) : BB);
+  for (int e = threadIdx.x; e < nb * BS; e += BLOCK) {
+    xs[e] = FROM_ZERO ? 0.0 : xin[b0 * BS + e];
+    bsh[e] = b[b0 * BS + e];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+  const int rbl = lane / BS < RB ? lane / BS : RB - 1;
+  const int r = lane % BS;
+  const bool lane_on = lane < RB * BS;
+  if (!FROM_ZERO) {
+    const int s0 = off_ptr[blk], s1 = off_ptr[blk + 1];
+    for (int s = s0 + wave; s < s1; s += WAVES_PER_BLOCK) {
+      const int lrow = (s - s0) * RB + rbl;
+      const bool active = lane_on && lrow < nb;
+      const int64_t k0 = OFF.slice_ptr[s];
+      const int w = (int)(OFF.slice_ptr[s + 1] - k0);
+      const double* __restrict__ vb = OFF.val + k0 * (BS * WAVE);
+      const int32_t* __restrict__ cb = OFF.col + k0 * RB;
+      double acc = 0.0;
+#pragma unroll 2
+      for (int k = 0; k < w; ++k) {
+        const int c = cb[k * RB + rbl];
+        const double* __restrict__ xv = xin + (int64_t)c * BS;
+        const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+        for (int cp = 0; cp < BS / 2; ++cp) {
+          const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+          acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+        }
+        if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+      }
+      if (active) bsh[lrow * BS + r] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int q = 0; q < n_colors; ++q) {
+    const int c = dir ? n_colors - 1 - q : q;
+    const int s0 = in_ptr[blk * n_colors + c], s1 = in_ptr[blk * n_colors + c + 1];
+    for (int s = s0 + wave; s < s1; s += WAVES_PER_BLOCK) {
+      const int lrow = in_row[(int64_t)s * RB + rbl];
+      const bool active = lane_on && lrow >= 0;
+      const int64_t k0 = IN.slice_ptr[s];
+      const int w = (int)(IN.slice_ptr[s + 1] - k0);
+      const double* __restrict__ vb = IN.val + k0 * (BS * WAVE);
+      const int32_t* __restrict__ cb = IN.col + k0 * RB;
+      double od[BS];
+#pragma unroll
+      for (int cc = 0; cc < BS; ++cc) od[cc] = active ? dinv[(b0 + lrow) * (BS * BS) + r * BS + cc] : 0.0;
+      double acc = 0.0;
+#pragma unroll 2
+      for (int k = 0; k < w; ++k) {
+        const int cl = cb[k * RB + rbl];
+        const double* xv = xs + cl * BS;
+        const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+        for (int cp = 0; cp < BS / 2; ++cp) {
+          const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+          acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+        }
+        if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+      }
+      const double t = active ? bsh[lrow * BS + r] - acc : 0.0;
+      const int base = lane - r;
+      double u = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < BS; ++cc) u += od[cc] * __shfl(t, base + cc, WAVE);
+      if (active) xs[lrow * BS + r] += u;
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < nb * BS; e += BLOCK) xout[b0 * BS + e] = xs[e];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Column-blocked restriction  b_c = P^T r  for large scalar levels (reference ProlMap::TransferF2C,
 // dof_map.cpp:636-654).  The gather form over P^T touches ~40 different cache lines of r per coarse row and is
 // TA/L2-bound (2.9 TB/s); here a workgroup owns a chunk of RESTRICT_CHUNK consecutive FINE rows, stages that

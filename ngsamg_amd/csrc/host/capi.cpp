@@ -168,6 +168,16 @@ int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int6
   });
 }
 
+int amgh_hybrid_dinv_block(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int pinv, double* dinv_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->br != A->bc || A->n_rows != A->n_cols) throw amgh::Error("amgh_hybrid_dinv_block: square matrix with square blocks expected");
+    if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv_block: bad arguments");
+    amgh::BCSR M = to_bcsr(A);
+    amgh::hybrid_mod_dinv_block(M, free_or_null, block_rows, pinv != 0, dinv_out);
+  });
+}
+
 int amgh_bgs_dinv(const amgh_matrix* A, int32_t n_blocks, const int32_t* block_ptr, const int32_t* block_rows, int pinv,
                   const int64_t* dinv_ptr, double* dinv_out) {
   return guard([&] {

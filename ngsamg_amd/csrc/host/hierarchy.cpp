@@ -17,6 +17,7 @@
 #include "hierarchy.hpp"
 #include <omp.h>
 #include <cmath>
+#include <cstdlib>
 #include <algorithm>
 #include <numeric>
 #include <sstream>
@@ -598,6 +599,41 @@ void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, dou
   }
 }
 
+// the same for square-block matrices (reference hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): per block row k and scalar
+// row l, ad_k(l) = sum over the couplings that leave the block of rows of sum_m |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)); the
+// block diagonal is scaled by max(1, max_l 0.51 (1 + ad_k(l))), i.e. dinv_k = (pseudo-)inverse(A_kk) / that factor
+void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv) {
+  const int64_t n = A.n_rows;
+  const int bs = A.br, bb = bs * bs;
+  std::vector<double> d((size_t)n * bs, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { for (int r = 0; r < bs; r++) d[i * bs + r] = A.val[k * bb + r * bs + r]; break; }
+  calc_dinv(A, free, pinv, dinv);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    if (free && !free[i]) continue;
+    const int64_t b0 = (i / block_rows) * block_rows, b1 = b0 + block_rows;
+    double fac = 1.0;
+    for (int l = 0; l < bs; l++) {
+      const double dl = d[i * bs + l];
+      if (!(dl > 0.0)) continue;
+      double ad = 0.0;
+      for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+        const int64_t j = A.col[k];
+        if (j >= b0 && j < b1) continue;
+        if (j >= n) continue;                 // (ghost columns: rank-partitioned levels use the distributed setup's own routine)
+        for (int m = 0; m < bs; m++) {
+          const double dm = d[j * bs + m];
+          if (dm > 0.0) ad += std::fabs(A.val[k * bb + l * bs + m]) / std::sqrt(dl * dm);
+        }
+      }
+      fac = std::max(fac, 0.51 * (1.0 + ad));
+    }
+    if (fac != 1.0) for (int q = 0; q < bb; q++) dinv[i * bb + q] /= fac;
+  }
+}
+
 Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coords0, const Options& o) {
   auto H = new Hierarchy();
   H->opts = o;
@@ -715,7 +751,11 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     Level& L = H->levels.back();
     const int bs = L.A.br;
     const int64_t N = L.A.n_rows * bs;
-    if (N <= 4096) {
+    // beyond this size the inverse is left to the device (amgx_create with coarse_inv = NULL: blocked Gauss-Jordan on the
+    // matrix cores, csrc/device/dense_spd.hpp); NGSAMG_HOST_COARSE_MAX moves the limit (tests force the device path with it)
+    int64_t host_max = 4096;
+    if (const char* e = std::getenv("NGSAMG_HOST_COARSE_MAX")) host_max = std::atoll(e);
+    if (N <= host_max) {
       std::vector<int64_t> fidx;
       for (int64_t i = 0; i < L.A.n_rows; i++) if (L.free[i]) for (int c = 0; c < bs; c++) fidx.push_back(i * bs + c);
       const int64_t nfr = (int64_t)fidx.size();
@@ -736,8 +776,8 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       H->coarse_inv.assign((size_t)N * N, 0.0);
       for (int64_t a = 0; a < nfr; a++) for (int64_t b = 0; b < nfr; b++) H->coarse_inv[fidx[a] * N + fidx[b]] = D[a * nfr + b];
     } else {
-      H->coarse_n = 0;   // too large for a dense inverse: caller falls back to clev = none (smoothing only)
-      log << "  coarsest level too large for dense inverse (" << N << ")\n";
+      H->coarse_n = 0;   // left to the device
+      log << "  coarsest level (" << N << " unknowns): dense inverse left to the device\n";
     }
   }
   H->log = log.str();

@@ -28,6 +28,12 @@ def gs_block_rows(A):
     that need several lanes get 1024-lane workgroups, so the blocks stay as large as possible (fewer frozen couplings).
     0: the level keeps the multicolour form (rows too long, or a level small enough for the single-workgroup tail)."""
     import os
+    if A.br == A.bc and A.br in (2, 3, 6) and A.n_rows == A.n_cols:
+        # square-block levels (bgsb_sweep_kernel): a workgroup owns ~128 block rows, a whole number of BSELL slices
+        # (64 // bs block rows each); levels with fewer than four such blocks keep the multicolour form
+        rb = 64 // A.br
+        B = int(os.environ.get("AMGX_BGSB_ROWS", "0")) or rb * max(1, 128 // rb)
+        return B if (A.n_rows >= 4 * B and not os.environ.get("AMGX_NO_BGSB")) else 0
     if A.br != 1 or A.bc != 1 or A.n_rows <= 256:
         return 0
     mx = int(np.diff(A.rowptr).max()) if A.n_rows else 0
@@ -39,14 +45,19 @@ def gs_block_rows(A):
     return 0
 
 
-def hybrid_gs_data(A, free, B):
-    """blocked colouring + inverse of the l1-modified diagonal for blocks of B consecutive rows (host library)"""
+def hybrid_gs_data(A, free, B, pinv=False):
+    """blocked colouring + inverse of the l1-modified (block) diagonal for blocks of B consecutive rows (host library);
+    pinv: block levels whose diagonal blocks are pseudo-inverted (ngs_amg_regularize_cmats)"""
     lib = _lib.host()
     d = A.desc()
     fr = None if free is None else np.ascontiguousarray(free, dtype=np.uint8)
     color = np.full(A.n_rows, -1, dtype=np.int32)
     nc = C.c_int32()
     _lib.hcheck(lib.amgh_coloring_blocked(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(color, C.c_int32), C.byref(nc)))
+    if A.br > 1:
+        dinv = np.zeros(A.n_rows * A.br * A.br, dtype=np.float64)
+        _lib.hcheck(lib.amgh_hybrid_dinv_block(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), int(bool(pinv)), _lib.ptr(dinv, C.c_double)))
+        return color, int(nc.value), dinv
     dinv = np.zeros(A.n_cols, dtype=np.float64)          # (rank-partitioned levels: entries of the ghost columns stay 0)
     _lib.hcheck(lib.amgh_hybrid_dinv(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(dinv, C.c_double)))
     return color, int(nc.value), dinv
@@ -113,7 +124,8 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
             pre = getattr(lv, "hgs_pre", None)      # rank-partitioned levels: computed by the distributed setup (needs ghost diagonals)
             B = pre["B"] if pre else gs_block_rows(lv.A)
             if B > 0:
-                col, nc, dinv = (pre["color"], pre["n_colors"], pre["dinv"]) if pre else hybrid_gs_data(lv.A, lv.free, B)
+                pinv = bool(getattr(getattr(hierarchy, "options", None), "regularize_cmats", 0))
+                col, nc, dinv = (pre["color"], pre["n_colors"], pre["dinv"]) if pre else hybrid_gs_data(lv.A, lv.free, B, pinv)
                 info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv)
                 keep.append(info[i])
                 d.color, d.n_colors, d.dinv, d.gs_block_rows = _lib.ptr(col, C.c_int32), nc, _lib.ptr(dinv, C.c_double), B
@@ -135,12 +147,16 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
     if mg_cycle not in _lib.AMGX_CYCLE:
         raise NgsAMGError(f"unknown mg_cycle '{mg_cycle}' (V | W | BS)")
     desc.cycle = _lib.AMGX_CYCLE[mg_cycle]
-    if clev == "inv" and hierarchy.coarse_n == 0:
-        raise NgsAMGError("clev = inv but the hierarchy has no coarse inverse (coarsest level too large to invert densely: "
-                          "raise ngs_amg_max_levels or lower ngs_amg_max_coarse_size, or use ngs_amg_clev='none')")
     desc.clev = _lib.AMGX_CLEV_INV if clev == "inv" else _lib.AMGX_CLEV_NONE
-    desc.coarse_n = hierarchy.coarse_n if clev == "inv" else 0
-    desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
+    L = levels
+    if clev == "inv" and hierarchy.coarse_n == 0 and n > 0 and L[-1].A.n_rows == L[-1].A.n_cols and L[-1].A.n_rows > 0:
+        # the host setup hands over a dense inverse for up to 4096 unknowns; a larger coarsest level is inverted by
+        # amgx_create on the device (reference: the coarsest matrix is ALWAYS inverted, amg_pc.cpp:843-928)
+        desc.coarse_n = L[-1].A.n_rows * L[-1].A.br
+        desc.coarse_inv = None
+    else:
+        desc.coarse_n = hierarchy.coarse_n if clev == "inv" else 0
+        desc.coarse_inv = _lib.ptr(hierarchy.coarse_inv, C.c_double) if clev == "inv" else None
     desc.device = int(device)
     desc.use_graph = int(bool(use_graph))
     return desc, keep, info

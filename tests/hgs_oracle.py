@@ -23,7 +23,7 @@ def hgs_levels(levels, info):
         key = blk[rows].astype(np.int64) * (int(h["n_colors"]) + 1) + col[rows]
         L.gs_order = rows[np.argsort(key, kind="stable")].astype(np.int32)
         L.gs_block = blk
-        L.dinv = np.ascontiguousarray(h["dinv"][:n])
+        L.dinv = np.ascontiguousarray(h["dinv"][:n * lv.A.br * lv.A.br])
         out.append(L)
         types.append("gs_order")
     return out, types

@@ -69,3 +69,40 @@ def test_almost_everything_dirichlet(sm, osm):
     H = Hierarchy(to_matrix(p), free, p.coords, dim=3, energy=0, max_coarse_size=10)
     dev, x = _run(p, H, sm, osm)
     assert np.all(x[free == 0] == 0.0)
+
+
+@pytest.mark.parametrize("kind,sm", [("poisson", "jacobi"), ("poisson", "gs"), ("elast6", "jacobi")])
+def test_large_coarsest_level_is_inverted_on_the_device(kind, sm, monkeypatch):
+    """The reference always inverts the coarsest matrix (BaseAMGPC::CoarseLevelInv, amg_pc.cpp:843-928).  When the host
+    setup declines (more than NGSAMG_HOST_COARSE_MAX = 4096 unknowns) amgx_create forms the dense inverse on the device
+    (dense_spd.hpp: blocked Gauss-Jordan, f64 MFMA trailing updates): same cycle result as with the oracle's exact coarse
+    solve.  The limit is lowered here so that the oracle's dense Cholesky stays fast."""
+    from ngsamg_amd import fem
+    from ngsamg_amd._lib import Matrix
+    from ngsamg_amd.hierarchy import Hierarchy
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("NGSAMG_HOST_COARSE_MAX", "64")
+    if kind == "poisson":
+        p = fem.poisson_fast((26, 25, 24), dirichlet="right|top")
+        H = Hierarchy(Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val), p.free, p.coords, dim=3, energy=0, max_levels=2)
+    else:
+        p = fem.elasticity_fast((9, 8, 8), dirichlet="left", mu=1.0, lam=0.5, rotations=True)
+        H = Hierarchy(Matrix(p.n, p.n, 6, 6, p.rowptr, p.col, p.val), p.free, p.coords, dim=3, energy=1, max_levels=2, regularize_cmats=0)
+    assert H.n_levels == 2 and H.coarse_n == 0
+    nc = H.levels[-1].n * H.levels[-1].bs
+    assert nc > 128 and nc % 64 != 0            # several tiles, with padding
+    dev = DeviceAMGMatrix(H, sm_type=sm, device=0)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    x = np.empty_like(b)
+    dev.Mult(b, x)
+    ref = Oracle(H.levels, sm_type="jacobi" if sm == "jacobi" else "gs_mc").apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    # the stand-alone coarse solve: A_c x = r on the free dofs
+    r = rng.standard_normal(nc) * np.repeat(H.levels[-1].free, H.levels[-1].bs)
+    xc = np.empty(nc)
+    dev.CoarseSolve(r, xc)
+    Ac = H.levels[-1].A.to_scipy()
+    f = np.repeat(H.levels[-1].free.astype(bool), H.levels[-1].bs)
+    assert np.linalg.norm((Ac @ xc - r)[f]) <= 1e-9 * np.linalg.norm(r) and np.all(xc[~f] == 0.0)

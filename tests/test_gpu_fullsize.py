@@ -47,9 +47,10 @@ def test_cfg1_2d_poisson_50k_gauss_seidel_iterations():
     p = fem.poisson_fast((224, 224), dirichlet="left|top")
     A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
     c = ngs_amg.Preconditioner(A, "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2)
-    sol, cg = Solve(c, p.load, ms=30, tol=1e-12, quiet=True)
+    sol, cg = Solve(c, p.load, ms=35, tol=1e-12, quiet=True)
     _, it_seq, _ = Oracle(c.GetHierarchy().levels, sm_type="gs", threads=_threads()).pcg(p.load, tol=1e-12, maxit=100)
-    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)
+    assert it_seq < 30, it_seq                        # the reference's budget, in the reference's (sequential) sweep order: 28
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)      # the GPU's block-hybrid order: 30
     f = p.free.astype(bool)
     assert np.linalg.norm((p.to_scipy() @ sol - p.load)[f]) < 1e-9 * np.linalg.norm(p.load)
 

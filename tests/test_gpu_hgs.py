@@ -140,3 +140,60 @@ def test_in_cycle_kernel_probes():
             x1 = torch.empty_like(b); dev.Mult(b, x1)
             s.synchronize()
             assert torch.equal(x0, x1)
+
+
+# ---- square-block levels: bgsb_sweep_kernel (reference HybridGSSmoother<Mat<3,3>> / <Mat<6,6>>, gssmoother.cpp:891-896) ----
+
+@pytest.mark.parametrize("rot,shape", [(False, (14, 13, 12)), (True, (12, 11, 10)), (False, (40, 36))])
+@pytest.mark.parametrize("cycle", ["V", "W"])
+def test_block_levels_hgs_cycles_match_hybrid_oracle(rot, shape, cycle):
+    """elasticity levels (3x3 fine / 6x6 coarse, 6x6 everywhere, 2x2 / 3x3 in 2D) in the block-hybrid form: one launch per
+    sweep, blocks of ~128 block rows, l1-modified block diagonal; against the oracle's serial hybrid sweep"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    p, H = elasticity_case(shape, rotations=rot, max_coarse_size=10)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", mg_cycle=cycle, device=0)
+    assert dev.hgs[0] is not None and dev.hgs[0]["B"] % (64 // H.levels[0].bs) == 0, "level 0 did not take the block-hybrid path"
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = Oracle(lv, sm_type=types, cycle=cycle).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_block_levels_hgs_smoother_flags_and_iterations(rot):
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    p, H = elasticity_case((16, 14, 12), rotations=rot, max_coarse_size=10)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    orc = Oracle(lv, sm_type=types)
+    rng = np.random.default_rng(3)
+    n = p.n * p.bs
+    fr = np.repeat(p.free, p.bs).astype(np.float64)
+    A = H.levels[0].A.to_scipy()
+    for back in (False, True):
+        for ru, ur, xz in ((False, False, False), (False, True, False), (True, True, True), (False, False, True)):
+            b = rng.standard_normal(n) * fr
+            x = np.zeros(n) if xz else rng.standard_normal(n) * fr
+            res = (b - A @ x) if ru else rng.standard_normal(n)
+            xo, ro = orc.smooth(0, x.copy(), b, res.copy(), ru, ur, xz, back)
+            dev.Smooth(0, x, b, res, ru, ur, xz, back=back)
+            assert np.linalg.norm(x - xo) <= 1e-10 * max(np.linalg.norm(xo), 1.0)
+            if ur:
+                f = fr.astype(bool)
+                assert np.linalg.norm((res - ro)[f]) <= 1e-9 * max(np.linalg.norm(ro[f]), 1.0)
+    # symmetric preconditioner, and PCG needs at most 20 % more iterations than with the reference's sequential order
+    u, v = rng.standard_normal(n) * fr, rng.standard_normal(n) * fr
+    assert abs(np.dot(v, dev.apply(u)) - np.dot(u, dev.apply(v))) <= 1e-10 * abs(np.dot(v, dev.apply(u)))
+    b = rng.standard_normal(n) * fr
+    it_h = orc.pcg(b, tol=1e-8, maxit=200)[1]
+    it_seq = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=200)[1]
+    assert it_h <= int(np.ceil(1.2 * it_seq)) + 1
