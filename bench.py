@@ -548,7 +548,10 @@ def main():
                     continue
                 if l + 1 >= H.n_levels and op == 1:
                     continue
-                ms = amg.time_op(l, op, reps=50)
+                try:
+                    ms = amg.time_op(l, op, reps=50)
+                except Exception:            # (e.g. the fused Jacobi step on a Gauss-Seidel level)
+                    continue
                 M = H.levels[l].A if op < 2 else (H.levels[l].PT if op == 2 else H.levels[l].P)
                 by = matrix_bytes(M) + 8 * H.levels[l].n * H.levels[l].bs * (3 if op == 0 else 4 if op == 1 else 1 if op == 2 else 2)
                 info = amg.matrix_info(l, "A" if op < 2 else ("PT" if op == 2 else "P"))

@@ -171,7 +171,8 @@ int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* 
 int amgx_cycle_info(amgx_handle h, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n);
 /* device-format report per level matrix: which = 0 A, 1 P, 2 PT, 3 A' = A*omega*Dinv (pre-smoothing image),
  * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation); fmt: -1 not built, 0 CSR-vector,
- * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows; stored_entries counts padding
+ * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows, 4 rigid-body transfer blocks (P_ik = w_ik Q(t_ik)
+ * stored as (column, w, t): detected block by block at amgx_create, elasticity_energy.hpp:447-490); stored_entries counts padding
  * (for the traffic model in DESIGN.md) */
 int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);
 

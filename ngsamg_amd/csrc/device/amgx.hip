@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <climits>
 #include <cstdint>
@@ -20,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -94,10 +96,10 @@ struct DevBuf {
     alloc(count);
     if (count) HIPCHK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
   }
-  void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+  template <class A> void upload(const std::vector<T, A>& v) { upload(v.data(), v.size()); }
 };
 
-enum Fmt : int { FMT_CSRVEC = 0, FMT_SELL = 1, FMT_BSELL = 2 };
+enum Fmt : int { FMT_CSRVEC = 0, FMT_SELL = 1, FMT_BSELL = 2, FMT_RB = 4 };     // (3 is reported for windowed SELL, see amgx_matrix_info)
 
 struct DevMatrix {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -123,6 +125,15 @@ struct DevMatrix {
     DevBuf<uint16_t> rowloc;
     SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first, wdiag}; }
   } sell;
+  struct Rb {                          // rigid-body transfer blocks (kernels.hpp, RbMat): P_ik = w_ik Q(t_ik), or its transpose
+    int dim = 0, bf = 0, bc = 0;       // spatial dimension of Q (0: w I), fine / coarse block size
+    bool transposed = false;           // rows = coarse vertices (P^T)
+    int lanes = 16;
+    DevBuf<int32_t> ptr, col;
+    DevBuf<double> w, t;
+    int64_t nnz = 0;
+    RbMat view() const { return RbMat{ptr.p, col.p, w.p, t.p, nnz}; }
+  } rb;
   struct BSell {                       // block SELL (kernels.hpp, BSellMat)
     DevBuf<int64_t> slice_ptr;
     DevBuf<int32_t> col;
@@ -175,6 +186,11 @@ struct DevBGSB {                        // block-hybrid Gauss-Seidel on square-b
   DevMatrix off, in;                    // BSELL images: couplings that leave a workgroup's rows (global block columns, natural row
                                         //   order) / couplings inside them (LOCAL block columns, rows sorted by colour inside the block)
   DevBuf<int32_t> off_ptr, in_ptr, in_row;   // slice ranges per block / per (block, colour); local block row of every `in` slot (-1: padding)
+  // pre-smoothing from x = 0 in ONE pass over A (like DevGSB::lowin / rest): the sweep only needs the in-block couplings to LOWER
+  // colours (`lowin`, same slices as `in`); afterwards b_k - acc_k = Dmod_k x_k = fac_k A_kk x_k on every swept row, hence
+  // r = b - A x = -(R x) with R = A - L_in + (1 - fac) D - D ... stored negated in `rest` (natural order BSELL): r = rest * x
+  DevMatrix lowin, rest;
+  bool has_split = false;
   bool on() const { return BB > 0; }
 };
 
@@ -241,6 +257,29 @@ struct DevLevel {
 // host-side format construction
 // ---------------------------------------------------------------------------------------------------
 
+// vectors whose elements are NOT zeroed on resize: the SELL builders write every slot of these arrays themselves, and a serial
+// memset of 2.4 GB per image was a third of a second of amgx_create at cfg 2
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... Args> void construct(U* p, Args&&... args) { if constexpr (sizeof...(Args) > 0) ::new ((void*)p) U(std::forward<Args>(args)...); else ::new ((void*)p) U; }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
+// AMGX_SETUP_LOG=1: wall-clock time of the stages of amgx_create on stderr
+struct SetupClock {
+  bool on = std::getenv("AMGX_SETUP_LOG") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void lap(const char* what, int level = -1) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[amgx_create] %-42s level %2d  %8.1f ms\n", what, level, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // Host threads for the format builders of amgx_create (cold path, but 10^8 entries at cfg 2: serial loops were 7.5 s of
 // "upload"): contiguous index ranges, one per thread; f(begin, end, thread).  AMGX_SETUP_THREADS overrides the count.
 static int setup_threads() {
@@ -266,6 +305,39 @@ static void par_for(int64_t n, F&& f, int64_t min_per_thread = 4096) {
   for (auto& e : errs) if (e) std::rethrow_exception(e);
 }
 
+// The images of one level (A, P / P^T, smoother data, A', Q) are independent of each other: they are built by concurrent host
+// tasks, so the serial pieces of one builder (prefix sums, allocations, the host-to-device copies) overlap with the threaded
+// loops of the others.  AMGX_SETUP_SERIAL=1 runs them one after the other.
+struct SetupTasks {
+  int device;
+  bool serial = std::getenv("AMGX_SETUP_SERIAL") != nullptr;
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> errs;
+  std::mutex mu;
+  explicit SetupTasks(int dev) : device(dev) {}
+  ~SetupTasks() { for (auto& t : th) if (t.joinable()) t.join(); }
+  template <class F>
+  void run(F f) {
+    if (serial) { f(); return; }
+    th.emplace_back([this, f]() mutable {
+      try { HIPCHK(hipSetDevice(device)); f(); }
+      catch (...) { std::lock_guard<std::mutex> g(mu); errs.push_back(std::current_exception()); }
+    });
+  }
+  void wait() {
+    for (auto& t : th) if (t.joinable()) t.join();
+    th.clear();
+    if (!errs.empty()) { auto e = errs.front(); errs.clear(); std::rethrow_exception(e); }
+  }
+};
+
+template <class T>
+static void par_assign(RawVec<T>& v, size_t n, T value) {      // resize without the serial value-initialisation, fill on all threads
+  v.resize(n);
+  T* p = v.data();
+  par_for((int64_t)n, [&](int64_t a, int64_t b, int) { std::fill(p + a, p + b, value); }, 1 << 20);
+}
+
 // lanes per row of the CSR-vector kernels: the widest group that still keeps >= 80 % of its lanes busy
 // (a row of length L costs ceil(L/G) steps of G lanes), else the most efficient one
 static int pick_lanes(double avg_len) {
@@ -288,9 +360,10 @@ static int pick_lanes(double avg_len) {
 // 16-bit deltas  col = (rowrel ? row : 0) + cbase[column] + d  (see kernels.hpp, SellMat).
 struct HostSell {
   std::vector<int64_t> slice_ptr;
-  std::vector<int32_t> col32, cbase;
-  std::vector<uint16_t> col16;
-  std::vector<double> val;
+  RawVec<int32_t> col32;
+  std::vector<int32_t> cbase;
+  RawVec<uint16_t> col16;
+  RawVec<double> val;
   int64_t n_comp_slices = 0, stream_bytes = 0;
   int rowrel = 0, diag_first = 0;
 };
@@ -356,10 +429,10 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
   });
   for (int64_t s = 0; s < ns; ++s) S.slice_ptr[s + 1] += S.slice_ptr[s];
   const int64_t stored = S.slice_ptr[ns];
-  S.col32.assign(stored, 0);
-  S.col16.assign(stored, 0);
+  S.col32.resize(stored);            // (every slot of col32 / col16 / val is written by the fill pass below)
+  S.col16.resize(stored);
   S.cbase.assign(stored / WAVE, 0);
-  S.val.assign(stored, 0.0);
+  S.val.resize(stored);
   S.n_comp_slices = 0;
   S.stream_bytes = 8 * (ns + 1);
   std::vector<int64_t> t_comp(setup_threads(), 0), t_bytes(setup_threads(), 0);
@@ -473,43 +546,105 @@ static bool build_bsell(const amgx_matrix& A, DevMatrix& D, double max_pad, cons
   const int64_t ns = (n + RB - 1) / RB;
   auto row_of = [&](int64_t q) -> int64_t { return q < n ? (rows ? rows[q] : q) : -1; };
   std::vector<int64_t> sp(ns + 1, 0);
-  for (int64_t s = 0; s < ns; ++s) {
-    int w = 0;
-    for (int64_t q = s * RB; q < std::min<int64_t>(n, (s + 1) * RB); ++q) { const int64_t r = row_of(q); if (r >= 0) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r])); }
-    sp[s + 1] = sp[s] + w;
-  }
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s) {
+      int w = 0;
+      for (int64_t q = s * RB; q < std::min<int64_t>(n, (s + 1) * RB); ++q) { const int64_t r = row_of(q); if (r >= 0) w = std::max<int>(w, (int)(A.rowptr[r + 1] - A.rowptr[r])); }
+      sp[s + 1] = w;
+    }
+  }, 64);
+  for (int64_t s = 0; s < ns; ++s) sp[s + 1] += sp[s];
   const int64_t steps = sp[ns], nnz = A.rowptr[A.n_rows];
   if (nnz == 0 || (double)steps * RB > max_pad * (double)nnz) return false;
-  std::vector<int32_t> col((size_t)steps * RB, 0);
-  std::vector<double> val((size_t)steps * bs * WAVE, 0.0);
-  for (int64_t s = 0; s < ns; ++s) {
-    const int w = (int)(sp[s + 1] - sp[s]);
-    for (int rb = 0; rb < RB; ++rb) {
-      const int64_t r = row_of(s * RB + rb);
-      const int64_t rbeg = r >= 0 ? A.rowptr[r] : 0;
-      const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rbeg) : 0;
-      for (int k = 0; k < w; ++k) {
-        const int64_t kk = sp[s] + k;
-        col[kk * RB + rb] = k < len ? A.col[rbeg + k] : (int32_t)std::min<int64_t>(std::max<int64_t>(r, 0), A.n_rows - 1);   // padding: a valid block column
-        if (k >= len) continue;
-        const double* b = A.val + (rbeg + k) * bs * bs;
-        double* vk = val.data() + kk * (bs * WAVE);
-        for (int rr = 0; rr < bs; ++rr) {
-          const int lane = rb * bs + rr;
-          for (int c = 0; c < bs; ++c) {
-            const int cp = c / 2;
-            if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = b[rr * bs + c];
-            else vk[cp * (2 * WAVE) + lane * 2 + (c & 1)] = b[rr * bs + c];
+  RawVec<int32_t> col;
+  RawVec<double> val;
+  par_assign(col, (size_t)steps * RB, (int32_t)0);
+  par_assign(val, (size_t)steps * bs * WAVE, 0.0);
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t s = s0; s < s1; ++s) {
+      const int w = (int)(sp[s + 1] - sp[s]);
+      for (int rb = 0; rb < RB; ++rb) {
+        const int64_t r = row_of(s * RB + rb);
+        const int64_t rbeg = r >= 0 ? A.rowptr[r] : 0;
+        const int len = r >= 0 ? (int)(A.rowptr[r + 1] - rbeg) : 0;
+        for (int k = 0; k < w; ++k) {
+          const int64_t kk = sp[s] + k;
+          col[kk * RB + rb] = k < len ? A.col[rbeg + k] : (int32_t)std::min<int64_t>(std::max<int64_t>(r, 0), A.n_rows - 1);   // padding: a valid block column
+          if (k >= len) continue;
+          const double* b = A.val + (rbeg + k) * bs * bs;
+          double* vk = val.data() + kk * (bs * WAVE);
+          for (int rr = 0; rr < bs; ++rr) {
+            const int lane = rb * bs + rr;
+            for (int c = 0; c < bs; ++c) {
+              const int cp = c / 2;
+              if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = b[rr * bs + c];
+              else vk[cp * (2 * WAVE) + lane * 2 + (c & 1)] = b[rr * bs + c];
+            }
           }
         }
       }
     }
-  }
+  }, 16);
   D.fmt = FMT_BSELL;
   D.n_slices = (int)ns;
   D.stored = steps * RB;
   D.stream_bytes = steps * ((int64_t)bs * WAVE * 8 + RB * 4) + 8 * (ns + 1);
   D.bsell.slice_ptr.upload(sp); D.bsell.col.upload(col); D.bsell.val.upload(val);
+  return true;
+}
+
+// Rigid-body structure of a transfer matrix (see RbMat): every block of P (bf x bc) must be w Q(t), every block of P^T (bc x bf)
+// its transpose.  Returns false (and leaves D untouched) if any block deviates: the general block formats take over.
+static bool try_build_rb(const amgx_matrix& M, bool transposed, DevMatrix& D) {
+  if (std::getenv("AMGX_NO_RB_TRANSFER")) return false;
+  const int bf = transposed ? M.bc : M.br, bc = transposed ? M.br : M.bc;
+  int dim;
+  if (bc == 6 && (bf == 3 || bf == 6)) dim = 3;
+  else if (bc == 3 && (bf == 2 || bf == 3)) dim = 2;
+  else if (bc == 2 && bf == 2) dim = 0;
+  else return false;
+  const int64_t nnz = M.rowptr[M.n_rows];
+  if (nnz == 0 || nnz >= (int64_t)2147483647) return false;
+  std::vector<double> w((size_t)nnz), t((size_t)std::max(1, dim) * nnz, 0.0);
+  std::vector<char> bad(setup_threads(), 0);
+  const int br = M.br, bcm = M.bc;
+  par_for(nnz, [&](int64_t k0, int64_t k1, int tid) {
+    for (int64_t k = k0; k < k1; ++k) {
+      const double* b = M.val + k * br * bcm;
+      // entry (r of the fine block row, c of the coarse block column) of the un-transposed block
+      auto at = [&](int r, int c) { return transposed ? b[c * bcm + r] : b[r * bcm + c]; };
+      const double wk = at(0, 0);
+      double tt[3] = {0.0, 0.0, 0.0};
+      double ex[6][6];
+      for (int r = 0; r < bf; ++r) for (int c = 0; c < bc; ++c) ex[r][c] = 0.0;
+      const int nd = dim == 0 ? bf : dim;
+      for (int r = 0; r < nd; ++r) ex[r][r] = wk;
+      for (int r = nd; r < bf; ++r) ex[r][r] = wk;
+      if (dim == 3) {
+        if (wk != 0.0) { tt[0] = at(1, 5) / wk; tt[1] = at(2, 3) / wk; tt[2] = at(0, 4) / wk; }
+        ex[0][4] = wk * tt[2]; ex[0][5] = -wk * tt[1];
+        ex[1][3] = -wk * tt[2]; ex[1][5] = wk * tt[0];
+        ex[2][3] = wk * tt[1]; ex[2][4] = -wk * tt[0];
+      } else if (dim == 2) {
+        if (wk != 0.0) { tt[0] = at(1, 2) / wk; tt[1] = -at(0, 2) / wk; }
+        ex[0][2] = -wk * tt[1]; ex[1][2] = wk * tt[0];
+      }
+      const double tol = 1e-13 * (std::fabs(wk) * (1.0 + std::fabs(tt[0]) + std::fabs(tt[1]) + std::fabs(tt[2])));
+      for (int r = 0; r < bf; ++r)
+        for (int c = 0; c < bc; ++c)
+          if (!(std::fabs(at(r, c) - ex[r][c]) <= tol)) { bad[tid] = 1; return; }
+      w[k] = wk;
+      for (int q = 0; q < dim; ++q) t[(size_t)q * nnz + k] = tt[q];
+    }
+  }, 1 << 12);
+  for (char c : bad) if (c) return false;
+  std::vector<int32_t> rp((size_t)M.n_rows + 1);
+  for (int64_t i = 0; i <= M.n_rows; ++i) rp[i] = (int32_t)M.rowptr[i];
+  D.fmt = FMT_RB;
+  D.rb.dim = dim; D.rb.bf = bf; D.rb.bc = bc; D.rb.transposed = transposed; D.rb.nnz = nnz;
+  D.rb.ptr.upload(rp); D.rb.col.upload(M.col, (size_t)nnz); D.rb.w.upload(w); D.rb.t.upload(t);
+  D.stored = nnz;
+  D.stream_bytes = nnz * (4 + 8 + 8 * (int64_t)dim) + 4 * (M.n_rows + 1);
   return true;
 }
 
@@ -530,11 +665,13 @@ static void check_matrix(const amgx_matrix& A, const char* what) {
   }, 1 << 16);
 }
 
+// rb_mode: 1 = A is a prolongation, 2 = its transpose: block matrices are first tried in the rigid-body form (try_build_rb)
 static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, bool allow_sell = true, bool rowrel_ok = false, bool keep_csr = false,
-                          double max_pad = 1.35, int win = 0, const double* diag_override = nullptr) {
+                          double max_pad = 1.35, int win = 0, const double* diag_override = nullptr, int rb_mode = 0) {
   check_matrix(A, what);
   D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = A.br; D.bc = A.bc;
   D.nnz = A.rowptr[A.n_rows];
+  if (rb_mode && (A.br > 1 || A.bc > 1) && try_build_rb(A, rb_mode == 2, D)) return;
   const double avg = D.n_rows ? (double)D.nnz / (double)D.n_rows : 0.0;
   D.lanes = pick_lanes(avg);
   // scalar matrices: sliced ELL with G lanes per row; G = the smallest power of two that yields >= 2^20
@@ -799,6 +936,36 @@ struct Handle {
   template <int EP>
   void spmv_ep(const DevMatrix& M, const double* x, double* y, const EpArgs& ep, const Span sp = Span()) {
     if (M.n_rows == 0) return;
+    if (M.fmt == FMT_RB) {
+      if constexpr (EP != EP_MULT && EP != EP_AXPY) throw Err("rigid-body transfer blocks: y = M x and y = yin + s M x only");
+      else {
+        if (sp.part == PART_INT) return;             // (not split: everything runs in the boundary part)
+        const DevMatrix::Rb& R = M.rb;
+        const RbMat V = R.view();
+        if (!R.transposed) {
+          const int grid = grid_for(M.n_rows);
+#define LAUNCH_RBP(BF, BC, DM) hipLaunchKernelGGL((rb_prolong_kernel<BF, BC, DM, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, V, x, y, ep)
+          if (R.dim == 3 && R.bf == 6) LAUNCH_RBP(6, 6, 3);
+          else if (R.dim == 3) LAUNCH_RBP(3, 6, 3);
+          else if (R.dim == 2 && R.bf == 3) LAUNCH_RBP(3, 3, 2);
+          else if (R.dim == 2) LAUNCH_RBP(2, 3, 2);
+          else LAUNCH_RBP(2, 2, 0);
+#undef LAUNCH_RBP
+        } else {
+          constexpr int G = 16;
+          const int grid = grid_for(M.n_rows * G);
+#define LAUNCH_RBR(BF, BC, DM) hipLaunchKernelGGL((rb_restrict_kernel<BF, BC, DM, G, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, V, x, y, ep)
+          if (R.dim == 3 && R.bf == 6) LAUNCH_RBR(6, 6, 3);
+          else if (R.dim == 3) LAUNCH_RBR(3, 6, 3);
+          else if (R.dim == 2 && R.bf == 3) LAUNCH_RBR(3, 3, 2);
+          else if (R.dim == 2) LAUNCH_RBR(2, 3, 2);
+          else LAUNCH_RBR(2, 2, 0);
+#undef LAUNCH_RBR
+        }
+        HIPCHK(hipGetLastError());
+        return;
+      }
+    }
     if (M.fmt == FMT_SELL && M.sell.win) {
       if (M.sell.win != SELL_WIN) throw Err("windowed SELL: unexpected window size");
       int64_t a, b;
@@ -836,13 +1003,17 @@ struct Handle {
 #undef LAUNCH_CSR
     } else if constexpr (EP == EP_PRE) {
       throw Err("EP_PRE is only built for scalar matrices");
-    } else if (sp.part == PART_INT) {
-      return;                                   // block formats are not split: everything runs in the boundary part
     } else if (M.fmt == FMT_BSELL) {
-      const int grid = (M.n_slices + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-      if (M.br == 6) hipLaunchKernelGGL((bsell_spmv_kernel<6, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
-      else if (M.br == 3) hipLaunchKernelGGL((bsell_spmv_kernel<3, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
-      else hipLaunchKernelGGL((bsell_spmv_kernel<2, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, M.n_slices, M.bsell.view(), x, y, ep);
+      // units of RB = 64 / bs block rows (one slice); slices that straddle n_int belong to the boundary part
+      int64_t a, b;
+      unit_range(sp, WAVE / M.br, M.n_slices, a, b);
+      if (b <= a) return;
+      const int grid = (int)((b - a + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+      if (M.br == 6) hipLaunchKernelGGL((bsell_spmv_kernel<6, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, (int)a, (int)b, M.bsell.view(), x, y, ep);
+      else if (M.br == 3) hipLaunchKernelGGL((bsell_spmv_kernel<3, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, (int)a, (int)b, M.bsell.view(), x, y, ep);
+      else hipLaunchKernelGGL((bsell_spmv_kernel<2, EP>), dim3(grid), dim3(BLOCK), 0, stream, M.n_rows, (int)a, (int)b, M.bsell.view(), x, y, ep);
+    } else if (sp.part == PART_INT) {
+      return;                                   // the CSR block formats are not split: everything runs in the boundary part
     } else if (M.br >= 2 && M.bc >= 2 && (EP != EP_JAC || M.br == M.bc) && (M.br == M.bc || M.nnz >= 6 * M.n_rows)) {
       // (short rectangular rows, i.e. prolongations with <= 4 blocks per row, stay with the lane-per-block kernel: measured)
       // row-per-lane block CSR kernel; W lane groups per block row chosen from the average row length
@@ -1027,13 +1198,14 @@ struct Handle {
   }
 
   // one block-hybrid Gauss-Seidel sweep on a square-block level (bgsb_sweep_kernel): ONE launch; xin == nullptr: from x = 0
-  void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b) {
+  void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b, bool lower_only = false) {
     Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
     const DevBGSB& g = L.bgsb;
     if (g.n_blocks == 0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
     const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double);
-    const BSellMat OFF = g.off.bsell.view(), IN = g.in.bsell.view();
+    if (lower_only && (xin != nullptr || !g.has_split)) throw Err("block-hybrid Gauss-Seidel: the lower-colour copy serves the sweep from zero only");
+    const BSellMat OFF = g.off.bsell.view(), IN = lower_only ? g.lowin.bsell.view() : g.in.bsell.view();
 #define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(g.n_blocks), dim3(BLOCK), lds, stream, L.n, g.BB, 0, OFF, g.off_ptr.p, IN, \
                                                g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, xin, xout)
     const bool fz = xin == nullptr;
@@ -1178,9 +1350,15 @@ struct Handle {
         if (fold) diag_apply(L, r, x, true); // z = x + omega * Dinv * r  (folded post-smoothing, see fold_prolongation)
       }
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.bgsb.on()) {
-      // forward block-hybrid sweep from x = 0 (nothing outside the workgroup's rows is read), then the residual
-      bgsb_sweep(L, 0, nullptr, x, b);
-      residual(L.A, x, b, r);
+      // forward block-hybrid sweep from x = 0 (nothing outside the workgroup's rows is read), then the residual; with the
+      // split copies A is read once in total: r = rest * x (see DevBGSB)
+      if (L.bgsb.has_split) {
+        bgsb_sweep(L, 0, nullptr, x, b, true);
+        mult(L.bgsb.rest, x, r);
+      } else {
+        bgsb_sweep(L, 0, nullptr, x, b);
+        residual(L.A, x, b, r);
+      }
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on()) {
       // forward block-hybrid sweep from x = 0: inside a block only couplings to lower colours contribute (all other
       // values are still 0); afterwards (b - L_in x)_k = x_k / dinv_k on every swept row, hence
@@ -1740,8 +1918,14 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
 // BSELL image of selected entries of a square-block matrix: `rows` lists block rows in storage order (-1 = padding slot),
 // slices of RB = 64 / bs consecutive list entries; keep(i, j) selects entries, mapcol(i, j) gives the stored block column,
 // padcol = column of padding steps (any valid index of the gathered vector).
+template <class Keep, class MapCol, class Scale>
+static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& rows, Keep keep, MapCol mapcol, int32_t padcol, DevMatrix& D, Scale scale);
 template <class Keep, class MapCol>
 static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& rows, Keep keep, MapCol mapcol, int32_t padcol, DevMatrix& D) {
+  build_bsell_sel(A, rows, keep, mapcol, padcol, D, [](int32_t, int32_t) { return 1.0; });
+}
+template <class Keep, class MapCol, class Scale>
+static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& rows, Keep keep, MapCol mapcol, int32_t padcol, DevMatrix& D, Scale scale) {
   const int bs = A.br;
   const int RB = WAVE / bs;
   const int64_t m = (int64_t)rows.size();
@@ -1763,8 +1947,10 @@ static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& ro
   }, 16);
   for (int64_t s = 0; s < ns; ++s) sp[s + 1] += sp[s];
   const int64_t steps = sp[ns];
-  std::vector<int32_t> col((size_t)std::max<int64_t>(1, steps * RB), padcol);
-  std::vector<double> val((size_t)std::max<int64_t>(1, steps * bs * WAVE), 0.0);
+  RawVec<int32_t> col;
+  RawVec<double> val;
+  par_assign(col, (size_t)std::max<int64_t>(1, steps * RB), padcol);
+  par_assign(val, (size_t)std::max<int64_t>(1, steps * bs * WAVE), 0.0);
   par_for(ns, [&](int64_t s0, int64_t s1, int) {
     for (int64_t s = s0; s < s1; ++s)
       for (int rb = 0; rb < RB; ++rb) {
@@ -1776,12 +1962,13 @@ static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& ro
           if (!keep(i, j)) continue;
           col[kk * RB + rb] = mapcol(i, j);
           const double* blk = A.val + k * bs * bs;
+          const double sc = scale(i, j);
           double* vk = val.data() + kk * (bs * WAVE);
           for (int rr = 0; rr < bs; ++rr) {
             const int lane = rb * bs + rr;
             for (int c = 0; c < bs; ++c) {
-              if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = blk[rr * bs + c];
-              else vk[(c / 2) * (2 * WAVE) + lane * 2 + (c & 1)] = blk[rr * bs + c];
+              if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = sc * blk[rr * bs + c];
+              else vk[(c / 2) * (2 * WAVE) + lane * 2 + (c & 1)] = sc * blk[rr * bs + c];
             }
           }
           ++kk;
@@ -1828,6 +2015,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   g.BB = BB; g.n_blocks = nblk; g.n_colors = nc;
   // off: natural order, every block padded to whole slices
   std::vector<int32_t> rows_off, off_ptr(nblk + 1, 0);
+  rows_off.reserve((size_t)n + (size_t)nblk * RB);
   for (int blk = 0; blk < nblk; ++blk) {
     const int64_t b0 = (int64_t)blk * BB, b1 = std::min<int64_t>(n, b0 + BB);
     for (int64_t i = b0; i < b1; ++i) rows_off.push_back((int32_t)i);
@@ -1850,6 +2038,40 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   for (size_t q = 0; q < rows_in.size(); ++q) in_row[q] = rows_in[q] < 0 ? -1 : (int32_t)(rows_in[q] % BB);
   build_bsell_sel(d.A, rows_in, [&](int32_t i, int32_t j) { return same_block(i, j); }, [BB](int32_t, int32_t j) { return (int32_t)(j % BB); }, 0, g.in);
   g.off_ptr.upload(off_ptr); g.in_ptr.upload(in_ptr); g.in_row.upload(in_row);
+  // ---- one-pass pre-smoothing from zero: valid where dinv_k is a true inverse of fac_k * A_kk (not a pseudo-inverse) ----------
+  if (std::getenv("AMGX_BGSB_NO_SPLIT")) return;
+  std::vector<double> fac((size_t)n, 1.0);
+  std::vector<char> nofac(setup_threads(), 0);
+  par_for(n, [&](int64_t i0, int64_t i1, int t) {
+    for (int64_t i = i0; i < i1; ++i) {
+      if (d.color[i] < 0) continue;
+      const double* Akk = nullptr;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) if (d.A.col[k] == i) { Akk = d.A.val + k * bs * bs; break; }
+      if (!Akk) { nofac[t] = 1; return; }
+      const double* Dk = d.dinv + i * bs * bs;
+      // M = Dinv_k A_kk must be (1 / fac) I with fac >= 1
+      double m00 = 0.0;
+      for (int c = 0; c < bs; ++c) m00 += Dk[c] * Akk[c * bs];
+      if (!(m00 > 1e-12 && m00 <= 1.0 + 1e-10)) { nofac[t] = 1; return; }
+      for (int r = 0; r < bs; ++r)
+        for (int c = 0; c < bs; ++c) {
+          double m = 0.0;
+          for (int q = 0; q < bs; ++q) m += Dk[r * bs + q] * Akk[q * bs + c];
+          if (std::fabs(m - (r == c ? m00 : 0.0)) > 1e-10 * m00) { nofac[t] = 1; return; }
+        }
+      fac[i] = 1.0 / m00;
+    }
+  });
+  for (char c : nofac) if (c) return;
+  auto lower_in = [&](int32_t i, int32_t j) { return j != i && same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && d.color[j] < d.color[i]; };
+  build_bsell_sel(d.A, rows_in, lower_in, [BB](int32_t, int32_t j) { return (int32_t)(j % BB); }, 0, g.lowin);
+  if (g.lowin.n_slices != g.in.n_slices) throw Err("block-hybrid Gauss-Seidel: lower / in slice mismatch");
+  std::vector<int32_t> rows_nat;
+  for (int64_t i = 0; i < n; ++i) rows_nat.push_back((int32_t)i);
+  while (rows_nat.size() % RB) rows_nat.push_back(-1);
+  build_bsell_sel(d.A, rows_nat, [&](int32_t i, int32_t j) { return !lower_in(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.rest,
+                  [&](int32_t i, int32_t j) { return (i == j && d.color[i] >= 0) ? fac[i] - 1.0 : -1.0; });
+  g.has_split = true;
 }
 
 struct HostCsr {
@@ -2129,6 +2351,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
   std::vector<amgx_level_desc> pl(d->levels, d->levels + d->n_levels);
   std::vector<LevelPerm> pstore(d->n_levels);
   permute_gs_levels(d, pl, pstore);
+  SetupClock clk;
+  clk.lap("renumbering of Gauss-Seidel levels");
   h->perm.resize(d->n_levels);
   for (int l = 0; l < d->n_levels; ++l) if (!pstore[l].perm.empty()) h->perm[l].upload(pstore[l].perm);
   const amgx_level_desc* levels = pl.data();
@@ -2142,39 +2366,43 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     L.sm_type = s.sm_type; L.omega = s.omega; L.sm_steps = s.sm_steps; L.sm_symm = s.sm_symm;
     if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS && s.sm_type != AMGX_SM_BGS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
+    SetupTasks tasks(d->device);
     // block GS walks the CSR arrays of A, so keep A in CSR there
-    upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0);
+    tasks.run([&] { upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0); });
     if (!last) {
       const amgx_level_desc& c = levels[l + 1];
       if (s.P.n_rows != s.A.n_rows || s.P.n_cols > c.A.n_cols || s.P.n_cols < c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
         throw Err("P does not match the level matrices");
       if (s.PT.n_rows != s.P.n_cols || s.PT.n_cols != s.P.n_rows || s.PT.br != s.P.bc || s.PT.bc != s.P.br)
         throw Err("PT does not match P");
-      upload_matrix(s.P, L.P, "P");
-      upload_matrix(s.PT, L.PT, "PT");
-      // big scalar levels restrict through the column-blocked form (the P^T gather is TA/L2-bound there)
-      {
+      if (!s.dinv) throw Err("dinv missing");
+      tasks.run([&] {
+        upload_matrix(s.P, L.P, "P", true, false, false, 1.35, 0, nullptr, 1);
+        upload_matrix(s.PT, L.PT, "PT", true, false, false, 1.35, 0, nullptr, 2);
+        // big scalar levels restrict through the column-blocked form (the P^T gather is TA/L2-bound there)
         // Measured non-win (profiles/r01/restrict_blocked.txt): 121 + 22 us vs 134 us for the P^T gather at cfg 2,
         // so the blocked form is OFF unless AMGX_RESTRICT_MIN_ROWS asks for it (kept for the fused-residual plan).
         int64_t min_rows = INT64_MAX;
         if (const char* e = std::getenv("AMGX_RESTRICT_MIN_ROWS")) min_rows = std::atoll(e);
         if (s.P.br == 1 && s.P.bc == 1 && s.P.n_rows >= min_rows && s.P.rowptr[s.P.n_rows] < (int64_t)2147483647)
           build_restrict(s.P, L.R);
-      }
-      if (!s.dinv) throw Err("dinv missing");
-      L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
-      if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
-      else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
-      else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
-      if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
+      });
+      tasks.run([&] {
+        L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
+        if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
+        else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
+        else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
+        if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
+      });
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
+        tasks.run([&] {
         // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
-        std::vector<double> sv((size_t)nnz);
+        std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnz)]);      // (uninitialised: every entry is written below)
         // (rank-partitioned levels: dinv must cover the ghost columns too, i.e. n_cols entries)
         par_for(nnz, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
         amgx_matrix As = s.A;
-        As.val = sv.data();
+        As.val = sv.get();
         // one-thread-per-row form: the diagonal slot carries omega*Dinv_i (SellMat::wdiag), the epilogue then needs no
         // dinv stream (80 MB per pass at cfg 2); AMGX_NO_WDIAG=1 keeps A'_ii there
         std::vector<double> wdv;
@@ -2190,10 +2418,10 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             }
           });
           bool plain = true;
-          for (char c : notplain) if (c) plain = false;
+          for (char cc : notplain) if (cc) plain = false;
           if (plain) {
             wdv.resize((size_t)s.A.n_rows);
-            for (int64_t i = 0; i < s.A.n_rows; ++i) wdv[i] = s.omega * s.dinv[i];
+            par_for(s.A.n_rows, [&](int64_t i0, int64_t i1, int) { for (int64_t i = i0; i < i1; ++i) wdv[i] = s.omega * s.dinv[i]; }, 1 << 16);
           }
         }
         upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
@@ -2207,6 +2435,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
           build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
         }
+        });
         // post-smoothing folded into the prolongation (V-cycle).  Square levels: Q is built here.  Rank-partitioned
         // levels: Q needs the P rows of the ghost vertices, so the caller supplies it (amgx_level_desc.Q) and drives
         // the level through amgx_cycle_down / amgx_cycle_up.
@@ -2217,15 +2446,17 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             if (s.Q.n_rows != s.A.n_rows || s.Q.br != 1 || s.Q.bc != 1 || s.Q.n_cols < c.A.n_rows || s.Q.n_cols > c.A.n_cols)
               throw Err("Q does not match the level matrices");
             if (s.Q.rowptr[s.Q.n_rows] >= (int64_t)2147483647) throw Err("Q: too many entries");
-            upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+            tasks.run([&, qpad] { upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN); });
           } else if (s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows) {
-            HostCsr q;
-            fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
-            if (q.rowptr[s.A.n_rows] < (int64_t)2147483647) {
-              amgx_matrix Qm = s.P;
-              Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
-              upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
-            }
+            tasks.run([&, qpad] {
+              HostCsr q;
+              fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
+              if (q.rowptr[s.A.n_rows] < (int64_t)2147483647) {
+                amgx_matrix Qm = s.P;
+                Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
+                upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+              }
+            });
           }
         }
       }
@@ -2234,6 +2465,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows && s.P.br == s.A.br && !std::getenv("AMGX_NO_FOLD") &&
           !std::getenv("AMGX_NO_BLOCK_FOLD"))
       {
+        tasks.run([&] {
         HostCsr q;
         fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
         // Fold only where it pays: the way up then streams Q instead of A + P (+ the round trip of x + P x_c), but
@@ -2249,14 +2481,19 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
           upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)");
         }
+        });
       }
+      tasks.wait();
+      clk.lap("level images (A, P, P^T, smoother data, A', Q: concurrent host tasks)", l);
     } else if (s.dinv) {
+      tasks.wait();
       L.dinv.upload(s.dinv, (size_t)L.n * L.bs * L.bs);
       if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
       else if (s.sm_type == AMGX_SM_GS && s.color && s.gs_block_rows > 0) build_gsb(s, L, nullptr);
       else if (s.sm_type == AMGX_SM_GS && s.color) build_gs(s, L);
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
+    tasks.wait();
     const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
     HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));
@@ -2389,7 +2626,9 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     }
   }
   HIPCHK(hipDeviceSynchronize());
+  clk.lap("coarse inverse, tail program");
   if (dense_first >= 0) build_dense_tail(*h, d, levels, dense_first);
+  clk.lap("collapsed coarse levels (dense operator)");
   return h.release();
 }
 

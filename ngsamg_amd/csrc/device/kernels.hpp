@@ -454,11 +454,12 @@ struct BSellMat {
 #define BSELL_UNROLL 2
 #endif
 template <int BS, int EP>
-__global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int n_slices, BSellMat M,
+__global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int slice0, int n_slices, BSellMat M,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
   constexpr int RB = WAVE / BS;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  // (slice0 .. n_slices: interior / boundary block rows of a rank-partitioned level, see sell_spmv_kernel)
+  const int s = __builtin_amdgcn_readfirstlane(slice0 + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
   const int rbl = lane / BS < RB ? lane / BS : RB - 1;      // idle lanes (lane >= RB*BS) shadow the last block row
   const int r = lane % BS;
@@ -1596,6 +1597,107 @@ __global__ __launch_bounds__(BLOCK) void dense_gemv_kernel(int n, const double* 
 #pragma unroll
   for (int o = WAVE >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
   if (lane == 0) y[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Rigid-body transfer blocks.  The prolongation blocks of the elasticity (and vector-H1) hierarchies are not general
+// matrices: P_ik = w_ik Q(t_ik) with the rigid-body transformation Q(t) = [I, -skew(t); 0, I] of the offset t between the
+// fine vertex and the coarse vertex (reference src/elasticity/elasticity_energy.hpp:447-490, the aux-smoothed
+// prolongation multiplies it with a SCALAR weight, vertex_factory_impl.hpp:1968-2020).  Streaming the 6 x 6 block costs
+// 292 bytes per entry, its generator (column, w, t) 36: the transfers of cfg 5 shrink from 1.9 GB to 0.24 GB per pass and
+// the block is rebuilt in registers (u_f = w (u_c + o_c x t), o_f = w o_c).  amgx_create detects the structure block by
+// block and keeps the general block-CSR form for anything else.
+//   DIM 3: coarse block size 6, fine 3 (displacements only) or 6;  DIM 2: coarse 3, fine 2 or 3 (w I for vector H1 = t = 0);
+//   DIM 0: w I with equal block sizes
+struct RbMat {
+  const int32_t* ptr;         // [n_rows + 1]
+  const int32_t* col;         // [nnz]
+  const double* w;            // [nnz]
+  const double* t;            // [DIM][nnz] (structure of arrays)
+  int64_t nnz;
+};
+template <int BF, int BC, int DIM>
+__device__ __forceinline__ void rb_forward(const double* __restrict__ xc, double w, double t0, double t1, double t2, double* acc) {
+  // acc[0..BF) += w Q(t) xc
+  if (DIM == 3) {
+    const double o0 = xc[3], o1 = xc[4], o2 = xc[5];
+    acc[0] += w * (xc[0] + o1 * t2 - o2 * t1);
+    acc[1] += w * (xc[1] + o2 * t0 - o0 * t2);
+    acc[2] += w * (xc[2] + o0 * t1 - o1 * t0);
+    if (BF == 6) { acc[3] += w * o0; acc[4] += w * o1; acc[5] += w * o2; }
+  } else if (DIM == 2) {
+    const double o = xc[2];
+    acc[0] += w * (xc[0] - t1 * o);
+    acc[1] += w * (xc[1] + t0 * o);
+    if (BF == 3) acc[2] += w * o;
+  } else {
+#pragma unroll
+    for (int r = 0; r < BF; ++r) acc[r] += w * xc[r];
+  }
+}
+template <int BF, int BC, int DIM>
+__device__ __forceinline__ void rb_transposed(const double* __restrict__ rf, double w, double t0, double t1, double t2, double* acc) {
+  // acc[0..BC) += w Q(t)^T rf
+  if (DIM == 3) {
+    const double f0 = rf[0], f1 = rf[1], f2 = rf[2];
+    acc[0] += w * f0; acc[1] += w * f1; acc[2] += w * f2;
+    double m0 = t1 * f2 - t2 * f1, m1 = t2 * f0 - t0 * f2, m2 = t0 * f1 - t1 * f0;
+    if (BF == 6) { m0 += rf[3]; m1 += rf[4]; m2 += rf[5]; }
+    acc[3] += w * m0; acc[4] += w * m1; acc[5] += w * m2;
+  } else if (DIM == 2) {
+    acc[0] += w * rf[0]; acc[1] += w * rf[1];
+    double m = -t1 * rf[0] + t0 * rf[1];
+    if (BF == 3) m += rf[2];
+    acc[2] += w * m;
+  } else {
+#pragma unroll
+    for (int r = 0; r < BC; ++r) acc[r] += w * rf[r];
+  }
+}
+// y = (yin) + s * P x_c : one thread per fine block row (rows have ~3 entries); EP_MULT or EP_AXPY
+template <int BF, int BC, int DIM, int EP>
+__global__ __launch_bounds__(BLOCK) void rb_prolong_kernel(int64_t n_rows, RbMat M, const double* __restrict__ x, double* y, EpArgs ep) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n_rows) return;
+  double acc[BF];
+#pragma unroll
+  for (int r = 0; r < BF; ++r) acc[r] = 0.0;
+  const int e = M.ptr[i + 1];
+  for (int k = M.ptr[i]; k < e; ++k) {
+    const double* __restrict__ xc = x + (int64_t)M.col[k] * BC;
+    const double w = M.w[k];
+    const double t0 = DIM >= 2 ? M.t[k] : 0.0, t1 = DIM >= 2 ? M.t[M.nnz + k] : 0.0, t2 = DIM == 3 ? M.t[2 * M.nnz + k] : 0.0;
+    rb_forward<BF, BC, DIM>(xc, w, t0, t1, t2, acc);
+  }
+#pragma unroll
+  for (int r = 0; r < BF; ++r) y[i * BF + r] = EP == EP_AXPY ? ep.yin[i * BF + r] + ep.s * acc[r] : acc[r];
+}
+// y = P^T r : G lanes per coarse block row (rows have 30 ... 60 entries), entries (fine row, w, t)
+template <int BF, int BC, int DIM, int G, int EP>
+__global__ __launch_bounds__(BLOCK) void rb_restrict_kernel(int64_t n_rows, RbMat M, const double* __restrict__ x, double* y, EpArgs ep) {
+  const int64_t tg = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t J = tg / G;
+  const int sub = (int)(tg % G);
+  double acc[BC];
+#pragma unroll
+  for (int r = 0; r < BC; ++r) acc[r] = 0.0;
+  if (J < n_rows) {
+    const int e = M.ptr[J + 1];
+    for (int k = M.ptr[J] + sub; k < e; k += G) {
+      const double* __restrict__ rf = x + (int64_t)M.col[k] * BF;
+      const double w = M.w[k];
+      const double t0 = DIM >= 2 ? M.t[k] : 0.0, t1 = DIM >= 2 ? M.t[M.nnz + k] : 0.0, t2 = DIM == 3 ? M.t[2 * M.nnz + k] : 0.0;
+      rb_transposed<BF, BC, DIM>(rf, w, t0, t1, t2, acc);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < BC; ++r)
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, G);
+  if (J < n_rows && sub == 0) {
+#pragma unroll
+    for (int r = 0; r < BC; ++r) y[J * BC + r] = EP == EP_AXPY ? ep.yin[J * BC + r] + ep.s * acc[r] : acc[r];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -145,14 +145,16 @@ def test_in_cycle_kernel_probes():
 # ---- square-block levels: bgsb_sweep_kernel (reference HybridGSSmoother<Mat<3,3>> / <Mat<6,6>>, gssmoother.cpp:891-896) ----
 
 @pytest.mark.parametrize("rot,shape", [(False, (14, 13, 12)), (True, (12, 11, 10)), (False, (40, 36))])
-@pytest.mark.parametrize("cycle", ["V", "W"])
-def test_block_levels_hgs_cycles_match_hybrid_oracle(rot, shape, cycle):
+@pytest.mark.parametrize("cycle,split", [("V", True), ("W", True), ("V", False)])
+def test_block_levels_hgs_cycles_match_hybrid_oracle(rot, shape, cycle, split, monkeypatch):
     """elasticity levels (3x3 fine / 6x6 coarse, 6x6 everywhere, 2x2 / 3x3 in 2D) in the block-hybrid form: one launch per
     sweep, blocks of ~128 block rows, l1-modified block diagonal; against the oracle's serial hybrid sweep"""
     from ngsamg_amd.device import DeviceAMGMatrix
     from oracle.pyoracle import Oracle
     from tests.problems import elasticity_case
     from tests.hgs_oracle import hgs_levels
+    if not split:         # pre-smoothing as sweep + full residual instead of the one-pass lower / rest copies
+        monkeypatch.setenv("AMGX_BGSB_NO_SPLIT", "1")
     p, H = elasticity_case(shape, rotations=rot, max_coarse_size=10)
     dev = DeviceAMGMatrix(H, sm_type="hgs", mg_cycle=cycle, device=0)
     assert dev.hgs[0] is not None and dev.hgs[0]["B"] % (64 // H.levels[0].bs) == 0, "level 0 did not take the block-hybrid path"

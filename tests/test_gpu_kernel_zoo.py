@@ -138,3 +138,51 @@ def test_transfer_block_shapes(bf, bc_, avg):
     out = np.empty_like(xf)
     dev.Prolong(0, 1.0, xf, xc, out)
     assert _rel(out, xf + Ps @ xc) < 1e-13
+
+
+@pytest.mark.parametrize("shape,rot", [((9, 8, 7), False), ((9, 8, 7), True), ((20, 17), False), ((20, 17), True)])
+def test_rigid_body_transfer_blocks(shape, rot, monkeypatch):
+    """P_ik = w_ik Q(t_ik) (elasticity_energy.hpp:447-490) stored as (column, w, t) instead of the bf x bc block:
+    amgx_create detects the structure; TransferF2C / AddC2F (dof_map.cpp:636-709) agree with the general block kernels and
+    with scipy on the explicit matrices, and a perturbed block falls back to the general format"""
+    import scipy.sparse as sp
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from tests.problems import elasticity_case
+    p, H = elasticity_case(shape, rotations=rot, max_coarse_size=5)
+    dev = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
+    monkeypatch.setenv("AMGX_NO_RB_TRANSFER", "1")
+    gen = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
+    monkeypatch.delenv("AMGX_NO_RB_TRANSFER")
+    rng = np.random.default_rng(0)
+    for l in range(H.n_levels - 1):
+        assert dev.matrix_info(l, "P")["fmt"] == "rigid-body" and dev.matrix_info(l, "PT")["fmt"] == "rigid-body"
+        assert gen.matrix_info(l, "P")["fmt"] != "rigid-body"
+        assert dev.matrix_info(l, "P")["stream_bytes"] < (0.3 if len(shape) == 3 else 0.7) * gen.matrix_info(l, "P")["stream_bytes"]
+        P = H.levels[l].P.to_scipy()
+        nf, nc = P.shape
+        xf, xc = rng.standard_normal(nf), rng.standard_normal(nc)
+        got, ref = np.empty(nc), np.empty(nc)
+        dev.TransferF2C(l, xf, got)
+        gen.TransferF2C(l, xf, ref)
+        assert np.linalg.norm(got - P.T @ xf) <= 1e-13 * np.linalg.norm(P.T @ xf) and np.linalg.norm(got - ref) <= 1e-13 * np.linalg.norm(ref)
+        y1, y2 = xf.copy(), xf.copy()
+        dev.AddC2F(l, -0.7, y1, xc)
+        gen.AddC2F(l, -0.7, y2, xc)
+        assert np.linalg.norm(y1 - (xf - 0.7 * (P @ xc))) <= 1e-13 * np.linalg.norm(y1) and np.linalg.norm(y1 - y2) <= 1e-13 * np.linalg.norm(y2)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    x1, x2 = np.empty_like(b), np.empty_like(b)
+    dev.Mult(b, x1)
+    gen.Mult(b, x2)
+    assert np.linalg.norm(x1 - x2) <= 1e-12 * np.linalg.norm(x2)
+    # one block that is not a rigid-body transformation: the level keeps the general block format
+    import copy
+    H2 = _H(list(H.levels))
+    H2.coarse_n, H2.coarse_inv = H.coarse_n, H.coarse_inv
+    L0 = copy.copy(H.levels[0])
+    Pm = copy.copy(L0.P)
+    Pm.val = L0.P.val.copy()
+    Pm.val.reshape(-1)[1] += 1e-3
+    L0.P = Pm
+    H2.levels[0] = L0
+    dev2 = DeviceAMGMatrix(H2, sm_type="jacobi", device=0)
+    assert dev2.matrix_info(0, "P")["fmt"] != "rigid-body" and dev2.matrix_info(0, "PT")["fmt"] == "rigid-body"

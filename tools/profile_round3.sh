@@ -1,0 +1,64 @@
+#!/bin/bash
+# Profiles of round 3 on the GPU box (gpurun): kernel-trace statistics and HBM traffic counters of bench.py for cfg 2 (Jacobi,
+# Gauss-Seidel) AND the block configurations cfg 3 / cfg 5 ("no rocprof evidence at all for cfg 3 / cfg 5").
+#   tools/profile_round3.sh <out_dir under gpurun_out> <commit> [part]      part: a (cfg 2), b (cfg 3 / cfg 5), c (rank-partitioned), default all
+# PMC passes are separate runs with --pmc only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).
+set -o pipefail
+OUT=gpurun_out/$1; COMMIT=$2; PART=${3:-abc}
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# every native library is built HERE, outside the profiler: under rocprofv3 the preloaded profiler library has initialised the
+# GPU before python starts, and a compiler child spawned from the profiled process would be an exec hop the pool refuses
+python -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1 || { echo "build failed" >> $OUT/progress.txt; exit 1; }
+export NGSAMG_NO_BUILD=1
+kt() {   # kt <tag> <bench args...>: kernel trace + stats of one bench command; stats of the launches after amgx_create beside rocprof's own
+  tag=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$tag -- python bench.py "$@" > $OUT/bench_under_rocprof_$tag.json 2> $OUT/kt_$tag.log
+  f=$(find $OUT/kt_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$tag.csv
+  f=$(find $OUT/kt_$tag -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/stats_after_setup.py $f $OUT/kernel_stats_${tag}_after_setup.csv
+  rm -rf $OUT/kt_$tag; echo "kt $tag done" >> $OUT/progress.txt
+}
+pmc() {  # pmc <tag> <bench args...>: the two counter passes, summarised per kernel
+  tag=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${tag}_$c -- python bench.py "$@" --no-graph --steps 5 --warmup 2 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $OUT/pmc_${tag}_$c.log
+    f=$(find $OUT/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py $f $OUT/pmc_${tag}_${c}_by_kernel.csv
+    rm -rf $OUT/pmc_${tag}_$c
+  done
+  echo "pmc $tag done" >> $OUT/progress.txt
+}
+if [[ $PART == *a* ]]; then
+  kt jacobi                                   # the driver's command
+  kt gs --smoother gs --steps 50 --warmup 10 --no-cpu-baseline --no-reference-defaults
+  pmc jacobi
+  pmc gs --smoother gs
+  python bench.py > $OUT/bench_jacobi.json 2> $OUT/bench_jacobi.err; echo "bench jacobi" >> $OUT/progress.txt
+  python bench.py --smoother gs --steps 100 --no-reference-defaults > $OUT/bench_gs.json 2> $OUT/bench_gs.err; echo "bench gs" >> $OUT/progress.txt
+  python bench.py --hierarchy spw --steps 100 --no-cpu-baseline > $OUT/bench_jacobi_spw_hierarchy.json 2> /dev/null
+  python bench.py --nv 108 --no-cpu-baseline --no-reference-defaults > $OUT/bench_nv108.json 2> /dev/null
+fi
+if [[ $PART == *b* ]]; then
+  for cfg in cfg3 cfg5; do
+    kt ${cfg}_jacobi --config $cfg --steps 50 --warmup 10 --no-cpu-baseline --no-reference-defaults
+    kt ${cfg}_gs --config $cfg --smoother gs --steps 50 --warmup 10 --no-cpu-baseline --no-reference-defaults
+    pmc ${cfg}_jacobi --config $cfg
+    pmc ${cfg}_gs --config $cfg --smoother gs
+    python bench.py --config $cfg --steps 50 --warmup 10 --cpu-seconds 8 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+    python bench.py --config $cfg --smoother gs --steps 50 --warmup 10 --cpu-seconds 8 > $OUT/bench_${cfg}_gs.json 2> $OUT/bench_${cfg}_gs.err
+    echo "bench $cfg" >> $OUT/progress.txt
+  done
+fi
+if [[ $PART == *c* ]]; then
+  NGSAMG_FORCE_DIST=1 python bench.py --steps 100 --no-cpu-baseline > $OUT/bench_dist_world1.json 2> $OUT/bench_dist_world1.err
+  NGSAMG_FORCE_DIST=1 python bench.py --nv 108 --steps 200 --no-cpu-baseline > $OUT/bench_dist_world1_nv108.json 2> /dev/null
+  AMGX_DIST_GRAPH=0 NGSAMG_FORCE_DIST=1 python bench.py --nv 108 --steps 200 --no-cpu-baseline > $OUT/bench_dist_world1_nv108_direct_launches.json 2> /dev/null
+  NGSAMG_FORCE_DIST=1 python bench.py --smoother gs --steps 50 --no-cpu-baseline > $OUT/bench_dist_world1_gs.json 2> /dev/null
+  NGSAMG_FORCE_DIST=1 python bench.py --config cfg3 --steps 30 --warmup 5 > $OUT/bench_dist_world1_cfg3.json 2> /dev/null
+  NGSAMG_FORCE_DIST=1 python bench.py --config cfg5 --smoother gs --steps 30 --warmup 5 > $OUT/bench_dist_world1_cfg5_gs.json 2> /dev/null; echo "bench dist" >> $OUT/progress.txt
+  NGSAMG_FORCE_DIST=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_d1 -- python bench.py --nv 108 --steps 5 --warmup 3 --no-cpu-baseline > /dev/null 2> $OUT/trace_d1.log
+  f=$(find $OUT/trace_d1 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 > $OUT/trace_dist_world1_nv108.txt
+  rm -rf $OUT/trace_d1
+fi
+echo $COMMIT > $OUT/commit.txt
+ls $OUT
