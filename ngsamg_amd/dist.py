@@ -370,17 +370,21 @@ def _bs(s):
     return int(getattr(s, "bs", 1))
 
 
-def _spmm(A, B):
-    """C = A B through the host library (OpenMP Gustavson, sorted columns)"""
+def _spmm(A, B, br=1, bk=1, bc=1):
+    """C = A B through the host library (OpenMP Gustavson, sorted columns).  A has br x bk blocks, B bk x bc blocks (scalar
+    scipy matrices in AoS numbering): the product runs on the block matrices -- one index operation per block instead of per
+    entry (36x fewer for the 6 x 6 levels; it was the largest single cost of the distributed elasticity setup)"""
     lib = _lib.host()
-    MA, MB = _mat(A), _mat(B)
+    MA, MB = _mat(A, br, bk), _mat(B, bk, bc)
     da, db = MA.desc(), MB.desc()
     rp = np.zeros(MA.n_rows + 1, dtype=np.int64)
     _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), None, None))
     col = np.zeros(rp[-1], dtype=np.int32)
-    val = np.zeros(rp[-1])
+    val = np.zeros(rp[-1] * br * bc)
     _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), _lib.ptr(col, C.c_int32), _lib.ptr(val, C.c_double)))
-    return sp.csr_matrix((val, col, rp), shape=(MA.n_rows, MB.n_cols))
+    if br == 1 and bc == 1:
+        return sp.csr_matrix((val, col, rp), shape=(MA.n_rows, MB.n_cols))
+    return sp.bsr_matrix((val.reshape(-1, br, bc), col, rp), shape=(MA.n_rows * br, MB.n_cols * bc)).tocsr()
 
 
 def _peer_segments(owner):
@@ -606,8 +610,8 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         P_own_ext = sp.bsr_matrix((dat, ix, ip), shape=(s.n * bf, ncx * bc)).tocsr()
         P_ext = sp.vstack([P_own_ext, P_gh], format="csr")
         P = sp.csr_matrix(sp.bsr_matrix((dat, ix, ip), shape=(s.n * bf, c.n * bc)))
-        AP = _spmm(s.A, P_ext)
-        c.A = _spmm(sp.csr_matrix(P.T), AP)
+        AP = _spmm(s.A, P_ext, bf, bf, bc)
+        c.A = _spmm(sp.csr_matrix(P.T), AP, bc, bf, bc)
         c.A.sort_indices()
         s.AP, s.P_own_ext = AP, P_own_ext          # for the folded prolongation Q = P - w Dinv (A P), see _fold
         s.P = P

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: launches, mean counter value per launch.
+"""Aggregate a rocprofv3 --pmc counter_collection CSV per (kernel, grid size): launches, mean counter value per launch.
+The grid size separates the launches of one kernel on different levels (level 0 is the largest grid).
 python tools/pmc_summary.py <counter_collection.csv> [out.csv]"""
 import csv
 import sys
@@ -11,6 +12,8 @@ def main():
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     for r in rows:
         k = r.get("Kernel_Name") or r.get("Kernel Name")
+        g = r.get("Grid_Size") or r.get("Grid Size") or ""
+        k = f"{k[:150]} [grid {g}]"
         c = r.get("Counter_Name") or r.get("Counter Name")
         v = float(r.get("Counter_Value") or r.get("Counter Value") or 0)
         a = acc[k][c]
@@ -21,7 +24,7 @@ def main():
     w.writerow(["kernel", "counter", "launches", "mean_per_launch", "total"])
     for k, cs in sorted(acc.items(), key=lambda kv: -max(v[1] for v in kv[1].values())):
         for c, (n, t) in cs.items():
-            w.writerow([k[:160], c, n, t / n, t])
+            w.writerow([k[:200], c, n, t / n, t])
 
 
 if __name__ == "__main__":

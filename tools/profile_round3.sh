@@ -11,9 +11,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # GPU before python starts, and a compiler child spawned from the profiled process would be an exec hop the pool refuses
 python -c 'import __graft_entry__ as g; g.build()' > $OUT/build.log 2>&1 || { echo "build failed" >> $OUT/progress.txt; exit 1; }
 export NGSAMG_NO_BUILD=1
+# a profiled command may run for minutes without printing: keep gpurun's silence watchdog informed (every step has its own timeout)
+( while true; do date >> $OUT/heartbeat.txt; sleep 60; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 kt() {   # kt <tag> <bench args...>: kernel trace + stats of one bench command; stats of the launches after amgx_create beside rocprof's own
   tag=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$tag -- python bench.py "$@" > $OUT/bench_under_rocprof_$tag.json 2> $OUT/kt_$tag.log
+  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$tag -- python bench.py "$@" > $OUT/bench_under_rocprof_$tag.json 2> $OUT/kt_$tag.log
   f=$(find $OUT/kt_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_$tag.csv
   f=$(find $OUT/kt_$tag -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/stats_after_setup.py $f $OUT/kernel_stats_${tag}_after_setup.csv
   rm -rf $OUT/kt_$tag; echo "kt $tag done" >> $OUT/progress.txt
@@ -21,7 +25,9 @@ kt() {   # kt <tag> <bench args...>: kernel trace + stats of one bench command; 
 pmc() {  # pmc <tag> <bench args...>: the two counter passes, summarised per kernel
   tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${tag}_$c -- python bench.py "$@" --no-graph --steps 5 --warmup 2 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $OUT/pmc_${tag}_$c.log
+    # (AMGX_NO_DENSE_TAIL: forming the collapsed coarse operator is thousands of tiny launches, minutes under the counter collection;
+    #  the level-0 kernels the counters are read for are the same either way)
+    AMGX_NO_DENSE_TAIL=1 timeout -k 10 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${tag}_$c -- python bench.py "$@" --no-graph --steps 5 --warmup 2 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $OUT/pmc_${tag}_$c.log
     f=$(find $OUT/pmc_${tag}_$c -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python tools/pmc_summary.py $f $OUT/pmc_${tag}_${c}_by_kernel.csv
     rm -rf $OUT/pmc_${tag}_$c
@@ -29,7 +35,7 @@ pmc() {  # pmc <tag> <bench args...>: the two counter passes, summarised per ker
   echo "pmc $tag done" >> $OUT/progress.txt
 }
 if [[ $PART == *a* ]]; then
-  kt jacobi                                   # the driver's command
+  kt jacobi --no-reference-defaults          # the driver's command without the second (default-hierarchy) handle, whose kernels carry the same names
   kt gs --smoother gs --steps 50 --warmup 10 --no-cpu-baseline --no-reference-defaults
   pmc jacobi
   pmc gs --smoother gs
