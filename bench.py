@@ -485,6 +485,17 @@ def main():
         except Exception as e:
             log(f"in-cycle timing of the Gauss-Seidel sweep unavailable: {e!r}")
             k_ms = None
+    if args.smoother == "gs" and args.config != "cfg2" and lv0.bs > 1:
+        # block levels: the backward block-hybrid sweep (bgsb_sweep_kernel) timed inside the cycle, same byte model
+        try:
+            k_ms = amg.time_op(0, 9, reps=30)
+            spmv_bytes = matrix_bytes(lv0.A) + 4 * V0 + 8 * lv0.bs * lv0.bs * lv0.n        # + the inverted block diagonals
+            k_name = f"bgsb_sweep_kernel<{bs0}, false> (level 0: backward block-hybrid Gauss-Seidel sweep, {bs0}x{bs0} blocks)"
+            tname = f"traffic_bgsb_sweep_{args.config}.json"
+            in_cycle = True
+        except Exception as e:
+            log(f"in-cycle timing of the block Gauss-Seidel sweep unavailable: {e!r}")
+            k_ms = None
     if k_ms is None:
         k_ms = amg.time_op(0, 0, reps=50)
         if args.config != "cfg2":
@@ -615,7 +626,7 @@ def main():
             xc, c_it, c_errs = orc.pcg(b_host, tol=1e-8, maxit=200)
             A0 = H.levels[0].A.to_scipy()
             c_res = float(np.linalg.norm((b_host - A0 @ xc) * free_s) / np.linalg.norm(b_host))
-            pcg = {"tol": 1e-8, "gpu_iterations": int(cg.iterations), "cpu_iterations": int(c_it),
+            pcg = {"tol": 1e-8, "converges": bool(cg.iterations < 200 and g_res < 1e-5), "gpu_iterations": int(cg.iterations), "cpu_iterations": int(c_it),
                    "gpu_rel_residual": g_res, "cpu_rel_residual": c_res,
                    "solution_rel_diff": float(np.linalg.norm(xs.cpu().numpy() - xc) / np.linalg.norm(xc))}
             try:
@@ -761,6 +772,10 @@ def main():
                                       if args.hierarchy == "aaf" else "library default (SPW, one step per level)")
         if cpu is not None:
             out["cpu_baseline"] = cpu
+            if cpu.get("pcg") is not None:
+                # (block-Jacobi with omega = 0.9 is not a convergent smoother on the rotational model problem of cfg 5: the
+                #  applications/s of such a line is the throughput of a cycle, not of a solver)
+                out["converges"] = cpu["pcg"].get("converges")
         emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -102,6 +102,14 @@ int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int6
 /* square-block matrices (hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): dinv_k = (pseudo-)inverse(A_kk) / max(1, max_l 0.51 (1 + ad_k(l))),
  * ad_k(l) = sum over the couplings leaving the block of rows of sum_m |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)); dinv_out: [n * bs * bs] */
 int amgh_hybrid_dinv_block(const amgh_matrix* A, const uint8_t* free_or_null, int64_t block_rows, int pinv, double* dinv_out);
+/* Compact sweep blocks instead of runs of consecutive rows (amgx_level_desc.gs_block_ids): the reference's hybrid smoother freezes
+ * the couplings between mesh-partitioner subdomains, which are compact; amgh_compact_blocks grows blocks of ~target_rows (<= max_rows)
+ * vertices breadth-first over the matrix graph.  amgh_coloring_blockids / amgh_hybrid_dinv_block_ids: the colouring and the
+ * l1-modified block diagonal for such blocks (same rules as above with "same block" decided by the ids) */
+int amgh_compact_blocks(const amgh_matrix* A, const uint8_t* free_or_null, int32_t target_rows, int32_t max_rows, int32_t* block_of_row_out,
+                        int64_t* n_blocks_out);
+int amgh_coloring_blockids(const amgh_matrix* A, const uint8_t* free_or_null, const int32_t* block_of_row, int32_t* color_out, int32_t* n_colors);
+int amgh_hybrid_dinv_block_ids(const amgh_matrix* A, const uint8_t* free_or_null, const int32_t* block_of_row, int pinv, double* dinv_out);
 
 /* Block Gauss-Seidel data (reference BSmoother, src/base/smoothers/block_gssmoother.cpp:17-150).  Blocks are sets of
  * block rows -- the aggregates of the level, as GetGSBlocks builds them (amg_pc_vertex_impl.hpp:1171-1269); block k owns

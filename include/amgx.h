@@ -83,6 +83,12 @@ typedef struct amgx_level_desc {
                               /*   frozen at their sweep-start values.  `color` then only has to separate coupled rows of the  */
                               /*   SAME block (amgh_coloring_blocked) and `dinv` should be the inverse of the l1-modified      */
                               /*   diagonal (amgh_hybrid_dinv).  Rows may have at most 16 * (1024 / B) + 1 entries.            */
+                              /*   Square-block levels (2x2, 3x3, 6x6): B = block rows per workgroup (amgh_hybrid_dinv_block).  */
+  const int32_t* gs_block_ids;/* optional, square-block levels with gs_block_rows = B > 0: [n] sweep block of every block row   */
+                              /*   (ids 0 .. n_blocks-1, at most B rows per block) instead of runs of B consecutive rows --     */
+                              /*   compact blocks (amgh_compact_blocks) freeze fewer couplings, like the mesh-partitioner        */
+                              /*   subdomains of the reference's hybrid smoother; colours from amgh_coloring_blockids, dinv     */
+                              /*   from amgh_hybrid_dinv_block_ids                                                              */
 } amgx_level_desc;
 
 typedef struct amgx_hierarchy_desc {

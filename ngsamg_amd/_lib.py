@@ -86,6 +86,9 @@ def host():
     lib.amgh_hybrid_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p]
     lib.amgh_hybrid_dinv_ext.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p, c_f64p]
     lib.amgh_hybrid_dinv_block.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, C.c_int, c_f64p]
+    lib.amgh_compact_blocks.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int32, C.c_int32, c_i32p, c_i64p]
+    lib.amgh_coloring_blockids.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_i32p, c_i32p, c_i32p]
+    lib.amgh_hybrid_dinv_block_ids.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_i32p, C.c_int, c_f64p]
     lib.amgh_bgs_dinv.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, C.c_int, c_i64p, c_f64p]
     lib.amgh_bgs_coloring.argtypes = [C.POINTER(amgh_matrix), C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p]
     lib.amgh_transpose_count.argtypes = [C.POINTER(amgh_matrix), c_i64p]
@@ -193,7 +196,7 @@ class amgx_level_desc(C.Structure):
                 ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32),
                 ("bgs_n_blocks", C.c_int32), ("bgs_block_ptr", c_i32p), ("bgs_block_rows", c_i32p),
                 ("bgs_dinv_ptr", c_i64p), ("bgs_dinv", c_f64p), ("bgs_color", c_i32p), ("bgs_n_colors", C.c_int32),
-                ("Q", amgx_matrix), ("gs_block_rows", C.c_int32)]
+                ("Q", amgx_matrix), ("gs_block_rows", C.c_int32), ("gs_block_ids", c_i32p)]
 
 
 class amgx_hierarchy_desc(C.Structure):
@@ -243,7 +246,7 @@ AMGH_SYMBOLS = [
     "amgh_last_error", "amgh_default_options", "amgh_setup", "amgh_n_levels", "amgh_level_get",
     "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
     "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble", "amgh_bgs_dinv", "amgh_bgs_coloring",
-    "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext", "amgh_hybrid_dinv_block",
+    "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext", "amgh_hybrid_dinv_block", "amgh_compact_blocks", "amgh_coloring_blockids", "amgh_hybrid_dinv_block_ids",
 ]
 
 

@@ -186,6 +186,7 @@ struct DevBGSB {                        // block-hybrid Gauss-Seidel on square-b
   DevMatrix off, in;                    // BSELL images: couplings that leave a workgroup's rows (global block columns, natural row
                                         //   order) / couplings inside them (LOCAL block columns, rows sorted by colour inside the block)
   DevBuf<int32_t> off_ptr, in_ptr, in_row;   // slice ranges per block / per (block, colour); local block row of every `in` slot (-1: padding)
+  DevBuf<int32_t> blk_ptr, blk_rows;         // block rows of every sweep block (runs of consecutive rows, or compact blocks: gs_block_ids)
   // pre-smoothing from x = 0 in ONE pass over A (like DevGSB::lowin / rest): the sweep only needs the in-block couplings to LOWER
   // colours (`lowin`, same slices as `in`); afterwards b_k - acc_k = Dmod_k x_k = fac_k A_kk x_k on every swept row, hence
   // r = b - A x = -(R x) with R = A - L_in + (1 - fac) D - D ... stored negated in `rest` (natural order BSELL): r = rest * x
@@ -1203,10 +1204,10 @@ struct Handle {
     const DevBGSB& g = L.bgsb;
     if (g.n_blocks == 0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
-    const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double);
+    const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double) + (size_t)g.BB * sizeof(int);
     if (lower_only && (xin != nullptr || !g.has_split)) throw Err("block-hybrid Gauss-Seidel: the lower-colour copy serves the sweep from zero only");
     const BSellMat OFF = g.off.bsell.view(), IN = lower_only ? g.lowin.bsell.view() : g.in.bsell.view();
-#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(g.n_blocks), dim3(BLOCK), lds, stream, L.n, g.BB, 0, OFF, g.off_ptr.p, IN, \
+#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(g.n_blocks), dim3(BLOCK), lds, stream, g.BB, 0, g.blk_ptr.p, g.blk_rows.p, OFF, g.off_ptr.p, IN, \
                                                g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, xin, xout)
     const bool fz = xin == nullptr;
     switch (L.bs) {
@@ -1496,7 +1497,10 @@ struct Handle {
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.bgsb.on()) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
+      const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
+      if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       bgsb_sweep(L, 1, L.tmp.p, x, b);     // backward block-hybrid sweep, tmp -> x
+      if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
@@ -2003,6 +2007,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
       const int ci = d.color[i];
       if (ci >= nc) { bad[t] = 1; return; }
       if (ci < 0) continue;
+      if (d.gs_block_ids) continue;                       // (checked against the block ids below)
       const int64_t b0 = (i / BB) * BB, b1 = b0 + BB;
       for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
         const int64_t j = d.A.col[k];
@@ -2011,32 +2016,63 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
     }
   });
   for (char c : bad) { if (c == 1) throw Err("colour index out of range"); if (c == 2) throw Err("invalid blocked colouring: two coupled block rows of one block share a colour"); }
-  const int nblk = (int)((n + BB - 1) / BB);
+  // sweep blocks: runs of BB consecutive rows, or the caller's compact blocks (gs_block_ids, at most BB rows each)
+  std::vector<int32_t> blk_of((size_t)n), lpos((size_t)n), blk_ptr, blk_rows((size_t)n);
+  int nblk = 0;
+  if (d.gs_block_ids) {
+    int32_t mx = -1;
+    for (int64_t i = 0; i < n; ++i) { if (d.gs_block_ids[i] < 0) throw Err("gs_block_ids: negative block id"); mx = std::max(mx, d.gs_block_ids[i]); }
+    nblk = mx + 1;
+    blk_ptr.assign((size_t)nblk + 1, 0);
+    for (int64_t i = 0; i < n; ++i) { blk_of[i] = d.gs_block_ids[i]; blk_ptr[blk_of[i] + 1]++; }
+    for (int q = 0; q < nblk; ++q) { if (blk_ptr[q + 1] > BB) throw Err("gs_block_ids: a block has more than gs_block_rows rows"); blk_ptr[q + 1] += blk_ptr[q]; }
+    std::vector<int32_t> pos(blk_ptr.begin(), blk_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) { lpos[i] = pos[blk_of[i]] - blk_ptr[blk_of[i]]; blk_rows[pos[blk_of[i]]++] = (int32_t)i; }
+  } else {
+    nblk = (int)((n + BB - 1) / BB);
+    blk_ptr.assign((size_t)nblk + 1, 0);
+    for (int q = 0; q <= nblk; ++q) blk_ptr[q] = (int32_t)std::min<int64_t>(n, (int64_t)q * BB);
+    for (int64_t i = 0; i < n; ++i) { blk_of[i] = (int32_t)(i / BB); lpos[i] = (int32_t)(i % BB); blk_rows[i] = (int32_t)i; }
+  }
+  // (the colouring was validated against runs of consecutive rows above; with block ids it is validated here)
+  if (d.gs_block_ids) {
+    std::vector<char> bad2(setup_threads(), 0);
+    par_for(n, [&](int64_t i0, int64_t i1, int t) {
+      for (int64_t i = i0; i < i1; ++i) {
+        const int ci = d.color[i];
+        if (ci < 0) continue;
+        for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+          const int64_t j = d.A.col[k];
+          if (j != i && blk_of[j] == blk_of[i] && d.color[j] == ci) { bad2[t] = 1; return; }
+        }
+      }
+    });
+    for (char c : bad2) if (c) throw Err("invalid blocked colouring: two coupled block rows of one sweep block share a colour");
+  }
   g.BB = BB; g.n_blocks = nblk; g.n_colors = nc;
-  // off: natural order, every block padded to whole slices
+  // off: block by block in list order, every block padded to whole slices
   std::vector<int32_t> rows_off, off_ptr(nblk + 1, 0);
   rows_off.reserve((size_t)n + (size_t)nblk * RB);
   for (int blk = 0; blk < nblk; ++blk) {
-    const int64_t b0 = (int64_t)blk * BB, b1 = std::min<int64_t>(n, b0 + BB);
-    for (int64_t i = b0; i < b1; ++i) rows_off.push_back((int32_t)i);
+    for (int32_t q = blk_ptr[blk]; q < blk_ptr[blk + 1]; ++q) rows_off.push_back(blk_rows[q]);
     while (rows_off.size() % RB) rows_off.push_back(-1);
     off_ptr[blk + 1] = (int32_t)(rows_off.size() / RB);
   }
-  auto same_block = [BB](int64_t i, int64_t j) { return i / BB == j / BB; };
+  auto same_block = [&blk_of](int64_t i, int64_t j) { return blk_of[i] == blk_of[j]; };
   build_bsell_sel(d.A, rows_off, [&](int32_t i, int32_t j) { return !same_block(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.off);
   // in: per block the swept rows by colour, every (block, colour) group padded to whole slices
   std::vector<int32_t> rows_in, in_ptr((size_t)nblk * nc + 1, 0), in_row;
   for (int blk = 0; blk < nblk; ++blk) {
-    const int64_t b0 = (int64_t)blk * BB, b1 = std::min<int64_t>(n, b0 + BB);
     for (int c = 0; c < nc; ++c) {
-      for (int64_t i = b0; i < b1; ++i) if (d.color[i] == c) rows_in.push_back((int32_t)i);
+      for (int32_t q = blk_ptr[blk]; q < blk_ptr[blk + 1]; ++q) if (d.color[blk_rows[q]] == c) rows_in.push_back(blk_rows[q]);
       while (rows_in.size() % RB) rows_in.push_back(-1);
       in_ptr[(size_t)blk * nc + c + 1] = (int32_t)(rows_in.size() / RB);
     }
   }
   in_row.resize(rows_in.size());
-  for (size_t q = 0; q < rows_in.size(); ++q) in_row[q] = rows_in[q] < 0 ? -1 : (int32_t)(rows_in[q] % BB);
-  build_bsell_sel(d.A, rows_in, [&](int32_t i, int32_t j) { return same_block(i, j); }, [BB](int32_t, int32_t j) { return (int32_t)(j % BB); }, 0, g.in);
+  for (size_t q = 0; q < rows_in.size(); ++q) in_row[q] = rows_in[q] < 0 ? -1 : lpos[rows_in[q]];
+  build_bsell_sel(d.A, rows_in, [&](int32_t i, int32_t j) { return same_block(i, j); }, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.in);
+  g.blk_ptr.upload(blk_ptr); g.blk_rows.upload(blk_rows);
   g.off_ptr.upload(off_ptr); g.in_ptr.upload(in_ptr); g.in_row.upload(in_row);
   // ---- one-pass pre-smoothing from zero: valid where dinv_k is a true inverse of fac_k * A_kk (not a pseudo-inverse) ----------
   if (std::getenv("AMGX_BGSB_NO_SPLIT")) return;
@@ -2064,7 +2100,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   });
   for (char c : nofac) if (c) return;
   auto lower_in = [&](int32_t i, int32_t j) { return j != i && same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && d.color[j] < d.color[i]; };
-  build_bsell_sel(d.A, rows_in, lower_in, [BB](int32_t, int32_t j) { return (int32_t)(j % BB); }, 0, g.lowin);
+  build_bsell_sel(d.A, rows_in, lower_in, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.lowin);
   if (g.lowin.n_slices != g.in.n_slices) throw Err("block-hybrid Gauss-Seidel: lower / in slice mismatch");
   std::vector<int32_t> rows_nat;
   for (int64_t i = 0; i < n; ++i) rows_nat.push_back((int32_t)i);
@@ -3013,7 +3049,7 @@ int amgx_time_op(amgx_handle hh, int level, int op, int reps, double* avg_ms) {
       // the dominant kernel timed where it runs: inside the cycle, between the previous cycle's last kernel and the
       // partial-sum reduction (cache state and clocks of the real application), averaged over `reps` cycles
       if (op == 8 && (L.RF.empty() || !(h.plain(L) && L.sm_type == AMGX_SM_JACOBI))) throw amgx::Err("amgx_time_op: level has no fused pre-smoothing + restriction kernel");
-      if (op == 9 && !(has_c && h.plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols && !h.folded(L)))
+      if (op == 9 && !(has_c && h.plain(L) && L.sm_type == AMGX_SM_GS && (L.gsb.on() || L.bgsb.on()) && L.n == L.ncols && !h.folded(L)))
         throw amgx::Err("amgx_time_op: level has no block-hybrid Gauss-Seidel sweep");
       h.probe_kind = op;
       if (h.stream == nullptr) throw amgx::Err("amgx_time_op: op 8 needs a non-default stream");

@@ -915,8 +915,11 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_s
 //            diagonal (amgh_hybrid_dinv_block, hybrid_smoother_utils.hpp:86-141)
 // Every entry of A is read once per sweep.  Out of place (other workgroups read the old values), except from zero where
 // nothing outside the block is read.
+// blk_ptr / blk_rows: the block rows of every sweep block (ascending inside a block).  Runs of consecutive rows, or compact
+// blocks grown over the matrix graph (amgh_compact_blocks): the local index of a row = its position in its block's list.
 template <int BS, bool FROM_ZERO>
-__global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int64_t n_rows, int BB, int block0, BSellMat OFF, const int32_t* __restrict__ off_ptr,
+__global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_rows,
+                                                           BSellMat OFF, const int32_t* __restrict__ off_ptr,
                                                            BSellMat IN, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_row,
                                                            int n_colors, int dir, const double* __restrict__ dinv, const double* __restrict__ b,
                                                            const double* __restrict__ xin, double* __restrict__ xout) {
@@ -924,12 +927,16 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int64_t n_rows, int B
   constexpr int RB = WAVE / BS;
   double* xs = bgsb_sh;
   double* bsh = bgsb_sh + (size_t)BB * BS;
+  int* rowsh = reinterpret_cast<int*>(bgsb_sh + (size_t)2 * BB * BS);      // global block row of every local row
   const int blk = block0 + blockIdx.x;
-  const int64_t b0 = (int64_t)blk * BB;
-  const int nb = (int)((n_rows - b0) < BB ? (n_rows - b0) : BB);
+  const int p0 = blk_ptr[blk];
+  const int nb = blk_ptr[blk + 1] - p0;
+  for (int e = threadIdx.x; e < nb; e += BLOCK) rowsh[e] = blk_rows[p0 + e];
+  __syncthreads();
   for (int e = threadIdx.x; e < nb * BS; e += BLOCK) {
-    xs[e] = FROM_ZERO ? 0.0 : xin[b0 * BS + e];
-    bsh[e] = b[b0 * BS + e];
+    const int64_t g = (int64_t)rowsh[e / BS] * BS + e % BS;
+    xs[e] = FROM_ZERO ? 0.0 : xin[g];
+    bsh[e] = b[g];
   }
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int64_t n_rows, int B
       const int32_t* __restrict__ cb = IN.col + k0 * RB;
       double od[BS];
 #pragma unroll
-      for (int cc = 0; cc < BS; ++cc) od[cc] = active ? dinv[(b0 + lrow) * (BS * BS) + r * BS + cc] : 0.0;
+      for (int cc = 0; cc < BS; ++cc) od[cc] = active ? dinv[(int64_t)rowsh[lrow] * (BS * BS) + r * BS + cc] : 0.0;
       double acc = 0.0;
 #pragma unroll 2
       for (int k = 0; k < w; ++k) {
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int64_t n_rows, int B
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < nb * BS; e += BLOCK) xout[b0 * BS + e] = xs[e];
+  for (int e = threadIdx.x; e < nb * BS; e += BLOCK) xout[(int64_t)rowsh[e / BS] * BS + e % BS] = xs[e];
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -26,6 +26,15 @@ amgh::BCSR to_bcsr(const amgh_matrix* m) {
   return A;
 }
 
+// pattern only (no 8.5 GB copy of the values of a cfg-5 level for routines that look at the graph)
+amgh::BCSR to_bcsr_pattern(const amgh_matrix* m) {
+  amgh::BCSR A;
+  A.n_rows = m->n_rows; A.n_cols = m->n_cols; A.br = m->br; A.bc = m->bc;
+  A.rowptr.assign(m->rowptr, m->rowptr + m->n_rows + 1);
+  A.col.assign(m->col, m->col + A.rowptr.back());
+  return A;
+}
+
 void view(const amgh::BCSR& A, amgh_matrix* m) {
   m->n_rows = A.n_rows; m->n_cols = A.n_cols; m->br = A.br; m->bc = A.bc;
   m->rowptr = A.rowptr.data(); m->col = A.col.data(); m->val = A.val.data();
@@ -175,6 +184,36 @@ int amgh_hybrid_dinv_block(const amgh_matrix* A, const uint8_t* free_or_null, in
     if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv_block: bad arguments");
     amgh::BCSR M = to_bcsr(A);
     amgh::hybrid_mod_dinv_block(M, free_or_null, block_rows, pinv != 0, dinv_out);
+  });
+}
+
+int amgh_compact_blocks(const amgh_matrix* A, const uint8_t* free_or_null, int32_t target_rows, int32_t max_rows, int32_t* block_of_row_out,
+                        int64_t* n_blocks_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->n_rows != A->n_cols || target_rows < 1 || max_rows < target_rows || !block_of_row_out) throw amgh::Error("amgh_compact_blocks: bad arguments");
+    amgh::BCSR M = to_bcsr_pattern(A);
+    const int64_t nb = amgh::compact_blocks(M, free_or_null, target_rows, max_rows, block_of_row_out);
+    if (n_blocks_out) *n_blocks_out = nb;
+  });
+}
+
+int amgh_coloring_blockids(const amgh_matrix* A, const uint8_t* free_or_null, const int32_t* block_of_row, int32_t* color_out, int32_t* n_colors) {
+  return guard([&] {
+    check_matrix(A);
+    if (!block_of_row || !color_out) throw amgh::Error("amgh_coloring_blockids: bad arguments");
+    amgh::BCSR M = to_bcsr_pattern(A);
+    const int nc = amgh::greedy_coloring_blockids(M, free_or_null, block_of_row, color_out);
+    if (n_colors) *n_colors = nc;
+  });
+}
+
+int amgh_hybrid_dinv_block_ids(const amgh_matrix* A, const uint8_t* free_or_null, const int32_t* block_of_row, int pinv, double* dinv_out) {
+  return guard([&] {
+    check_matrix(A);
+    if (A->br != A->bc || A->n_rows != A->n_cols || !block_of_row || !dinv_out) throw amgh::Error("amgh_hybrid_dinv_block_ids: bad arguments");
+    amgh::BCSR M = to_bcsr(A);
+    amgh::hybrid_mod_dinv_block(M, free_or_null, 1, pinv != 0, dinv_out, block_of_row);
   });
 }
 

@@ -31,8 +31,10 @@ def gs_block_rows(A):
     if A.br == A.bc and A.br in (2, 3, 6) and A.n_rows == A.n_cols:
         # square-block levels (bgsb_sweep_kernel): a workgroup owns ~128 block rows, a whole number of BSELL slices
         # (64 // bs block rows each); levels with fewer than four such blocks keep the multicolour form
+        # (levels below 50 k block rows are latency-bound: a workgroup walks its colour phases one after the other, and half-size
+        #  blocks have fewer in-block colours -- A/B at cfg 5, 8 k-row level: 110 + 158 us -> 90 + 101 us per cycle)
         rb = 64 // A.br
-        B = int(os.environ.get("AMGX_BGSB_ROWS", "0")) or rb * max(1, 128 // rb)
+        B = int(os.environ.get("AMGX_BGSB_ROWS", "0")) or rb * max(1, (128 if A.n_rows >= 50000 else 64) // rb)
         return B if (A.n_rows >= 4 * B and not os.environ.get("AMGX_NO_BGSB")) else 0
     if A.br != 1 or A.bc != 1 or A.n_rows <= 256:
         return 0
@@ -61,6 +63,24 @@ def hybrid_gs_data(A, free, B, pinv=False):
     dinv = np.zeros(A.n_cols, dtype=np.float64)          # (rank-partitioned levels: entries of the ghost columns stay 0)
     _lib.hcheck(lib.amgh_hybrid_dinv(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(dinv, C.c_double)))
     return color, int(nc.value), dinv
+
+
+def hybrid_gs_data_compact(A, free, B, pinv=False):
+    """square-block levels: compact sweep blocks of at most B block rows grown over the matrix graph (amgh_compact_blocks)
+    instead of runs of consecutive rows, with their colouring and l1-modified block diagonal.
+    Returns (block_of_row, color, n_colors, dinv)."""
+    lib = _lib.host()
+    d = A.desc()
+    fr = np.ascontiguousarray(np.ones(A.n_rows, dtype=np.uint8) if free is None else free, dtype=np.uint8)
+    blk = np.zeros(A.n_rows, dtype=np.int32)
+    nb = C.c_int64()
+    _lib.hcheck(lib.amgh_compact_blocks(C.byref(d), _lib.ptr(fr, C.c_uint8), max(1, (7 * int(B)) // 8), int(B), _lib.ptr(blk, C.c_int32), C.byref(nb)))
+    color = np.full(A.n_rows, -1, dtype=np.int32)
+    nc = C.c_int32()
+    _lib.hcheck(lib.amgh_coloring_blockids(C.byref(d), _lib.ptr(fr, C.c_uint8), _lib.ptr(blk, C.c_int32), _lib.ptr(color, C.c_int32), C.byref(nc)))
+    dinv = np.zeros(A.n_rows * A.br * A.br, dtype=np.float64)
+    _lib.hcheck(lib.amgh_hybrid_dinv_block_ids(C.byref(d), _lib.ptr(fr, C.c_uint8), _lib.ptr(blk, C.c_int32), int(bool(pinv)), _lib.ptr(dinv, C.c_double)))
+    return blk, color, int(nc.value), dinv
 
 
 def _is_torch(v):
@@ -124,11 +144,21 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
             pre = getattr(lv, "hgs_pre", None)      # rank-partitioned levels: computed by the distributed setup (needs ghost diagonals)
             B = pre["B"] if pre else gs_block_rows(lv.A)
             if B > 0:
+                import os
                 pinv = bool(getattr(getattr(hierarchy, "options", None), "regularize_cmats", 0))
-                col, nc, dinv = (pre["color"], pre["n_colors"], pre["dinv"]) if pre else hybrid_gs_data(lv.A, lv.free, B, pinv)
-                info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv)
+                blk = None
+                if pre:
+                    col, nc, dinv = pre["color"], pre["n_colors"], pre["dinv"]
+                elif lv.A.br > 1 and not os.environ.get("AMGX_BGSB_LINE_BLOCKS"):
+                    # block levels: compact sweep blocks (fewer frozen couplings than runs of consecutive rows = grid lines)
+                    blk, col, nc, dinv = hybrid_gs_data_compact(lv.A, lv.free, B, pinv)
+                else:
+                    col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B, pinv)
+                info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv, block_of_row=blk)
                 keep.append(info[i])
                 d.color, d.n_colors, d.dinv, d.gs_block_rows = _lib.ptr(col, C.c_int32), nc, _lib.ptr(dinv, C.c_double), B
+                if blk is not None:
+                    d.gs_block_ids = _lib.ptr(blk, C.c_int32)
         g = getattr(lv, "bgs", None)
         if types[i] == "bgs" and g is None and i + 1 < n:
             raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")

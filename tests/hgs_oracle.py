@@ -17,7 +17,7 @@ def hgs_levels(levels, info):
             continue
         L = copy(lv)
         n = lv.A.n_rows
-        blk = (np.arange(n) // h["B"]).astype(np.int32)
+        blk = (np.arange(n) // h["B"]).astype(np.int32) if h.get("block_of_row") is None else np.asarray(h["block_of_row"], dtype=np.int32)
         col = np.asarray(h["color"])
         rows = np.nonzero(col >= 0)[0]
         key = blk[rows].astype(np.int64) * (int(h["n_colors"]) + 1) + col[rows]

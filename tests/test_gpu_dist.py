@@ -548,3 +548,37 @@ def test_distributed_pcg_history_equals_serial_oracle(R, box, dmin, sm):
     # a second solve from the solution as initial guess stops immediately
     it2, errs2 = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
     assert errs2[0] <= 1e-7 * errs[0]
+
+
+@pytest.mark.parametrize("pg,gshape,dmin,sm", [((3, 1, 1), (23, 14, 13), 100, "jacobi"), ((8, 1, 1), (43, 9, 10), 40, "jacobi"), ((5, 1, 1), (27, 12, 11), 60, "hgs")])
+def test_strong_split_device_matches_serial_oracle(pg, gshape, dmin, sm):
+    """bench.py --gpus N in miniature: ONE global grid cut into balanced, unequal slabs (virtual ranks on this GPU), two
+    rank-partitioned levels, the gathered level, the collapsed replicated tail, the whole cycle replayed from its graph --
+    against the serial oracle on the assembled global hierarchy, and the distributed PCG against the oracle's"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    R = int(np.prod(pg))
+    states = [D.assemble_poisson_owned(r, pg, None, gshape=gshape, coords="rng") for r in range(R)]
+    assert len({s.n for s in states}) > 1
+    amg = D.DistributedAMG(D.LoopbackComm(R), states, dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm, spw=0,
+                           **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    sts = amg.dist_levels[0]
+    rng = np.random.default_rng(5)
+    bh = [rng.standard_normal(s.n) * s.free for s in sts]
+    bs = [torch.from_numpy(v).cuda() for v in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in sts]
+    for _ in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
+    ref = orc.apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= (1e-12 if sm == "jacobi" else 1e-10) * np.linalg.norm(ref)
+    assert amg._dev.graph_info()["replays"] == 2
+    xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in sts]
+    it, errs = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
+    _, ito, erro = orc.pcg(np.concatenate(bh), tol=1e-8, maxit=100)
+    assert it == ito and np.all(np.abs(errs - np.asarray(erro)[:it + 1]) <= 1e-6 * erro[0])
