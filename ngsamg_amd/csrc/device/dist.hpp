@@ -138,6 +138,7 @@ struct Comm {
   struct GKey { std::vector<const void*> p; int status; bool operator<(const GKey& o) const { return status != o.status ? status < o.status : p < o.p; } };
   struct GVal { hipGraphExec_t exec; int64_t exchanges; };
   std::map<GKey, GVal> graphs;
+  int64_t n_direct_runs = 0;             // applications launched directly; the first one always is (see dist_apply)
   int64_t n_graph_replays = 0;
   std::string graph_note;
   void drop_graphs() { for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec); graphs.clear(); }
@@ -693,7 +694,11 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     }
   }
   const int64_t ex0 = c.n_exchanges;
-  if (want_graph) {
+  // The FIRST application of a communicator is always launched directly: RCCL sets up its point-to-point and all-gather
+  // connections lazily inside the first calls, which must not happen inside a stream capture; the capture starts with the
+  // second application, when every connection exists.
+  const bool capture_now = want_graph && c.n_direct_runs > 0;
+  if (capture_now) {
     // the communication stream joins the capture through the first cross-stream ordering and is joined back by the last
     // exchange_end / accumulate, as hipStreamEndCapture requires
     c.capturing = true;
@@ -746,6 +751,7 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     c.n_exchanges = ex0;
     c.graph_note = "whole-cycle graph capture failed (" + (why.empty() ? std::string(hipGetErrorString(e)) : why) + "): direct launches";
   }
+  ++c.n_direct_runs;
   body();
   if (host) {
     for (size_t i = 0; i < M.size(); ++i)

@@ -908,11 +908,15 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_s
 // Block-hybrid Gauss-Seidel for SQUARE-BLOCK levels (BS = 2, 3, 6): ONE launch per sweep instead of one per colour.
 // The reference's hybrid smoother with workgroups in the role of the ranks (HybridGSSmoother<Mat<BS,BS>>,
 // gssmoother.cpp:709-861, 891-896), like gsb_sweep_kernel for scalar levels: a workgroup owns BB consecutive block rows;
-//   phase 0: b' = b - A_off x_old   -- the couplings that leave the block read the sweep-start vector (frozen); A_off
-//            streams as BSELL slices exactly like bsell_spmv_kernel, b' stays in LDS
-//   colour phases: x_B += Dinv_B (b'_B - A_in,B: x) on the in-block couplings (BSELL slices sorted by colour inside the block,
-//            LOCAL block columns), x in LDS, one workgroup barrier per colour; Dinv = inverse of the l1-modified block
-//            diagonal (amgh_hybrid_dinv_block, hybrid_smoother_utils.hpp:86-141)
+//   phase 0: b' = b - (A_off + A_oth) x_old   -- everything that multiplies sweep-start values, with all waves busy:
+//            A_off = the couplings that leave the block (frozen) + the diagonal block, streamed as BSELL slices exactly like
+//            bsell_spmv_kernel; A_oth = the in-block couplings to the colours this sweep reaches LATER (higher colours in a
+//            forward sweep, lower ones in a backward sweep), all their slices at once, x from LDS; b' stays in LDS
+//   colour phases: x_B += Dinv_B (b'_B - A_in,B: x) on the in-block couplings to the colours already swept (BSELL slices
+//            sorted by colour inside the block, LOCAL block columns), x in LDS, one workgroup barrier per colour -- these run
+//            one after the other inside a workgroup and carry ~9 % of A for line blocks; Dinv = inverse of the l1-modified
+//            block diagonal (amgh_hybrid_dinv_block, hybrid_smoother_utils.hpp:86-141)
+// A = A_off + A_lowin + A_upin (three images, every entry once): forward sweep IN = lowin, OTH = upin; backward the reverse.
 // Every entry of A is read once per sweep.  Out of place (other workgroups read the old values), except from zero where
 // nothing outside the block is read.
 // blk_ptr / blk_rows: the block rows of every sweep block (ascending inside a block).  Runs of consecutive rows, or compact
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_s
 template <int BS, bool FROM_ZERO>
 __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_rows,
                                                            BSellMat OFF, const int32_t* __restrict__ off_ptr,
-                                                           BSellMat IN, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_row,
+                                                           BSellMat IN, BSellMat OTH, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_row,
                                                            int n_colors, int dir, const double* __restrict__ dinv, const double* __restrict__ b,
                                                            const double* __restrict__ xin, double* __restrict__ xout) {
   extern __shared__ double bgsb_sh[];
@@ -957,6 +961,31 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
       for (int k = 0; k < w; ++k) {
         const int c = cb[k * RB + rbl];
         const double* __restrict__ xv = xin + (int64_t)c * BS;
+        const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
+#pragma unroll
+        for (int cp = 0; cp < BS / 2; ++cp) {
+          const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+          acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+        }
+        if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+      }
+      if (active) bsh[lrow * BS + r] -= acc;
+    }
+    __syncthreads();
+    // the other in-block image: all colours at once, sweep-start values from LDS (a row sits in one slice of it)
+    const int t0 = in_ptr[blk * n_colors], t1 = in_ptr[(blk + 1) * n_colors];
+    for (int s = t0 + wave; s < t1; s += WAVES_PER_BLOCK) {
+      const int lrow = in_row[(int64_t)s * RB + rbl];
+      const bool active = lane_on && lrow >= 0;
+      const int64_t k0 = OTH.slice_ptr[s];
+      const int w = (int)(OTH.slice_ptr[s + 1] - k0);
+      const double* __restrict__ vb = OTH.val + k0 * (BS * WAVE);
+      const int32_t* __restrict__ cb = OTH.col + k0 * RB;
+      double acc = 0.0;
+#pragma unroll 2
+      for (int k = 0; k < w; ++k) {
+        const int cl = cb[k * RB + rbl];
+        const double* xv = xs + cl * BS;
         const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
 #pragma unroll
         for (int cp = 0; cp < BS / 2; ++cp) {

@@ -149,8 +149,11 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
                 blk = None
                 if pre:
                     col, nc, dinv = pre["color"], pre["n_colors"], pre["dinv"]
-                elif lv.A.br > 1 and not os.environ.get("AMGX_BGSB_LINE_BLOCKS"):
-                    # block levels: compact sweep blocks (fewer frozen couplings than runs of consecutive rows = grid lines)
+                elif lv.A.br > 1 and os.environ.get("AMGX_BGSB_COMPACT"):
+                    # block levels: compact sweep blocks (amgh_compact_blocks) freeze half as many couplings as runs of consecutive
+                    # rows (= grid lines) and bring the PCG count to within one of the sequential sweep (cfg 3: 17 vs 16; line
+                    # blocks 20), but the in-block colour phases then carry half of A and run one slice per wave and phase:
+                    # 250 instead of 467 applications/s at cfg 3, 128 instead of 223 at cfg 5 -- not the default
                     blk, col, nc, dinv = hybrid_gs_data_compact(lv.A, lv.free, B, pinv)
                 else:
                     col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B, pinv)

@@ -11,8 +11,12 @@ SURVEY.md 8e) is realised here in the row-partitioned form that maps onto the si
     hence restriction and prolongation need no communication; the Galerkin product needs the P rows of the ghost
     vertices once, at setup;
   * per cycle and distributed level there are two halo exchanges (before the two passes over A: `b` for the fused
-    pre-smoothing pass, `x + P x_c` for the post-smoothing pass): pack = index_select into a send buffer, exchange =
-    torch.distributed batch_isend_irecv (backend nccl = RCCL over xGMI) straight into the ghost segment;
+    pre-smoothing pass, `x + P x_c` -- or the coarse solution, in the folded form -- for the way up).  The DATA PATH is
+    native (csrc/device/dist.hpp behind the C ABI: amgx_comm_* / amgx_dist_apply): hand-written pack kernels, ncclSend /
+    ncclRecv on a communication stream straight into the ghost segment, interior rows processed meanwhile, the whole
+    cycle replayed from one hipGraph.  torch.distributed (gloo) only carries the rendezvous, the 128-byte RCCL id and
+    the host messages of THIS setup; the stage-by-stage driver at the end of this file (index_select + all_gather through
+    a backend object) is the CPU test backend and refuses to run where a GPU is present;
   * once a level is small it is gathered and the remaining hierarchy is REPLICATED on every rank (one all-gather of
     the level's right-hand side per cycle) - the GPU analogue of the reference's contraction to one rank
     (`CtrMap`, src/base/coarsening/dof_contract.cpp:49-223) without the extra latency hop back.
@@ -877,7 +881,17 @@ class DistributedAMG:
             self._dev = _DeviceDist(self, device)
             self.ops = self._dev.ops
             return
-        # stage-by-stage driver for test backends (tests/dist_cpu_backend.py): same tables, same stage order
+        # stage-by-stage driver for test backends (tests/dist_cpu_backend.py): same tables, same stage order.  It is test
+        # infrastructure for boxes WITHOUT a GPU: where a device exists the product path is the native driver above
+        # (NGSAMG_STAGE_BACKEND_OK=1 lifts the refusal, e.g. to compare the two on one box)
+        try:
+            import torch
+            has_gpu = torch.cuda.is_available()
+        except Exception:
+            has_gpu = False
+        if has_gpu and not os.environ.get("NGSAMG_STAGE_BACKEND_OK"):
+            raise NgsAMGError("DistributedAMG: the stage-by-stage Python backend is the CPU test path; on a GPU box use the native driver "
+                              "(backend=None) or set NGSAMG_STAGE_BACKEND_OK=1")
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
         self._alloc()
 

@@ -94,7 +94,11 @@ def test_elast_2d_lo(rot):
     b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
     x = np.zeros_like(b)
     c.Mult(b, x)
-    ref = Oracle(H.levels, sm_type="gs_mc").apply(b)
+    # default smoother: Gauss-Seidel in the block-hybrid form where a level is large enough (block levels too since round 3);
+    # the oracle runs the same blocks, colours and modified diagonals, multicolour order on the other levels
+    from tests.hgs_oracle import hgs_levels
+    lv, types = hgs_levels(H.levels, c.GetAMGMatrix()._dev.hgs)
+    ref = Oracle(lv, sm_type=types).apply(b)
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
 
 

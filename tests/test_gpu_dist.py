@@ -135,7 +135,7 @@ def test_rccl_world_size_one(sm):
     out = _run_check("--world", "1", "--box", "20", "--sm", sm)
     assert "self-loop halo ok = True" in out
     # the whole collective cycle (RCCL operations included) was captured into a hipGraph and replayed
-    assert "graph enabled = True graphs = 1 replays = 3" in out, out
+    assert "graph enabled = True graphs = 1 replays = 2" in out, out        # (the first application is launched directly)
 
 
 @pytest.mark.parametrize("mode", ["1", "pad"])
@@ -146,7 +146,7 @@ def test_rccl_world_size_one_runs_the_allgather_branch(mode, graph):
     kernel of unequal pieces ("pad"), captured in the cycle's graph and with direct launches."""
     out = _run_check("--world", "1", "--box", "20", "--sm", "jacobi", extra_env={"AMGX_DIST_FORCE_ALLGATHER": mode, "AMGX_DIST_GRAPH": graph})
     assert f"allgather = {mode}" in out
-    assert ("graph enabled = True graphs = 1 replays = 3" in out) == (graph == "1"), out
+    assert ("graph enabled = True graphs = 1 replays = 2" in out) == (graph == "1"), out
 
 
 def _halo_tables(R, n, rng):
@@ -513,7 +513,7 @@ def test_whole_cycle_graph_equals_direct_launches(R, box, dmin, sm, monkeypatch)
             for a, b_ in zip(xg, xd):
                 assert torch.equal(a, b_)
     gi, di = ag._dev.graph_info(), ad._dev.graph_info()
-    assert gi["enabled"] and gi["graphs"] == 2 and gi["replays"] == 6, gi
+    assert gi["enabled"] and gi["graphs"] == 2 and gi["replays"] == 5, gi      # (the very first application runs directly: RCCL connections)
     assert not di["enabled"] and di["replays"] == 0
     assert ag._dev.n_exchanges() == ad._dev.n_exchanges()
 
@@ -577,7 +577,7 @@ def test_strong_split_device_matches_serial_oracle(pg, gshape, dmin, sm):
     ref = orc.apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= (1e-12 if sm == "jacobi" else 1e-10) * np.linalg.norm(ref)
-    assert amg._dev.graph_info()["replays"] == 2
+    assert amg._dev.graph_info()["replays"] == 1
     xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in sts]
     it, errs = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
     _, ito, erro = orc.pcg(np.concatenate(bh), tol=1e-8, maxit=100)

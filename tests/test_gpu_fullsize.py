@@ -104,6 +104,15 @@ def test_cfg3_cfg5_elasticity_126_cubed(rot):
         ref = Oracle(H.levels, sm_type="gs_mc", threads=_threads()).apply(b)
         x = _apply(dev, b)
         assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    # the default Gauss-Seidel form since round 3: block-hybrid sweeps on the block levels (bgsb_sweep_kernel), one launch per sweep
+    del dev
+    from tests.hgs_oracle import hgs_levels
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    assert dev.hgs[0] is not None and dev.hgs[0]["B"] in (120, 126)
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    ref = Oracle(lv, sm_type=types, threads=_threads()).apply(b)
+    x = _apply(dev, b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
 
 
 def test_cfg4_arrangement_8_virtual_ranks_production_formats():

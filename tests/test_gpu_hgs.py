@@ -168,6 +168,33 @@ def test_block_levels_hgs_cycles_match_hybrid_oracle(rot, shape, cycle, split, m
 
 
 @pytest.mark.parametrize("rot", [False, True])
+def test_block_levels_hgs_compact_sweep_blocks(rot, monkeypatch):
+    """AMGX_BGSB_COMPACT=1: sweep blocks grown over the matrix graph (amgx_level_desc.gs_block_ids) instead of runs of
+    consecutive rows -- same kernel, same oracle (blocks = the ids), fewer frozen couplings"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    monkeypatch.setenv("AMGX_BGSB_COMPACT", "1")
+    p, H = elasticity_case((14, 13, 12), rotations=rot, max_coarse_size=10)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    assert dev.hgs[0] is not None and dev.hgs[0]["block_of_row"] is not None
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    x = dev.apply(b)
+    ref = Oracle(lv, sm_type=types).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    monkeypatch.delenv("AMGX_BGSB_COMPACT")
+    lines = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    assert lines.hgs[0]["block_of_row"] is None
+    lvl, typl = hgs_levels(H.levels, lines.hgs)
+    it_c = Oracle(lv, sm_type=types).pcg(b, tol=1e-8, maxit=200)[1]
+    it_l = Oracle(lvl, sm_type=typl).pcg(b, tol=1e-8, maxit=200)[1]
+    assert it_c <= it_l
+
+
+@pytest.mark.parametrize("rot", [False, True])
 def test_block_levels_hgs_smoother_flags_and_iterations(rot):
     from ngsamg_amd.device import DeviceAMGMatrix
     from oracle.pyoracle import Oracle

@@ -250,3 +250,57 @@ def test_spw_pairing_rule_properties():
     rng = np.random.default_rng(0)
     it = Oracle(H.levels, sm_type="gs", threads=8).pcg(rng.standard_normal(p.n) * p.free, tol=1e-12, maxit=100)[1]
     assert it < 30
+
+
+def test_compact_sweep_blocks_colouring_and_l1_block_diagonal():
+    """amgh_compact_blocks / amgh_coloring_blockids / amgh_hybrid_dinv_block_ids (block-hybrid Gauss-Seidel on block levels):
+    blocks of at most max_rows block rows cover every row once and are far more compact than runs of consecutive rows; the
+    colouring separates coupled rows of one block; the diagonal follows hybrid_smoother_utils.hpp:86-141"""
+    import ctypes as C
+    from ngsamg_amd import _lib
+    lib = _lib.host()
+    p = fem.elasticity_fast((8, 8, 40), dirichlet="left", mu=1.0, lam=0.5, rotations=True)
+    A = to_matrix(p)
+    d = A.desc()
+    fr = np.ascontiguousarray(p.free, dtype=np.uint8)
+    blk = np.zeros(p.n, dtype=np.int32)
+    nb = C.c_int64()
+    _lib.hcheck(lib.amgh_compact_blocks(C.byref(d), _lib.ptr(fr, C.c_uint8), 56, 64, _lib.ptr(blk, C.c_int32), C.byref(nb)))
+    assert blk.min() == 0 and blk.max() + 1 == nb.value
+    sizes = np.bincount(blk)
+    assert sizes.max() <= 64 and np.all(sizes[np.unique(blk[fr.astype(bool)])] >= 1)
+    assert np.all(sizes[blk[~fr.astype(bool)]] == 1)                      # non-free rows: blocks of their own
+    free_sizes = np.bincount(blk[fr.astype(bool)])
+    assert free_sizes[free_sizes > 0].mean() > 40
+    S = sp.csr_matrix((np.ones(p.col.size), p.col, p.rowptr), shape=(p.n, p.n)).tocoo()
+    off = S.row != S.col
+    frac_compact = np.mean(blk[S.row[off]] == blk[S.col[off]])
+    frac_lines = np.mean((S.row[off] // 60) == (S.col[off] // 60))
+    assert frac_compact > 1.5 * frac_lines and frac_compact > 0.45       # couplings inside a block: compact vs consecutive rows
+    color = np.zeros(p.n, dtype=np.int32)
+    nc = C.c_int32()
+    _lib.hcheck(lib.amgh_coloring_blockids(C.byref(d), _lib.ptr(fr, C.c_uint8), _lib.ptr(blk, C.c_int32), _lib.ptr(color, C.c_int32), C.byref(nc)))
+    assert np.all(color[~fr.astype(bool)] == -1) and np.all(color[fr.astype(bool)] >= 0)
+    same = off & (blk[S.row] == blk[S.col]) & (color[S.row] >= 0) & (color[S.col] >= 0)
+    assert not np.any(color[S.row[same]] == color[S.col[same]])
+    dinv = np.zeros(p.n * 36)
+    _lib.hcheck(lib.amgh_hybrid_dinv_block_ids(C.byref(d), _lib.ptr(fr, C.c_uint8), _lib.ptr(blk, C.c_int32), 0, _lib.ptr(dinv, C.c_double)))
+    val = p.val.reshape(-1, 6, 6)
+    diag = np.zeros((p.n, 6))
+    D = np.zeros((p.n, 6, 6))
+    for i in range(p.n):
+        for k in range(p.rowptr[i], p.rowptr[i + 1]):
+            if p.col[k] == i:
+                D[i], diag[i] = val[k], np.diag(val[k])
+    rng = np.random.default_rng(0)
+    for i in rng.choice(np.nonzero(fr)[0], 25, replace=False):
+        fac = 1.0
+        for l in range(6):
+            ad = 0.0
+            for k in range(p.rowptr[i], p.rowptr[i + 1]):
+                j = p.col[k]
+                if blk[j] == blk[i]:
+                    continue
+                ad += np.sum(np.abs(val[k][l]) / np.sqrt(diag[i, l] * diag[j]))
+            fac = max(fac, 0.51 * (1.0 + ad))
+        assert np.allclose(dinv[i * 36:(i + 1) * 36].reshape(6, 6), np.linalg.inv(D[i]) / fac, rtol=1e-10, atol=1e-14)
