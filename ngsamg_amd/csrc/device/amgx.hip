@@ -1089,8 +1089,16 @@ struct Handle {
     spmv_ep<EP_JAC>(L.A, xin, xout, EpArgs{b, xin, L.dinv.p, L.omega, nullptr, ep_nt}, sp);
   }
 
-  void zero(double* v, int64_t n) { if (n) HIPCHK(hipMemsetAsync(v, 0, n * sizeof(double), stream)); }
-  void copy(double* dst, const double* src, int64_t n) { if (n && dst != src) HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, stream)); }
+  void zero(double* v, int64_t n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(vec_zero_kernel, dim3(grid_for((n + 1) / 2)), dim3(BLOCK), 0, stream, n, v);
+    HIPCHK(hipGetLastError());
+  }
+  void copy(double* dst, const double* src, int64_t n) {
+    if (n <= 0 || dst == src) return;
+    hipLaunchKernelGGL(vec_copy_kernel, dim3(grid_for((n + 1) / 2)), dim3(BLOCK), 0, stream, n, src, dst);
+    HIPCHK(hipGetLastError());
+  }
 
   // x (+)= omega * dinv * v
   // rows: block rows to process (default: the owned rows; a rank-partitioned level may ask for its ghost rows too)

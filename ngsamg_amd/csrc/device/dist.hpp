@@ -66,6 +66,13 @@ struct Rccl {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------------
+// device-to-device copy as a kernel of our own (see vec_copy_kernel)
+static inline void dev_copy(double* dst, const double* src, int64_t n, hipStream_t st) {
+  if (n <= 0 || dst == src) return;
+  hipLaunchKernelGGL(vec_copy_kernel, dim3((unsigned)(((n + 1) / 2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, n, src, dst);
+  HIPCHK(hipGetLastError());
+}
+
 struct HaloTable {                       // one level of one rank
   int bs = 1;
   int64_t n = 0, n_ghost = 0, n_int = 0; // owned block rows, ghost block rows, interior rows (no ghost column)
@@ -238,8 +245,7 @@ struct Comm {
           const HaloTable& tq = *items[q].t;
           const int kq = tq.peer_pos((int)i);
           if (kq < 0 || (tq.recv_ptr[kq + 1] - tq.recv_ptr[kq]) * tq.bs != ns) throw Err("local exchange: send / receive sizes do not match");
-          HIPCHK(hipMemcpyAsync(items[q].vec + (tq.n + tq.recv_ptr[kq]) * tq.bs, t.sendbuf.p + t.send_ptr[k] * t.bs, ns * sizeof(double),
-                                hipMemcpyDeviceToDevice, comm_stream));
+          dev_copy(items[q].vec + (tq.n + tq.recv_ptr[kq]) * tq.bs, t.sendbuf.p + t.send_ptr[k] * t.bs, ns, comm_stream);
         }
       }
     }
@@ -278,8 +284,7 @@ struct Comm {
           const HaloTable& tq = *items[q].t;
           const int kq = tq.peer_pos((int)i);
           if (kq < 0 || (tq.send_ptr[kq + 1] - tq.send_ptr[kq]) * tq.bs != nr) throw Err("local exchange: send / receive sizes do not match");
-          HIPCHK(hipMemcpyAsync(tq.sendbuf.p + tq.send_ptr[kq] * tq.bs, items[i].vec + (t.n + t.recv_ptr[k]) * t.bs, nr * sizeof(double),
-                                hipMemcpyDeviceToDevice, comm_stream));
+          dev_copy(tq.sendbuf.p + tq.send_ptr[kq] * tq.bs, items[i].vec + (t.n + t.recv_ptr[k]) * t.bs, nr, comm_stream);
         }
       }
     }
@@ -488,7 +493,7 @@ struct DistCycle {
         }
       } else {
         for (size_t q = 0; q < M.size(); ++q)
-          if (d->counts[i]) HIPCHK(hipMemcpyAsync(M[q]->bglob.p + d->offs[i] * bsk, d->bk.p, d->counts[i] * bsk * sizeof(double), hipMemcpyDeviceToDevice, c.compute));
+          if (d->counts[i]) dev_copy(M[q]->bglob.p + d->offs[i] * bsk, d->bk.p, d->counts[i] * bsk, c.compute);
       }
     }
   }
@@ -714,7 +719,7 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     const int64_t nb = b_status == 0 ? d->next(0) : d->n(0);
     if (nb == 0) {}
     else if (host) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyHostToDevice, c.compute));
-    else if (b[i] != d->bext[0].p) HIPCHK(hipMemcpyAsync(d->bext[0].p, b[i], nb * sizeof(double), hipMemcpyDeviceToDevice, c.compute));
+    else if (b[i] != d->bext[0].p) dev_copy(d->bext[0].p, b[i], nb, c.compute);
     b0[i] = d->bext[0].p;
     cy.x.push_back(host ? d->x0.p : x[i]);
   }

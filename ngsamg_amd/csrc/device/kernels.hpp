@@ -1291,6 +1291,24 @@ __global__ __launch_bounds__(BLOCK) void diag_apply_kernel(int64_t n, const doub
   }
 }
 
+// v = 0 / dst = src as kernels of our own (two entries per lane; in a captured cycle they are plain kernel nodes, where the
+// runtime's memset / memcpy nodes are blit launches with their own tail paths)
+__global__ __launch_bounds__(BLOCK) void vec_zero_kernel(int64_t n, double* __restrict__ v) {
+  const int64_t i = 2 * ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
+  if (i + 1 < n) {
+    if ((reinterpret_cast<uintptr_t>(v) & 15) == 0) *reinterpret_cast<double2*>(v + i) = make_double2(0.0, 0.0);
+    else { v[i] = 0.0; v[i + 1] = 0.0; }
+  } else if (i < n) v[i] = 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void vec_copy_kernel(int64_t n, const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t i = 2 * ((int64_t)blockIdx.x * BLOCK + threadIdx.x);
+  if (i + 1 < n) {
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0)
+      *reinterpret_cast<double2*>(dst + i) = *reinterpret_cast<const double2*>(src + i);
+    else { const double a = src[i], b = src[i + 1]; dst[i] = a; dst[i + 1] = b; }
+  } else if (i < n) dst[i] = src[i];
+}
+
 // y += s * x
 __global__ __launch_bounds__(BLOCK) void axpy_kernel(int64_t n, double s, const double* __restrict__ x, double* y) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -1334,12 +1334,22 @@ class _DeviceDist:
         self.rhs_buffer(i)
         return self._rhs[i][0]
 
-    def Mult(self, bs, xs, b_status=1):
+    def _bind_stream(self):
+        """the communicator works on torch's current stream.  On the legacy default stream (handle 0) it keeps its own
+        non-blocking stream (a null stream cannot be captured into the cycle's graph), which torch's default stream does not
+        order with: what the caller enqueued there so far (allocations, fills, the right-hand side) is waited for here."""
         import torch
-        st = int(torch.cuda.current_stream().cuda_stream)
+        cur = torch.cuda.current_stream()
+        st = int(cur.cuda_stream)
+        if st == 0:
+            cur.synchronize()
         if st != self._stream:
             self._ck(self._lib.amgx_comm_set_stream(self._comm, C.c_void_p(st)))
             self._stream = st
+
+    def Mult(self, bs, xs, b_status=1):
+        import torch
+        self._bind_stream()
         n = len(self._dists)
         if len(bs) != n or len(xs) != n:
             raise NgsAMGError("Mult: one b and one x per local rank")
@@ -1363,10 +1373,7 @@ class _DeviceDist:
         """amgx_dist_pcg: collective PCG with the rank-partitioned cycle as preconditioner; xs hold the initial guess and
         receive the solution.  Returns (iterations, err_0 .. err_iterations)."""
         import torch
-        st = int(torch.cuda.current_stream().cuda_stream)
-        if st != self._stream:
-            self._ck(self._lib.amgx_comm_set_stream(self._comm, C.c_void_p(st)))
-            self._stream = st
+        self._bind_stream()
         n = len(self._dists)
         for i, (b, x) in enumerate(zip(bs, xs)):
             m = self.amg.dist_levels[0][i].n * _bs(self.amg.dist_levels[0][i])
