@@ -319,11 +319,22 @@ struct SetupTasks {
   std::mutex mu;
   explicit SetupTasks(int dev) : device(dev) {}
   ~SetupTasks() { for (auto& t : th) if (t.joinable()) t.join(); }
+  bool log = std::getenv("AMGX_SETUP_LOG") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   template <class F>
-  void run(F f) {
-    if (serial) { f(); return; }
-    th.emplace_back([this, f]() mutable {
-      try { HIPCHK(hipSetDevice(device)); f(); }
+  void timed(F& f, const char* name) {
+    if (!log) { f(); return; }
+    const auto a = std::chrono::steady_clock::now();
+    f();
+    const auto b = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[amgx_create]   task %-28s %8.1f .. %8.1f ms\n", name, std::chrono::duration<double, std::milli>(a - t0).count(),
+                 std::chrono::duration<double, std::milli>(b - t0).count());
+  }
+  template <class F>
+  void run(F f, const char* name = "") {
+    if (serial) { timed(f, name); return; }
+    th.emplace_back([this, f, name]() mutable {
+      try { HIPCHK(hipSetDevice(device)); timed(f, name); }
       catch (...) { std::lock_guard<std::mutex> g(mu); errs.push_back(std::current_exception()); }
     });
   }
@@ -2315,6 +2326,7 @@ static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_lev
 
 }  // namespace amgx
 #include "dense_spd.hpp"
+#include "devbuild.hpp"
 namespace amgx {
 
 // ---- collapsed coarse levels (see dense_op_gemv_kernel) -----------------------------------------------------------
@@ -2419,8 +2431,31 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS && s.sm_type != AMGX_SM_BGS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
     SetupTasks tasks(d->device);
+    // big scalar levels: the CSR arrays go to the device once and kernels write the images of A, A' and Q there (devbuild.hpp)
+    const bool dev_images = dev_images_wanted(s.A);
+    const bool verify_images = dev_images && std::getenv("AMGX_VERIFY_IMAGES") != nullptr;
+    DevCsrSrc csrA;
+    DbDiagInfo diagA;
+    if (dev_images) {
+      check_matrix(s.A, "A");
+      csrA.upload(s.A);
+      if (s.dinv) L.dinv.upload(s.dinv, (size_t)(last ? L.n : L.ncols) * L.bs * L.bs);
+      diagA = dev_diag_check(csrA, (s.dinv && s.A.n_rows <= s.A.n_cols) ? L.dinv.p : nullptr);
+      clk.lap("CSR of A to the device", l);
+    }
     // block GS walks the CSR arrays of A, so keep A in CSR there
-    tasks.run([&] { upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0); });
+    tasks.run([&] {
+      if (dev_images && dev_upload_matrix(csrA, L.A, true, 1.35, 0, &diagA)) {
+        if (verify_images) { DevMatrix H; upload_matrix(s.A, H, "A", true, true, false); verify_same_image(L.A, H, "A"); }
+        return;
+      }
+      if (verify_images) {
+        DevMatrix H;
+        upload_matrix(s.A, H, "A", true, true, false);
+        if (H.fmt == FMT_SELL && H.lanes == 1) throw Err("AMGX_VERIFY_IMAGES: the device builder declined A where the host builder forms a SELL image");
+      }
+      upload_matrix(s.A, L.A, "A", true, true, s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0);
+    }, "A");
     if (!last) {
       const amgx_level_desc& c = levels[l + 1];
       if (s.P.n_rows != s.A.n_rows || s.P.n_cols > c.A.n_cols || s.P.n_cols < c.A.n_rows || s.P.br != s.A.br || s.P.bc != c.A.br)
@@ -2438,16 +2473,35 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         if (const char* e = std::getenv("AMGX_RESTRICT_MIN_ROWS")) min_rows = std::atoll(e);
         if (s.P.br == 1 && s.P.bc == 1 && s.P.n_rows >= min_rows && s.P.rowptr[s.P.n_rows] < (int64_t)2147483647)
           build_restrict(s.P, L.R);
-      });
+      }, "P, PT");
       tasks.run([&] {
-        L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
+        if (!dev_images) L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
         if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
         else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
         else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
         if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
-      });
+      }, "smoother data");
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
         tasks.run([&] {
+        auto fused_restrict = [&] {
+          // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
+          // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
+          // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
+          if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 &&
+              s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
+          {
+            L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
+            if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
+            build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
+          }
+        };
+        // (device builder: A' = A diag(omega Dinv) from the CSR of A that is already there; the diagonal slot carries omega*Dinv_i
+        //  under the same conditions as below)
+        const bool dev_wdiag = s.omega != 0.0 && !std::getenv("AMGX_NO_WDIAG") && diagA.plain;
+        if (dev_images && !verify_images && dev_upload_matrix(csrA, L.Apre, true, 1.35, 0, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) {
+          fused_restrict();
+          return;
+        }
         // column-scaled image for the fused pre-smoothing pass (memory for bandwidth: one more copy of A)
         const int64_t nnz = s.A.rowptr[s.A.n_rows];
         std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnz)]);      // (uninitialised: every entry is written below)
@@ -2476,18 +2530,16 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             par_for(s.A.n_rows, [&](int64_t i0, int64_t i1, int) { for (int64_t i = i0; i < i1; ++i) wdv[i] = s.omega * s.dinv[i]; }, 1 << 16);
           }
         }
-        upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
-        // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
-        // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
-        // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
-        if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 &&
-            s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
-        {
-          L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
-          if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
-          build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
-        }
-        });
+        if (dev_images && verify_images) {
+          DevMatrix H;
+          upload_matrix(As, H, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
+          if (dev_upload_matrix(csrA, L.Apre, true, 1.35, 0, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) verify_same_image(L.Apre, H, "A'");
+          else if (H.fmt == FMT_SELL && H.lanes == 1) throw Err("AMGX_VERIFY_IMAGES: the device builder declined A' where the host builder forms a SELL image");
+          else L.Apre = std::move(H);
+        } else
+          upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
+        fused_restrict();
+        }, "A' + fused restriction");
         // post-smoothing folded into the prolongation (V-cycle).  Square levels: Q is built here.  Rank-partitioned
         // levels: Q needs the P rows of the ghost vertices, so the caller supplies it (amgx_level_desc.Q) and drives
         // the level through amgx_cycle_down / amgx_cycle_up.
@@ -2501,6 +2553,27 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             tasks.run([&, qpad] { upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN); });
           } else if (s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows) {
             tasks.run([&, qpad] {
+              // (device: the sparse product and the windowed image of its result, devbuild.hpp)
+              if (dev_images) {
+                check_matrix(s.P, "P");
+                DevCsrSrc csrP, csrQ;
+                csrP.upload(s.P);
+                if (dev_fold_prolongation(csrA, csrP, L.dinv.p, s.omega, csrQ) && dev_upload_matrix(csrQ, L.Q, false, qpad, SELL_WIN, nullptr)) {
+                  if (verify_images) {
+                    HostCsr q;
+                    fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
+                    if ((int64_t)q.rowptr[s.A.n_rows] != csrQ.nnz) throw Err("AMGX_VERIFY_IMAGES: Q: different numbers of entries");
+                    amgx_matrix Qm = s.P;
+                    Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
+                    DevMatrix H;
+                    upload_matrix(Qm, H, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+                    verify_same_image(L.Q, H, "Q");
+                  }
+                  return;
+                }
+                L.Q = DevMatrix();
+                if (verify_images) std::fprintf(stderr, "[amgx_create] AMGX_VERIFY_IMAGES: level %d: Q is left to the host builder\n", l);
+              }
               HostCsr q;
               fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
               if (q.rowptr[s.A.n_rows] < (int64_t)2147483647) {
@@ -2508,7 +2581,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
                 Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
                 upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
               }
-            });
+            }, "Q = (I - w Dinv A) P");
           }
         }
       }

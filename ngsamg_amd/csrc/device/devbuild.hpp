@@ -1,0 +1,414 @@
+// Device-side builders of the big scalar level images (included by amgx.hip after the host builders).
+//
+// amgx_create used to form every image on the host: at cfg 2 (148 M entries) the SELL images of A and A', the product
+// Q = (I - omega Dinv A) P (reference: the sparse products of utils_sparseMM.cpp:107-238 on the setup side) and its windowed
+// image were 2.6 s of host loops behind 4 GB of pageable host-to-device copies.  Here the CSR arrays of A and P go to the
+// device once and kernels write the images where they are used:
+//     db_width / db_scan / db_fill     CSR -> SELL-64-pair image (one thread per row; natural order or a row list)
+//     db_window_sort                   row order of the windowed form (rows of a 512-row window by decreasing length, stable)
+//     db_fold<false|true>              row-wise sparse product Q = P - omega Dinv (A P): count, then fill (columns ascending)
+// Every kernel restates its host builder (build_sell, upload_matrix's window sort, fold_prolongation) decision by decision and
+// in the same floating-point order without contraction, so the images are bit-identical: AMGX_VERIFY_IMAGES=1 builds both and
+// compares every array; AMGX_HOST_IMAGES=1 keeps the host builders.
+#pragma once
+
+namespace amgx {
+
+struct DevCsrSrc {                      // a scalar CSR matrix on the device, 64-bit row pointers as in amgx_matrix
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  DevBuf<int64_t> rowptr;
+  DevBuf<int32_t> col;
+  DevBuf<double> val;
+  void upload(const amgx_matrix& A) {
+    n_rows = A.n_rows; n_cols = A.n_cols; nnz = A.rowptr[A.n_rows];
+    rowptr.upload(A.rowptr, (size_t)A.n_rows + 1);
+    col.upload(A.col, (size_t)std::max<int64_t>(1, nnz));
+    val.upload(A.val, (size_t)std::max<int64_t>(1, nnz));
+  }
+};
+
+constexpr int DB_BLOCK = 256;                    // 4 slices (waves) per workgroup
+constexpr int DB_FOLD_CAP = 64;                  // distinct coarse columns of one row of Q the product kernel holds (else: host builder)
+
+// width of every slice of 64 list entries: sp[s + 1] = 64 * (longest row of the slice), sp[0] = 0
+__global__ __launch_bounds__(DB_BLOCK) void db_width_kernel(int64_t m, const int32_t* __restrict__ rows, const int64_t* __restrict__ rowptr,
+                                                            int64_t ns, int64_t* __restrict__ sp) {
+  const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (s >= ns) return;
+  const int64_t q = s * WAVE + l;
+  int len = 0;
+  if (q < m) {
+    const int64_t r = rows ? (int64_t)rows[q] : q;
+    if (r >= 0) len = (int)(rowptr[r + 1] - rowptr[r]);
+  }
+  for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+  if (l == 0) { sp[s + 1] = (int64_t)len * WAVE; if (s == 0) sp[0] = 0; }
+}
+
+// in-place inclusive sum of v[1..n] (v[0] stays): one workgroup, a contiguous piece per thread
+__global__ __launch_bounds__(1024) void db_scan_kernel(int64_t n, int64_t* __restrict__ v) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t a = 1 + (int64_t)t * chunk, b = min(n + 1, a + chunk);
+  int64_t s = 0;
+  for (int64_t i = a; i < b; ++i) s += v[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int64_t x = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  int64_t run = t ? part[t - 1] : 0;
+  for (int64_t i = a; i < b; ++i) { run += v[i]; v[i] = run; }
+}
+
+struct DbFill {
+  int64_t m, n_cols, ns;
+  const int32_t* rows;
+  int rowrel, diag_first;
+  const int64_t* rowptr; const int32_t* col; const double* val;
+  const double* colscale; double omega;        // image of A' = A * diag(omega * colscale): value = val * (omega * colscale[col])
+  const double* wdiag; int64_t wdiag_rows;      // diagonal-first image whose diagonal slot carries omega * wdiag[row] (patch_sell_diag)
+  const int64_t* sp;
+  int32_t* col32; uint16_t* col16; int32_t* cbase; double* out;
+  uint8_t* comp; unsigned long long* counters;  // [0] slices in the 16-bit form, [1] bytes one product streams
+};
+
+// one wave per slice, one lane per list entry: build_sell's fill pass for G == 1
+__global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
+  const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (s >= a.ns) return;
+  const int64_t base = a.sp[s];
+  const int w = (int)((a.sp[s + 1] - base) / WAVE);
+  const int wp = w & ~1;
+  const int64_t q = s * WAVE + l;
+  const int64_t r = q < a.m ? (a.rows ? (int64_t)a.rows[q] : q) : -1;
+  const int64_t rb = r >= 0 ? a.rowptr[r] : 0;
+  const int len = r >= 0 ? (int)(a.rowptr[r + 1] - rb) : 0;
+  int dp = 0;
+  if (a.diag_first && r >= 0)
+    for (int k = 0; k < len; ++k) if (a.col[rb + k] == r) { dp = k; break; }
+  const int64_t rk = a.rows ? r : q;
+  const int64_t rr = a.rowrel ? rk : 0;
+  const int32_t padcol = (r >= 0 && len) ? a.col[rb] : 0;
+  bool comp = true;
+  for (int j = 0; j < w; ++j) {
+    const bool has = j < len;
+    int64_t c = 0;
+    double v = 0.0;
+    if (has) {
+      const int se = !a.diag_first ? j : (j == 0 ? dp : (j <= dp ? j - 1 : j));
+      const int64_t ks = rb + se;
+      c = a.col[ks];
+      v = a.val[ks];
+      if (a.colscale) v = v * (a.omega * a.colscale[c]);
+      if (a.wdiag && j == 0 && r < a.wdiag_rows) v = a.omega * a.wdiag[r];
+    }
+    long long mn = has ? (long long)(c - (a.rowrel ? r : 0)) : LLONG_MAX;
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+    const int64_t cb = mn == LLONG_MAX ? 0 : (int64_t)mn;
+    if (cb < INT32_MIN / 2 || cb > INT32_MAX / 2) comp = false;
+    if (l == 0) a.cbase[base / WAVE + j] = (int32_t)cb;
+    const int64_t o = j < wp ? base + (int64_t)(j >> 1) * (2 * WAVE) + l * 2 + (j & 1) : base + (int64_t)(w - 1) * WAVE + l;
+    if (has) {
+      a.col32[o] = (int32_t)c;
+      a.out[o] = v;
+      const int64_t d = c - rr - cb;
+      if (d < 0 || d > 65535) comp = false;
+      a.col16[o] = (uint16_t)d;
+    } else {
+      a.col32[o] = padcol;
+      a.out[o] = 0.0;
+      if (a.rows && r < 0) { a.col16[o] = 0; continue; }          // lane never executes
+      int64_t d = (int64_t)padcol - rr - cb;
+      if (d < 0 || d > 65535) {
+        d = max((int64_t)0, -(rr + cb));
+        if (d > 65535 || rr + cb + d >= a.n_cols) comp = false;
+      }
+      a.col16[o] = (uint16_t)d;
+    }
+  }
+  const bool all = __all(comp ? 1 : 0) != 0;
+  if (l == 0) {
+    const bool flag = all && w > 0;
+    a.comp[s] = flag ? 1 : 0;
+    atomicAdd(a.counters + 0, flag ? 1ull : 0ull);
+    atomicAdd(a.counters + 1, flag ? (unsigned long long)((int64_t)w * WAVE * 10 + 4 * w) : (unsigned long long)((int64_t)w * WAVE * 12));
+  }
+}
+
+// encoding flag of slice s into bit 0 of its offset (after every slice has read the plain offsets)
+__global__ __launch_bounds__(BLOCK) void db_flag_kernel(int64_t ns, const uint8_t* __restrict__ comp, int64_t* __restrict__ sp) {
+  const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (s < ns && comp[s]) sp[s] |= 1;
+}
+
+// flags[0]: a row without a stored diagonal; flags[1]: a row whose dinv is not the plain inverse of its diagonal
+__global__ __launch_bounds__(BLOCK) void db_diag_check_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              const double* __restrict__ val, const double* __restrict__ dinv, int* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  bool found = false;
+  double aii = 0.0;
+  for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) if (col[k] == i) { aii = val[k]; found = true; break; }
+  if (!found) flags[0] = 1;
+  if (dinv && dinv[i] != 0.0 && !(fabs(dinv[i] * aii - 1.0) < 1e-13)) flags[1] = 1;
+}
+
+// rows of every window of WIN consecutive rows in order of decreasing length, equal lengths in row order (std::stable_sort)
+template <int WIN>
+__global__ __launch_bounds__(WIN) void db_window_sort_kernel(int64_t n_rows, const int64_t* __restrict__ rowptr, int32_t* __restrict__ rows,
+                                                             uint16_t* __restrict__ rowloc) {
+  __shared__ int lens[WIN];
+  const int64_t w0 = (int64_t)blockIdx.x * WIN;
+  const int t = threadIdx.x;
+  const int cnt = (int)min((int64_t)WIN, n_rows - w0);
+  const int len = t < cnt ? (int)(rowptr[w0 + t + 1] - rowptr[w0 + t]) : -1;
+  lens[t] = len;
+  __syncthreads();
+  if (t >= cnt) return;
+  int rank = 0;
+  for (int u = 0; u < cnt; ++u) { const int lu = lens[u]; rank += (lu > len) || (lu == len && u < t); }
+  rows[w0 + rank] = (int32_t)(w0 + t);
+  rowloc[w0 + rank] = (uint16_t)t;
+}
+
+struct DbFold {
+  int64_t n, p_rows;
+  const int64_t* arp; const int32_t* acol; const double* aval;
+  const int64_t* prp; const int32_t* pcol; const double* pval;
+  const double* dinv; double omega;
+};
+
+// fold_prolongation, one thread per row.  FILL = false: qrp[i + 1] = distinct columns of row i.  FILL = true (qrp scanned):
+// columns ascending, value = P_ic - omega * (Dinv_i * sum_j A_ij P_jc), the sum in the order of the entries of A_i and P_j.
+template <bool FILL>
+__global__ __launch_bounds__(BLOCK) void db_fold_kernel(DbFold a, int64_t* __restrict__ qrp, int32_t* __restrict__ qcol, double* __restrict__ qval,
+                                                        int* __restrict__ overflow) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  int32_t cols[DB_FOLD_CAP];
+  double own[FILL ? DB_FOLD_CAP : 1], acc[FILL ? DB_FOLD_CAP : 1];
+  int nc = 0;
+  bool over = false;
+  auto slot = [&](int32_t c) -> int {
+    for (int q = 0; q < nc; ++q) if (cols[q] == c) return q;
+    if (nc == DB_FOLD_CAP) { over = true; return -1; }
+    cols[nc] = c;
+    if (FILL) { own[nc] = 0.0; acc[nc] = 0.0; }
+    return nc++;
+  };
+  for (int64_t k = a.prp[i]; k < a.prp[i + 1]; ++k) {
+    const int sl = slot(a.pcol[k]);
+    if (FILL && sl >= 0) own[sl] += a.pval[k];
+  }
+  const double d = a.dinv[i];
+  if (d != 0.0)
+    for (int64_t k = a.arp[i]; k < a.arp[i + 1]; ++k) {
+      const int64_t j = a.acol[k];
+      if (j >= a.p_rows) continue;
+      const double av = a.aval[k];
+      for (int64_t q = a.prp[j]; q < a.prp[j + 1]; ++q) {
+        const int sl = slot(a.pcol[q]);
+        if (FILL && sl >= 0) acc[sl] += av * a.pval[q];
+      }
+    }
+  if (over) *overflow = 1;
+  if (!FILL) { qrp[i + 1] = nc; if (i == 0) qrp[0] = 0; return; }
+  if (over) return;
+  int64_t o = qrp[i];
+  for (int p = 0; p < nc; ++p) {                 // ascending columns: the smallest of what is left
+    int best = -1;
+    for (int q = 0; q < nc; ++q) if (cols[q] != INT32_MAX && (best < 0 || cols[q] < cols[best])) best = q;
+    double u = 0.0;
+    u += d * acc[best];
+    qcol[o] = cols[best];
+    qval[o] = own[best] - a.omega * u;
+    cols[best] = INT32_MAX;
+    ++o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+
+static bool dev_images_wanted(const amgx_matrix& A) {
+  if (std::getenv("AMGX_HOST_IMAGES")) return false;
+  if (A.br != 1 || A.bc != 1 || A.n_rows <= 0) return false;
+  const int64_t nnz = A.rowptr[A.n_rows];
+  if (nnz <= 0 || nnz >= (int64_t)2147483647) return false;
+  int64_t min_rows = 65536;
+  if (const char* e = std::getenv("AMGX_DEV_IMAGES_MIN_ROWS")) min_rows = std::atoll(e);
+  if (A.n_rows < min_rows) return false;
+  // upload_matrix's choice of lanes per row: the device builder is the one-thread-per-row form
+  const double avg = (double)nnz / (double)A.n_rows;
+  int G = 1;
+  while (G < 16 && A.n_rows * G < ((int64_t)1 << 20) && avg > 3.0 * G) G <<= 1;
+  if (const char* e = std::getenv("AMGX_SELL_MAX_LANES")) G = std::max(1, std::min(G, std::atoi(e)));
+  return G == 1;
+}
+
+struct DbDiagInfo { bool all_diag = false, plain = false; };
+
+static DbDiagInfo dev_diag_check(const DevCsrSrc& A, const double* d_dinv) {
+  DevBuf<int> fl;
+  fl.alloc(2);
+  HIPCHK(hipMemset(fl.p, 0, 2 * sizeof(int)));
+  hipLaunchKernelGGL(db_diag_check_kernel, dim3((unsigned)((A.n_rows + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, A.n_rows, A.rowptr.p, A.col.p, A.val.p, d_dinv, fl.p);
+  HIPCHK(hipGetLastError());
+  int h[2];
+  HIPCHK(hipMemcpy(h, fl.p, sizeof(h), hipMemcpyDeviceToHost));
+  return DbDiagInfo{h[0] == 0, h[1] == 0};
+}
+
+// slice offsets of the list `rows` (or the natural order) into sp [ns + 1]; returns the stored entries
+static int64_t dev_slice_offsets(const DevCsrSrc& A, const int32_t* d_rows, int64_t m, DevBuf<int64_t>& sp) {
+  const int64_t ns = (m + WAVE - 1) / WAVE;
+  sp.alloc((size_t)ns + 1);
+  hipLaunchKernelGGL(db_width_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, m, d_rows, A.rowptr.p, ns, sp.p);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, 0, ns, sp.p);
+  HIPCHK(hipGetLastError());
+  int64_t stored = 0;
+  HIPCHK(hipMemcpy(&stored, sp.p + ns, sizeof(int64_t), hipMemcpyDeviceToHost));
+  return stored;
+}
+
+// upload_matrix for a scalar matrix already on the device (same decisions, same image).  Returns false, D untouched, where the
+// host builder would not produce a one-thread-per-row SELL image (the caller then runs the host builder).
+//   d_colscale / omega: image of A * diag(omega * colscale);  d_wdiag: the diagonal slot carries omega * wdiag[row] (needs info.plain)
+static bool dev_upload_matrix(const DevCsrSrc& A, DevMatrix& D, bool rowrel_ok, double max_pad, int win, const DbDiagInfo* info,
+                              const double* d_colscale = nullptr, double omega = 0.0, const double* d_wdiag = nullptr) {
+  const int64_t m = A.n_rows;
+  if (m <= 0 || A.nnz <= 0) return false;
+  DevBuf<int64_t> sp;
+  int64_t stored = dev_slice_offsets(A, nullptr, m, sp);
+  if (!((double)stored <= max_pad * (double)A.nnz)) return false;                       // host: sellG = 0 -> CSR kernels
+  const bool windowed = win > 0 && (double)stored > 1.10 * (double)A.nnz && !std::getenv("AMGX_NO_SELL_WINDOW");
+  DevBuf<int32_t> rows;
+  DevBuf<uint16_t> rowloc;
+  if (windowed) {
+    if (win != SELL_WIN) throw Err("windowed SELL: unexpected window size");
+    rows.alloc((size_t)m); rowloc.alloc((size_t)m);
+    hipLaunchKernelGGL((db_window_sort_kernel<SELL_WIN>), dim3((unsigned)((m + SELL_WIN - 1) / SELL_WIN)), dim3(SELL_WIN), 0, 0, m, A.rowptr.p, rows.p, rowloc.p);
+    HIPCHK(hipGetLastError());
+    stored = dev_slice_offsets(A, rows.p, m, sp);
+  }
+  const int64_t ns = (m + WAVE - 1) / WAVE;
+  const bool rowrel = !windowed && rowrel_ok && A.n_cols >= A.n_rows;
+  const bool diag_first = !windowed && rowrel_ok && A.n_rows <= A.n_cols && !std::getenv("AMGX_NO_DIAG_FIRST") && info && info->all_diag;
+  const bool wdiag = d_wdiag && diag_first;
+  DevMatrix::Sell& S = D.sell;
+  S.col32.alloc((size_t)std::max<int64_t>(1, stored));
+  S.col16.alloc((size_t)std::max<int64_t>(1, stored));
+  S.val.alloc((size_t)std::max<int64_t>(1, stored));
+  S.cbase.alloc((size_t)(stored / WAVE + 32));       // (+ 32: slack behind the last slice, see upload_sell)
+  HIPCHK(hipMemset(S.cbase.p, 0, (size_t)(stored / WAVE + 32) * sizeof(int32_t)));
+  DevBuf<uint8_t> comp;
+  comp.alloc((size_t)ns);
+  DevBuf<unsigned long long> counters;
+  counters.alloc(2);
+  HIPCHK(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
+  DbFill f{m, A.n_cols, ns, windowed ? rows.p : nullptr, rowrel ? 1 : 0, diag_first ? 1 : 0, A.rowptr.p, A.col.p, A.val.p,
+           d_colscale, omega, wdiag ? d_wdiag : nullptr, A.n_rows, sp.p, S.col32.p, S.col16.p, S.cbase.p, S.val.p, comp.p, counters.p};
+  hipLaunchKernelGGL(db_fill_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, f);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(db_flag_kernel, dim3((unsigned)((ns + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, ns, comp.p, sp.p);
+  HIPCHK(hipGetLastError());
+  unsigned long long cnt[2];
+  HIPCHK(hipMemcpy(cnt, counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  const int64_t n_comp = (int64_t)cnt[0];
+  if (n_comp == ns) S.col32.release();               // only read by 32-bit slices
+  if (n_comp == 0) { S.col16.release(); S.cbase.release(); }
+  S.slice_ptr = std::move(sp);
+  S.rowrel = rowrel ? 1 : 0;
+  S.diag_first = diag_first ? 1 : 0;
+  S.wdiag = wdiag ? 1 : 0;
+  S.win = 0;
+  D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = 1; D.bc = 1; D.nnz = A.nnz;
+  D.fmt = FMT_SELL;
+  D.lanes = 1;
+  D.n_slices = (int)ns;
+  D.stored = stored;
+  D.stream_bytes = 8 * (ns + 1) + (int64_t)cnt[1];
+  if (windowed) {
+    D.stream_bytes += 2 * A.n_rows;
+    S.win = win;
+    S.rowloc = std::move(rowloc);
+  }
+  return true;
+}
+
+// Q = (I - omega Dinv A) P on the device (fold_prolongation); false = a row with more than DB_FOLD_CAP columns or too many entries
+static bool dev_fold_prolongation(const DevCsrSrc& A, const DevCsrSrc& P, const double* d_dinv, double omega, DevCsrSrc& Q) {
+  const int64_t n = A.n_rows;
+  DbFold a{n, P.n_rows, A.rowptr.p, A.col.p, A.val.p, P.rowptr.p, P.col.p, P.val.p, d_dinv, omega};
+  DevBuf<int> over;
+  over.alloc(1);
+  HIPCHK(hipMemset(over.p, 0, sizeof(int)));
+  Q.rowptr.alloc((size_t)n + 1);
+  const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL((db_fold_kernel<false>), dim3(grid), dim3(BLOCK), 0, 0, a, Q.rowptr.p, (int32_t*)nullptr, (double*)nullptr, over.p);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, 0, n, Q.rowptr.p);
+  HIPCHK(hipGetLastError());
+  int ho = 0;
+  int64_t nnz = 0;
+  HIPCHK(hipMemcpy(&ho, over.p, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&nnz, Q.rowptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (ho || nnz >= (int64_t)2147483647) return false;
+  Q.n_rows = n; Q.n_cols = P.n_cols; Q.nnz = nnz;
+  Q.col.alloc((size_t)std::max<int64_t>(1, nnz));
+  Q.val.alloc((size_t)std::max<int64_t>(1, nnz));
+  hipLaunchKernelGGL((db_fold_kernel<true>), dim3(grid), dim3(BLOCK), 0, 0, a, Q.rowptr.p, Q.col.p, Q.val.p, over.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return true;
+}
+
+// AMGX_VERIFY_IMAGES: every array of two SELL images bit by bit (the 16-bit columns only where a slice uses them)
+template <class T>
+static std::vector<T> db_download(const DevBuf<T>& b, size_t count) {
+  std::vector<T> h(count);
+  if (count) HIPCHK(hipMemcpy(h.data(), b.p, count * sizeof(T), hipMemcpyDeviceToHost));
+  return h;
+}
+static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char* what) {
+  auto fail = [&](const char* part) { throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built images differ in " + part); };
+  if (a.fmt != b.fmt || a.n_rows != b.n_rows || a.n_cols != b.n_cols || a.nnz != b.nnz || a.lanes != b.lanes || a.n_slices != b.n_slices ||
+      a.stored != b.stored || a.stream_bytes != b.stream_bytes) fail("the descriptor");
+  const DevMatrix::Sell &x = a.sell, &y = b.sell;
+  if (x.rowrel != y.rowrel || x.diag_first != y.diag_first || x.wdiag != y.wdiag || x.win != y.win) fail("the flags");
+  const size_t ns = (size_t)a.n_slices, st = (size_t)a.stored;
+  const auto spx = db_download(x.slice_ptr, ns + 1), spy = db_download(y.slice_ptr, ns + 1);
+  if (spx != spy) fail("slice_ptr");
+  const auto vx = db_download(x.val, st), vy = db_download(y.val, st);
+  if (std::memcmp(vx.data(), vy.data(), st * sizeof(double)) != 0) fail("val");
+  if ((x.col32.p == nullptr) != (y.col32.p == nullptr) || (x.col16.p == nullptr) != (y.col16.p == nullptr)) fail("the column encodings present");
+  if (x.col32.p) {
+    const auto cx = db_download(x.col32, st), cy = db_download(y.col32, st);
+    if (cx != cy) fail("col32");
+  }
+  if (x.col16.p) {
+    const auto cx = db_download(x.col16, st), cy = db_download(y.col16, st);
+    const auto bx = db_download(x.cbase, st / WAVE), by = db_download(y.cbase, st / WAVE);
+    if (bx != by) fail("cbase");
+    for (size_t s = 0; s < ns; ++s) {
+      if (!(spx[s] & 1)) continue;
+      const size_t o0 = (size_t)(spx[s] & ~(int64_t)63), o1 = (size_t)(spx[s + 1] & ~(int64_t)63);
+      if (std::memcmp(cx.data() + o0, cy.data() + o0, (o1 - o0) * sizeof(uint16_t)) != 0) fail("col16");
+    }
+  }
+  if (x.win) {
+    const auto rx = db_download(x.rowloc, (size_t)a.n_rows), ry = db_download(y.rowloc, (size_t)a.n_rows);
+    if (rx != ry) fail("rowloc");
+  }
+}
+
+}  // namespace amgx

@@ -1,0 +1,72 @@
+"""Device-side image builders (csrc/device/devbuild.hpp): SELL images of A and A', the sparse product Q = (I - omega Dinv A) P
+and its windowed image are written by kernels from the CSR arrays.  AMGX_VERIFY_IMAGES=1 makes amgx_create build every such image
+with the host builders too and compare all arrays bit by bit (it raises on the first difference); the cycle's result must be
+bitwise the same as with AMGX_HOST_IMAGES=1."""
+import os
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+
+from tests.problems import poisson_case, rhs
+
+pytestmark = pytest.mark.gpu
+
+
+@contextmanager
+def env(**kw):
+    old = {k: os.environ.get(k) for k in kw}
+    try:
+        for k, v in kw.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _formats(d):
+    return [{w: d.matrix_info(l, w) for w in ("A", "Apre", "Q")} for l in range(d.GetNLevels() - 1)]
+
+
+def _apply(H, p, sm, **e):
+    from ngsamg_amd.device import DeviceAMGMatrix
+    with env(**e):
+        d = DeviceAMGMatrix(H, device=0, sm_type=sm)
+    b = rhs(p, 3)
+    x = np.full(p.n, np.nan)
+    d.Mult(b, x)
+    return x, d
+
+
+# small levels take the one-thread-per-row form only with the lane cap (AMGX_SELL_MAX_LANES = 1, a test hook of upload_matrix)
+SMALL = dict(AMGX_DEV_IMAGES_MIN_ROWS=0, AMGX_SELL_MAX_LANES=1)
+
+
+@pytest.mark.parametrize("shape,diri,mcs", [((33, 33), "left|top", 5), ((224, 224), "left|top", 5), ((17, 17, 17), "right|top", 20),
+                                            ((9, 30, 13), ".*", 20), ((41, 37, 29), "right|top", 10), ((7, 5, 3), "", 4)])
+@pytest.mark.parametrize("sm", ["jacobi", "gs"])
+def test_device_built_images_equal_host_built_images(shape, diri, mcs, sm):
+    p, H = poisson_case(shape, diri, mcs)
+    xv, dv = _apply(H, p, sm, AMGX_VERIFY_IMAGES=1, **SMALL)        # raises if any array of any image differs
+    xh, dh = _apply(H, p, sm, AMGX_HOST_IMAGES=1, **SMALL)
+    xd, dd = _apply(H, p, sm, **SMALL)
+    assert np.array_equal(xd, xh) and np.array_equal(xv, xh)
+    assert _formats(dd) == _formats(dh)
+
+
+def test_device_built_images_million_rows_default_settings():
+    """the path as cfg 2 takes it (no hooks): 102^3 = 1.06 M rows, level 0 built on the device and verified against the host"""
+    p, H = poisson_case((102, 102, 102), "right|top", 50)
+    xv, dv = _apply(H, p, "jacobi", AMGX_VERIFY_IMAGES=1)
+    xh, dh = _apply(H, p, "jacobi", AMGX_HOST_IMAGES=1)
+    assert np.array_equal(xv, xh)
+    assert _formats(dv) == _formats(dh)
+    fi = _formats(dv)
+    assert fi[0]["A"]["fmt"] == "sell" and fi[0]["Apre"]["fmt"] == "sell" and fi[0]["Q"]["fmt"] == "sellwin"
