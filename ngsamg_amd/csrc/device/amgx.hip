@@ -1821,15 +1821,24 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
   }
 }
 
+}  // namespace amgx
+#include "devbuild.hpp"
+namespace amgx {
+
 // Block-hybrid Gauss-Seidel data (gsb_sweep_kernel).  Validated like the colourings above: two coupled rows of one block
 // sharing a colour would be a data race.
-static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* P) {
+// csr: the level matrix on the device (big levels): the three images and the split are then formed there (devbuild.hpp)
+static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* P, const DevCsrSrc* csr = nullptr) {
   const int64_t n = d.A.n_rows;
   DevGSB& g = L.gsb;
   const int B = d.gs_block_rows;
   // lanes per row from the longest row (a lane holds <= 16 entries, + 1 when G = 1); workgroup size TH = B * G
   int64_t mx = 0;
-  for (int64_t i = 0; i < n; ++i) mx = std::max<int64_t>(mx, d.A.rowptr[i + 1] - d.A.rowptr[i]);
+  {
+    std::vector<int64_t> tmx(setup_threads(), 0);
+    par_for(n, [&](int64_t i0, int64_t i1, int t) { int64_t m = 0; for (int64_t i = i0; i < i1; ++i) m = std::max<int64_t>(m, d.A.rowptr[i + 1] - d.A.rowptr[i]); tmx[t] = m; });
+    for (int64_t v : tmx) mx = std::max(mx, v);
+  }
   int G = 1;
   while (G < 16 && mx > 16 * G + (G == 1 ? 1 : 0)) G <<= 1;
   // the ranks of a partitioned level agree on ONE block size (the smallest any of them needs, dist.py) while their longest
@@ -1847,28 +1856,32 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
   if (!d.color || d.n_colors <= 0 || d.n_colors > 254) { if (n > 0) throw Err("block-hybrid Gauss-Seidel needs a blocked colouring with at most 254 colours"); return; }
   if (!d.dinv) throw Err("dinv missing");
   const int nc = d.n_colors;
-  for (int64_t i = 0; i < n; ++i) {
-    const int ci = d.color[i];
-    if (ci >= nc) throw Err("colour index out of range");
-    if (ci < 0) continue;
-    const int64_t b0 = (i / B) * B, b1 = b0 + B;
-    for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
-      const int64_t j = d.A.col[k];
-      if (j != i && j >= b0 && j < b1 && j < n && d.color[j] == ci) throw Err("invalid blocked colouring: two coupled rows of one block share a colour");
+  par_for(n, [&](int64_t i0, int64_t i1, int) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const int ci = d.color[i];
+      if (ci >= nc) throw Err("colour index out of range");
+      if (ci < 0) continue;
+      const int64_t b0 = (i / B) * B, b1 = b0 + B;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+        const int64_t j = d.A.col[k];
+        if (j != i && j >= b0 && j < b1 && j < n && d.color[j] == ci) throw Err("invalid blocked colouring: two coupled rows of one block share a colour");
+      }
     }
-  }
+  });
   g.B = B; g.G = G; g.TH = TH; g.n_colors = nc;
   g.n_blocks = (int)((n + B - 1) / B);
   const int64_t slots = (int64_t)g.n_blocks * B;
   std::vector<int32_t> rows((size_t)slots, -1);
   std::vector<uint8_t> sc((size_t)slots, 255);
-  for (int64_t b0 = 0; b0 < n; b0 += B) {
-    const int64_t b1 = std::min<int64_t>(n, b0 + B);
-    for (int64_t i = b0; i < b1; ++i) rows[i] = (int32_t)i;
-    std::stable_sort(rows.begin() + b0, rows.begin() + b1, [&](int32_t a, int32_t c) {
-      return (d.color[a] < 0 ? 255 : d.color[a]) < (d.color[c] < 0 ? 255 : d.color[c]); });
-    for (int64_t q = b0; q < b1; ++q) sc[q] = d.color[rows[q]] < 0 ? 255 : (uint8_t)d.color[rows[q]];
-  }
+  par_for(g.n_blocks, [&](int64_t k0, int64_t k1, int) {
+    for (int64_t kb = k0; kb < k1; ++kb) {
+      const int64_t b0 = kb * B, b1 = std::min<int64_t>(n, b0 + B);
+      for (int64_t i = b0; i < b1; ++i) rows[i] = (int32_t)i;
+      std::stable_sort(rows.begin() + b0, rows.begin() + b1, [&](int32_t a, int32_t c) {
+        return (d.color[a] < 0 ? 255 : d.color[a]) < (d.color[c] < 0 ? 255 : d.color[c]); });
+      for (int64_t q = b0; q < b1; ++q) sc[q] = d.color[rows[q]] < 0 ? 255 : (uint8_t)d.color[rows[q]];
+    }
+  }, 16);
   auto check_width = [&](const HostSell& S, const char* what) {
     const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
     for (int64_t q = 0; q < ns; ++q) {
@@ -1877,42 +1890,126 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
                                         " entries for gs_block_rows = " + std::to_string(B) + " (use smaller blocks)");
     }
   };
+  g.rowid.upload(rows);
+  g.slotcolor.upload(sc);
+  if (csr) {
+    // device builders: the colour-sorted image of A, the split by kernels, the images of its two parts
+    auto max_width = [&](const DevMatrix::Sell& S, const char* what) {
+      const auto sp = db_download(S.slice_ptr, S.slice_ptr.n);
+      int mw = 0;
+      for (size_t q = 0; q + 1 < sp.size(); ++q) mw = std::max(mw, (int)(((sp[q + 1] & ~(int64_t)63) - (sp[q] & ~(int64_t)63)) / WAVE));
+      if (mw > 2 * GSB_WP + 1) throw Err(std::string("block-hybrid Gauss-Seidel (") + what + "): a row has more than " + std::to_string((2 * GSB_WP) * G + 1) +
+                                         " entries for gs_block_rows = " + std::to_string(B) + " (use smaller blocks)");
+      return mw;
+    };
+    {
+      DevBuf<int64_t> sp;
+      const int64_t stored = dev_slice_offsets(*csr, g.rowid.p, slots, sp, G);
+      dev_build_sell(*csr, g.rowid.p, slots, G, false, false, nullptr, 0.0, nullptr, sp, stored, g.full, nullptr);
+      max_width(g.full, "A");
+    }
+    DevBuf<int32_t> dcolor;
+    dcolor.upload(d.color, (size_t)n);
+    DbSplit a{n, B, csr->rowptr.p, csr->col.p, csr->val.p, dcolor.p, L.dinv.p};
+    DevCsrSrc part[2];
+    for (int q = 0; q < 2; ++q) { part[q].n_rows = n; part[q].n_cols = d.A.n_cols; part[q].rowptr.alloc((size_t)n + 1); }
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(db_split_count_kernel, dim3(grid), dim3(BLOCK), 0, 0, a, part[0].rowptr.p, part[1].rowptr.p);
+    HIPCHK(hipGetLastError());
+    for (int q = 0; q < 2; ++q) {
+      hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, 0, n, part[q].rowptr.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpy(&part[q].nnz, part[q].rowptr.p + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+      part[q].col.alloc((size_t)std::max<int64_t>(1, part[q].nnz));
+      part[q].val.alloc((size_t)std::max<int64_t>(1, part[q].nnz));
+    }
+    g.cvec.alloc((size_t)n);
+    DevBuf<int> bad;
+    bad.alloc(1);
+    HIPCHK(hipMemset(bad.p, 0, sizeof(int)));
+    hipLaunchKernelGGL(db_split_fill_kernel, dim3(grid), dim3(BLOCK), 0, 0, a, part[0].rowptr.p, part[1].rowptr.p, part[0].col.p, part[0].val.p,
+                       part[1].col.p, part[1].val.p, g.cvec.p, bad.p);
+    HIPCHK(hipGetLastError());
+    int hbad = 0;
+    HIPCHK(hipMemcpy(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (hbad || std::getenv("AMGX_GSB_NO_SPLIT")) { g.cvec.release(); return; }
+    {
+      DevBuf<int64_t> sp;
+      const int64_t stored = dev_slice_offsets(part[0], g.rowid.p, slots, sp, G);
+      dev_build_sell(part[0], g.rowid.p, slots, G, false, false, nullptr, 0.0, nullptr, sp, stored, g.lowin, nullptr);
+      g.lowin_maxw = max_width(g.lowin, "lower part");
+    }
+    if (!dev_upload_matrix(part[1], g.rest, false, 1.6, SELL_WIN, nullptr)) {
+      // (the host builder's CSR fallback for a badly padded remainder: from the host copy of the part)
+      std::vector<int64_t> rp = db_download(part[1].rowptr, (size_t)n + 1);
+      std::vector<int32_t> cc = db_download(part[1].col, (size_t)std::max<int64_t>(1, part[1].nnz));
+      std::vector<double> vv = db_download(part[1].val, (size_t)std::max<int64_t>(1, part[1].nnz));
+      amgx_matrix F = d.A;
+      F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+      upload_matrix(F, g.rest, "A (block-hybrid Gauss-Seidel: rest)", true, false, false, 1.6, SELL_WIN);
+    }
+    g.has_split = true;
+    if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
+        P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
+      build_restrict(*P, L.RG, 512, 4 * 512);
+    return;
+  }
   {
     HostSell S;
     build_sell(d.A, rows.data(), slots, false, G, S);
     check_width(S, "A");
     upload_sell(S, g.full);
   }
-  g.rowid.upload(rows);
-  g.slotcolor.upload(sc);
   // split for the pre-smoothing from zero: lowin = in-block couplings to lower colours, rest = everything else but the
   // diagonal; couplings to non-free columns are dropped (x is 0 there), non-free rows are empty (their residual is not
   // needed: their prolongation rows are empty)
-  const int64_t nnz = d.A.rowptr[n];
   std::vector<double> cv((size_t)n, 0.0);
   std::vector<int64_t> rp[2];
-  std::vector<int32_t> cc[2];
-  std::vector<double> vv[2];
-  for (int part = 0; part < 2; ++part) { rp[part].assign(n + 1, 0); cc[part].reserve(nnz / 2 + 16); vv[part].reserve(nnz / 2 + 16); }
-  bool ok = true;
-  for (int64_t i = 0; i < n; ++i) {
-    const int ci = d.color[i];
-    if (ci >= 0) {
-      const int64_t b0 = (i / B) * B, b1 = b0 + B;
+  RawVec<int32_t> cc[2];
+  RawVec<double> vv[2];
+  for (int part = 0; part < 2; ++part) rp[part].assign(n + 1, 0);
+  // part of entry (i, k): 0 = in-block coupling to a lower colour, 1 = rest, -1 = dropped (the diagonal, a non-free column)
+  auto part_of = [&](int64_t i, int ci, int64_t j) -> int {
+    if (j == i) return -1;
+    const int cj = j < n ? d.color[j] : 0;            // ghost columns count as live
+    if (cj < 0) return -1;
+    const int64_t b0 = (i / B) * B, b1 = b0 + B;
+    return (j >= b0 && j < b1 && j < n && cj < ci) ? 0 : 1;
+  };
+  par_for(n, [&](int64_t i0, int64_t i1, int) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const int ci = d.color[i];
+      if (ci < 0) continue;
+      for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+        const int pt = part_of(i, ci, d.A.col[k]);
+        if (pt >= 0) rp[pt][i + 1]++;
+      }
+    }
+  });
+  for (int part = 0; part < 2; ++part) {
+    for (int64_t i = 0; i < n; ++i) rp[part][i + 1] += rp[part][i];
+    cc[part].resize((size_t)std::max<int64_t>(1, rp[part][n]));
+    vv[part].resize((size_t)std::max<int64_t>(1, rp[part][n]));
+  }
+  std::vector<char> bad(setup_threads(), 0);
+  par_for(n, [&](int64_t i0, int64_t i1, int t) {
+    for (int64_t i = i0; i < i1; ++i) {
+      const int ci = d.color[i];
+      if (ci < 0) continue;
+      int64_t o[2] = {rp[0][i], rp[1][i]};
       double aii = 0.0;
       for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
         const int64_t j = d.A.col[k];
         if (j == i) { aii = d.A.val[k]; continue; }
-        const int cj = j < n ? d.color[j] : 0;            // ghost columns count as live
-        if (cj < 0) continue;
-        const int part = (j >= b0 && j < b1 && j < n && cj < ci) ? 0 : 1;
-        cc[part].push_back((int32_t)j); vv[part].push_back(d.A.val[k]);
+        const int pt = part_of(i, ci, j);
+        if (pt < 0) continue;
+        cc[pt][o[pt]] = (int32_t)j; vv[pt][o[pt]] = d.A.val[k]; ++o[pt];
       }
-      if (d.dinv[i] != 0.0) cv[i] = 1.0 / d.dinv[i] - aii; else ok = false;     // a swept row without a diagonal inverse
+      if (d.dinv[i] != 0.0) cv[i] = 1.0 / d.dinv[i] - aii; else bad[t] = 1;     // a swept row without a diagonal inverse
     }
-    rp[0][i + 1] = (int64_t)cc[0].size();
-    rp[1][i + 1] = (int64_t)cc[1].size();
-  }
+  });
+  bool ok = true;
+  for (char c : bad) if (c) ok = false;
   if (ok && !std::getenv("AMGX_GSB_NO_SPLIT")) {
     amgx_matrix F = d.A;
     F.rowptr = rp[0].data(); F.col = cc[0].data(); F.val = vv[0].data();
@@ -2326,7 +2423,6 @@ static void permute_gs_levels(const amgx_hierarchy_desc* d, std::vector<amgx_lev
 
 }  // namespace amgx
 #include "dense_spd.hpp"
-#include "devbuild.hpp"
 namespace amgx {
 
 // ---- collapsed coarse levels (see dense_op_gemv_kernel) -----------------------------------------------------------
@@ -2477,7 +2573,25 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       tasks.run([&] {
         if (!dev_images) L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
         if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
-        else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) build_gsb(s, L, &s.P);
+        else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) {
+          build_gsb(s, L, &s.P, dev_images ? &csrA : nullptr);
+          if (verify_images) {
+            DevLevel H;
+            H.n = L.n; H.ncols = L.ncols; H.bs = L.bs;
+            build_gsb(s, H, &s.P, nullptr);
+            const DevGSB &x = L.gsb, &y = H.gsb;
+            if (x.B != y.B || x.G != y.G || x.TH != y.TH || x.n_blocks != y.n_blocks || x.n_colors != y.n_colors || x.lowin_maxw != y.lowin_maxw ||
+                x.has_split != y.has_split) throw Err("AMGX_VERIFY_IMAGES: block-hybrid Gauss-Seidel: the descriptors differ");
+            const size_t nsl = (size_t)((int64_t)x.n_blocks * x.B / (WAVE / x.G));
+            verify_same_sell(x.full, y.full, nsl, 0, "block-hybrid Gauss-Seidel: A");
+            if (x.has_split) {
+              verify_same_sell(x.lowin, y.lowin, nsl, 0, "block-hybrid Gauss-Seidel: lower part");
+              verify_same_image(x.rest, y.rest, "block-hybrid Gauss-Seidel: rest");
+              const auto cx = db_download(x.cvec, (size_t)L.n), cy = db_download(y.cvec, (size_t)L.n);
+              if (std::memcmp(cx.data(), cy.data(), (size_t)L.n * sizeof(double)) != 0) throw Err("AMGX_VERIFY_IMAGES: block-hybrid Gauss-Seidel: cvec differs");
+            }
+          }
+        }
         else if (s.sm_type == AMGX_SM_GS) build_gs(s, L);
         if (s.sm_type == AMGX_SM_BGS) build_bgs(s, L);
       }, "smoother data");

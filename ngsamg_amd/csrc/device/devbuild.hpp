@@ -30,20 +30,22 @@ struct DevCsrSrc {                      // a scalar CSR matrix on the device, 64
 constexpr int DB_BLOCK = 256;                    // 4 slices (waves) per workgroup
 constexpr int DB_FOLD_CAP = 64;                  // distinct coarse columns of one row of Q the product kernel holds (else: host builder)
 
-// width of every slice of 64 list entries: sp[s + 1] = 64 * (longest row of the slice), sp[0] = 0
+// width of every slice of R = 64 / G list entries (G lanes per row): sp[s + 1] = 64 * w, w = steps of the longest row
+// (build_sell: G == 1: its length; G > 1: 2 * ceil(ceil(len / 2) / G)), sp[0] = 0
 __global__ __launch_bounds__(DB_BLOCK) void db_width_kernel(int64_t m, const int32_t* __restrict__ rows, const int64_t* __restrict__ rowptr,
-                                                            int64_t ns, int64_t* __restrict__ sp) {
+                                                            int G, int64_t ns, int64_t* __restrict__ sp) {
   const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
   const int l = threadIdx.x & 63;
   if (s >= ns) return;
-  const int64_t q = s * WAVE + l;
+  const int64_t q = s * (WAVE / G) + l / G;
   int len = 0;
   if (q < m) {
     const int64_t r = rows ? (int64_t)rows[q] : q;
     if (r >= 0) len = (int)(rowptr[r + 1] - rowptr[r]);
   }
   for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
-  if (l == 0) { sp[s + 1] = (int64_t)len * WAVE; if (s == 0) sp[0] = 0; }
+  const int w = G == 1 ? len : 2 * (((len + 1) / 2 + G - 1) / G);
+  if (l == 0) { sp[s + 1] = (int64_t)w * WAVE; if (s == 0) sp[0] = 0; }
 }
 
 // in-place inclusive sum of v[1..n] (v[0] stays): one workgroup, a contiguous piece per thread
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(1024) void db_scan_kernel(int64_t n, int64_t* __res
 struct DbFill {
   int64_t m, n_cols, ns;
   const int32_t* rows;
-  int rowrel, diag_first;
+  int G, rowrel, diag_first;
   const int64_t* rowptr; const int32_t* col; const double* val;
   const double* colscale; double omega;        // image of A' = A * diag(omega * colscale): value = val * (omega * colscale[col])
   const double* wdiag; int64_t wdiag_rows;      // diagonal-first image whose diagonal slot carries omega * wdiag[row] (patch_sell_diag)
@@ -78,7 +80,7 @@ struct DbFill {
   uint8_t* comp; unsigned long long* counters;  // [0] slices in the 16-bit form, [1] bytes one product streams
 };
 
-// one wave per slice, one lane per list entry: build_sell's fill pass for G == 1
+// one wave per slice, G lanes per list entry: build_sell's fill pass
 __global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
   const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
   const int l = threadIdx.x & 63;
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
   const int64_t base = a.sp[s];
   const int w = (int)((a.sp[s + 1] - base) / WAVE);
   const int wp = w & ~1;
-  const int64_t q = s * WAVE + l;
+  const int G = a.G;
+  const int64_t q = s * (WAVE / G) + l / G;
   const int64_t r = q < a.m ? (a.rows ? (int64_t)a.rows[q] : q) : -1;
   const int64_t rb = r >= 0 ? a.rowptr[r] : 0;
   const int len = r >= 0 ? (int)(a.rowptr[r + 1] - rb) : 0;
@@ -98,16 +101,17 @@ __global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
   const int32_t padcol = (r >= 0 && len) ? a.col[rb] : 0;
   bool comp = true;
   for (int j = 0; j < w; ++j) {
-    const bool has = j < len;
+    const int e = G == 1 ? j : 2 * ((j >> 1) * G + (l % G)) + (j & 1);      // (lane, column) -> entry of the lane's row
+    const bool has = e < len;
     int64_t c = 0;
     double v = 0.0;
     if (has) {
-      const int se = !a.diag_first ? j : (j == 0 ? dp : (j <= dp ? j - 1 : j));
+      const int se = !a.diag_first ? e : (e == 0 ? dp : (e <= dp ? e - 1 : e));
       const int64_t ks = rb + se;
       c = a.col[ks];
       v = a.val[ks];
       if (a.colscale) v = v * (a.omega * a.colscale[c]);
-      if (a.wdiag && j == 0 && r < a.wdiag_rows) v = a.omega * a.wdiag[r];
+      if (a.wdiag && e == 0 && r < a.wdiag_rows) v = a.omega * a.wdiag[r];
     }
     long long mn = has ? (long long)(c - (a.rowrel ? r : 0)) : LLONG_MAX;
     for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
@@ -235,6 +239,56 @@ __global__ __launch_bounds__(BLOCK) void db_fold_kernel(DbFold a, int64_t* __res
   }
 }
 
+// Split of A for the block-hybrid Gauss-Seidel sweep from zero (build_gsb): part 0 = in-block couplings to lower colours,
+// part 1 = everything else but the diagonal; couplings to non-free columns are dropped, non-free rows are empty.
+struct DbSplit {
+  int64_t n; int B;
+  const int64_t* rowptr; const int32_t* col; const double* val;
+  const int32_t* color; const double* dinv;
+};
+__device__ __forceinline__ int db_split_part(const DbSplit& a, int64_t i, int ci, int64_t j) {
+  if (j == i) return -1;
+  const int cj = j < a.n ? a.color[j] : 0;            // ghost columns count as live
+  if (cj < 0) return -1;
+  const int64_t b0 = (i / a.B) * a.B, b1 = b0 + a.B;
+  return (j >= b0 && j < b1 && j < a.n && cj < ci) ? 0 : 1;
+}
+__global__ __launch_bounds__(BLOCK) void db_split_count_kernel(DbSplit a, int64_t* __restrict__ rp0, int64_t* __restrict__ rp1) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  int64_t c0 = 0, c1 = 0;
+  const int ci = a.color[i];
+  if (ci >= 0)
+    for (int64_t k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int pt = db_split_part(a, i, ci, a.col[k]);
+      if (pt == 0) ++c0; else if (pt == 1) ++c1;
+    }
+  rp0[i + 1] = c0; rp1[i + 1] = c1;
+  if (i == 0) { rp0[0] = 0; rp1[0] = 0; }
+}
+// cv[i] = 1 / dinv_i - a_ii on swept rows (0 elsewhere); *bad = 1: a swept row without a diagonal inverse
+__global__ __launch_bounds__(BLOCK) void db_split_fill_kernel(DbSplit a, const int64_t* __restrict__ rp0, const int64_t* __restrict__ rp1,
+                                                              int32_t* __restrict__ c0, double* __restrict__ v0, int32_t* __restrict__ c1,
+                                                              double* __restrict__ v1, double* __restrict__ cv, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const int ci = a.color[i];
+  double cvi = 0.0;
+  if (ci >= 0) {
+    int64_t o0 = rp0[i], o1 = rp1[i];
+    double aii = 0.0;
+    for (int64_t k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+      const int64_t j = a.col[k];
+      if (j == i) { aii = a.val[k]; continue; }
+      const int pt = db_split_part(a, i, ci, j);
+      if (pt == 0) { c0[o0] = (int32_t)j; v0[o0] = a.val[k]; ++o0; }
+      else if (pt == 1) { c1[o1] = (int32_t)j; v1[o1] = a.val[k]; ++o1; }
+    }
+    if (a.dinv[i] != 0.0) cvi = 1.0 / a.dinv[i] - aii; else *bad = 1;
+  }
+  cv[i] = cvi;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 
@@ -268,16 +322,54 @@ static DbDiagInfo dev_diag_check(const DevCsrSrc& A, const double* d_dinv) {
 }
 
 // slice offsets of the list `rows` (or the natural order) into sp [ns + 1]; returns the stored entries
-static int64_t dev_slice_offsets(const DevCsrSrc& A, const int32_t* d_rows, int64_t m, DevBuf<int64_t>& sp) {
-  const int64_t ns = (m + WAVE - 1) / WAVE;
+static int64_t dev_slice_offsets(const DevCsrSrc& A, const int32_t* d_rows, int64_t m, DevBuf<int64_t>& sp, int G = 1) {
+  const int R = WAVE / G;
+  const int64_t ns = (m + R - 1) / R;
   sp.alloc((size_t)ns + 1);
-  hipLaunchKernelGGL(db_width_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, m, d_rows, A.rowptr.p, ns, sp.p);
+  hipLaunchKernelGGL(db_width_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, m, d_rows, A.rowptr.p, G, ns, sp.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, 0, ns, sp.p);
   HIPCHK(hipGetLastError());
   int64_t stored = 0;
   HIPCHK(hipMemcpy(&stored, sp.p + ns, sizeof(int64_t), hipMemcpyDeviceToHost));
   return stored;
+}
+
+// build_sell + upload_sell for a matrix on the device: the image of the list `d_rows` [m] (null: natural order) with G lanes per
+// row; sp / stored = its slice offsets (dev_slice_offsets), consumed.  stream_bytes as HostSell::stream_bytes.
+static void dev_build_sell(const DevCsrSrc& A, const int32_t* d_rows, int64_t m, int G, bool rowrel, bool diag_first, const double* d_colscale,
+                           double omega, const double* d_wdiag, DevBuf<int64_t>& sp, int64_t stored, DevMatrix::Sell& S, int64_t* stream_bytes) {
+  const int R = WAVE / G;
+  const int64_t ns = (m + R - 1) / R;
+  S.col32.alloc((size_t)std::max<int64_t>(1, stored));
+  S.col16.alloc((size_t)std::max<int64_t>(1, stored));
+  S.val.alloc((size_t)std::max<int64_t>(1, stored));
+  S.cbase.alloc((size_t)(stored / WAVE + 32));       // (+ 32: slack behind the last slice, see upload_sell)
+  HIPCHK(hipMemset(S.cbase.p, 0, (size_t)(stored / WAVE + 32) * sizeof(int32_t)));
+  DevBuf<uint8_t> comp;
+  comp.alloc((size_t)std::max<int64_t>(1, ns));
+  DevBuf<unsigned long long> counters;
+  counters.alloc(2);
+  HIPCHK(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
+  DbFill f{m, A.n_cols, ns, d_rows, G, rowrel ? 1 : 0, diag_first ? 1 : 0, A.rowptr.p, A.col.p, A.val.p,
+           d_colscale, omega, d_wdiag, A.n_rows, sp.p, S.col32.p, S.col16.p, S.cbase.p, S.val.p, comp.p, counters.p};
+  if (ns > 0) {
+    hipLaunchKernelGGL(db_fill_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, f);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(db_flag_kernel, dim3((unsigned)((ns + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, ns, comp.p, sp.p);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned long long cnt[2];
+  HIPCHK(hipMemcpy(cnt, counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  const int64_t n_comp = (int64_t)cnt[0];
+  if (n_comp == ns) S.col32.release();               // only read by 32-bit slices
+  if (n_comp == 0) { S.col16.release(); S.cbase.release(); }
+  S.slice_ptr = std::move(sp);
+  S.rowrel = rowrel ? 1 : 0;
+  S.diag_first = diag_first ? 1 : 0;
+  S.wdiag = 0;
+  S.win = 0;
+  if (stream_bytes) *stream_bytes = 8 * (ns + 1) + (int64_t)cnt[1];
 }
 
 // upload_matrix for a scalar matrix already on the device (same decisions, same image).  Returns false, D untouched, where the
@@ -305,38 +397,15 @@ static bool dev_upload_matrix(const DevCsrSrc& A, DevMatrix& D, bool rowrel_ok, 
   const bool diag_first = !windowed && rowrel_ok && A.n_rows <= A.n_cols && !std::getenv("AMGX_NO_DIAG_FIRST") && info && info->all_diag;
   const bool wdiag = d_wdiag && diag_first;
   DevMatrix::Sell& S = D.sell;
-  S.col32.alloc((size_t)std::max<int64_t>(1, stored));
-  S.col16.alloc((size_t)std::max<int64_t>(1, stored));
-  S.val.alloc((size_t)std::max<int64_t>(1, stored));
-  S.cbase.alloc((size_t)(stored / WAVE + 32));       // (+ 32: slack behind the last slice, see upload_sell)
-  HIPCHK(hipMemset(S.cbase.p, 0, (size_t)(stored / WAVE + 32) * sizeof(int32_t)));
-  DevBuf<uint8_t> comp;
-  comp.alloc((size_t)ns);
-  DevBuf<unsigned long long> counters;
-  counters.alloc(2);
-  HIPCHK(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
-  DbFill f{m, A.n_cols, ns, windowed ? rows.p : nullptr, rowrel ? 1 : 0, diag_first ? 1 : 0, A.rowptr.p, A.col.p, A.val.p,
-           d_colscale, omega, wdiag ? d_wdiag : nullptr, A.n_rows, sp.p, S.col32.p, S.col16.p, S.cbase.p, S.val.p, comp.p, counters.p};
-  hipLaunchKernelGGL(db_fill_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, f);
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(db_flag_kernel, dim3((unsigned)((ns + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, ns, comp.p, sp.p);
-  HIPCHK(hipGetLastError());
-  unsigned long long cnt[2];
-  HIPCHK(hipMemcpy(cnt, counters.p, sizeof(cnt), hipMemcpyDeviceToHost));
-  const int64_t n_comp = (int64_t)cnt[0];
-  if (n_comp == ns) S.col32.release();               // only read by 32-bit slices
-  if (n_comp == 0) { S.col16.release(); S.cbase.release(); }
-  S.slice_ptr = std::move(sp);
-  S.rowrel = rowrel ? 1 : 0;
-  S.diag_first = diag_first ? 1 : 0;
+  int64_t bytes = 0;
+  dev_build_sell(A, windowed ? rows.p : nullptr, m, 1, rowrel, diag_first, d_colscale, omega, wdiag ? d_wdiag : nullptr, sp, stored, S, &bytes);
   S.wdiag = wdiag ? 1 : 0;
-  S.win = 0;
   D.n_rows = A.n_rows; D.n_cols = A.n_cols; D.br = 1; D.bc = 1; D.nnz = A.nnz;
   D.fmt = FMT_SELL;
   D.lanes = 1;
   D.n_slices = (int)ns;
   D.stored = stored;
-  D.stream_bytes = 8 * (ns + 1) + (int64_t)cnt[1];
+  D.stream_bytes = bytes;
   if (windowed) {
     D.stream_bytes += 2 * A.n_rows;
     S.win = win;
@@ -379,15 +448,13 @@ static std::vector<T> db_download(const DevBuf<T>& b, size_t count) {
   if (count) HIPCHK(hipMemcpy(h.data(), b.p, count * sizeof(T), hipMemcpyDeviceToHost));
   return h;
 }
-static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char* what) {
+static void verify_same_sell(const DevMatrix::Sell& x, const DevMatrix::Sell& y, size_t ns, int64_t n_rows, const char* what) {
   auto fail = [&](const char* part) { throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built images differ in " + part); };
-  if (a.fmt != b.fmt || a.n_rows != b.n_rows || a.n_cols != b.n_cols || a.nnz != b.nnz || a.lanes != b.lanes || a.n_slices != b.n_slices ||
-      a.stored != b.stored || a.stream_bytes != b.stream_bytes) fail("the descriptor");
-  const DevMatrix::Sell &x = a.sell, &y = b.sell;
   if (x.rowrel != y.rowrel || x.diag_first != y.diag_first || x.wdiag != y.wdiag || x.win != y.win) fail("the flags");
-  const size_t ns = (size_t)a.n_slices, st = (size_t)a.stored;
+  if (x.slice_ptr.n != y.slice_ptr.n || x.slice_ptr.n != ns + 1) fail("the number of slices");
   const auto spx = db_download(x.slice_ptr, ns + 1), spy = db_download(y.slice_ptr, ns + 1);
   if (spx != spy) fail("slice_ptr");
+  const size_t st = (size_t)(spx[ns] & ~(int64_t)63);
   const auto vx = db_download(x.val, st), vy = db_download(y.val, st);
   if (std::memcmp(vx.data(), vy.data(), st * sizeof(double)) != 0) fail("val");
   if ((x.col32.p == nullptr) != (y.col32.p == nullptr) || (x.col16.p == nullptr) != (y.col16.p == nullptr)) fail("the column encodings present");
@@ -406,9 +473,15 @@ static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char
     }
   }
   if (x.win) {
-    const auto rx = db_download(x.rowloc, (size_t)a.n_rows), ry = db_download(y.rowloc, (size_t)a.n_rows);
+    const auto rx = db_download(x.rowloc, (size_t)n_rows), ry = db_download(y.rowloc, (size_t)n_rows);
     if (rx != ry) fail("rowloc");
   }
+}
+static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char* what) {
+  if (a.fmt != b.fmt || a.n_rows != b.n_rows || a.n_cols != b.n_cols || a.nnz != b.nnz || a.lanes != b.lanes || a.n_slices != b.n_slices ||
+      a.stored != b.stored || a.stream_bytes != b.stream_bytes)
+    throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built images differ in the descriptor");
+  verify_same_sell(a.sell, b.sell, (size_t)a.n_slices, a.n_rows, what);
 }
 
 }  // namespace amgx
