@@ -481,7 +481,13 @@ static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char
   if (a.fmt != b.fmt || a.n_rows != b.n_rows || a.n_cols != b.n_cols || a.nnz != b.nnz || a.lanes != b.lanes || a.n_slices != b.n_slices ||
       a.stored != b.stored || a.stream_bytes != b.stream_bytes)
     throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built images differ in the descriptor");
-  verify_same_sell(a.sell, b.sell, (size_t)a.n_slices, a.n_rows, what);
+  if (a.fmt == FMT_SELL) { verify_same_sell(a.sell, b.sell, (size_t)a.n_slices, a.n_rows, what); return; }
+  // (both builders fell back to the CSR kernels)
+  if (a.rowptr.n != b.rowptr.n || a.col.n != b.col.n || a.val.n != b.val.n || db_download(a.rowptr, a.rowptr.n) != db_download(b.rowptr, b.rowptr.n) ||
+      db_download(a.col, a.col.n) != db_download(b.col, b.col.n))
+    throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": CSR images differ in the pattern");
+  const auto vx = db_download(a.val, a.val.n), vy = db_download(b.val, b.val.n);
+  if (std::memcmp(vx.data(), vy.data(), vx.size() * sizeof(double)) != 0) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": CSR images differ in the values");
 }
 
 }  // namespace amgx

@@ -24,6 +24,15 @@ struct BCSR {
   int bsz() const { return br * bc; }
 };
 
+// the caller's arrays as they are (C ABI entry points that only read the matrix: no copy of 10^8 entries)
+struct CsrView {
+  int64_t n_rows = 0, n_cols = 0;
+  int br = 1, bc = 1;
+  const int64_t* rowptr = nullptr;
+  const int32_t* col = nullptr;
+  const double* val = nullptr;
+};
+
 // C = A^T with sorted columns (reference TransposeSPMImpl, src/base/linalg/utils_sparseMM.cpp:54-93)
 BCSR transpose(const BCSR& A);
 

@@ -35,6 +35,13 @@ amgh::BCSR to_bcsr_pattern(const amgh_matrix* m) {
   return A;
 }
 
+amgh::CsrView as_view(const amgh_matrix* m) {
+  amgh::CsrView A;
+  A.n_rows = m->n_rows; A.n_cols = m->n_cols; A.br = m->br; A.bc = m->bc;
+  A.rowptr = m->rowptr; A.col = m->col; A.val = m->val;
+  return A;
+}
+
 void view(const amgh::BCSR& A, amgh_matrix* m) {
   m->n_rows = A.n_rows; m->n_cols = A.n_cols; m->br = A.br; m->bc = A.bc;
   m->rowptr = A.rowptr.data(); m->col = A.col.data(); m->val = A.val.data();
@@ -157,8 +164,7 @@ int amgh_coloring_blocked(const amgh_matrix* A, const uint8_t* free_or_null, int
   return guard([&] {
     check_matrix(A);
     if (block_rows < 1 || !color_out || !n_colors) throw amgh::Error("amgh_coloring_blocked: bad arguments");
-    amgh::BCSR M = to_bcsr(A);
-    *n_colors = amgh::greedy_coloring_blocked(M, free_or_null, block_rows, color_out);
+    *n_colors = amgh::greedy_coloring_blocked(as_view(A), free_or_null, block_rows, color_out);
   });
 }
 
@@ -172,8 +178,7 @@ int amgh_hybrid_dinv_ext(const amgh_matrix* A, const uint8_t* free_or_null, int6
     check_matrix(A);
     if (A->br != 1 || A->bc != 1) throw amgh::Error("amgh_hybrid_dinv: scalar matrices only");
     if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv: bad arguments");
-    amgh::BCSR M = to_bcsr(A);
-    amgh::hybrid_mod_dinv(M, free_or_null, block_rows, dinv_out, ghost_diag_or_null);
+    amgh::hybrid_mod_dinv(as_view(A), free_or_null, block_rows, dinv_out, ghost_diag_or_null);
   });
 }
 

@@ -541,7 +541,8 @@ int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color) {
 
 // greedy colouring that only sees couplings INSIDE blocks of `block_rows` consecutive rows (block-hybrid Gauss-Seidel:
 // couplings that cross a block boundary are frozen during a sweep, so they put no constraint on the order)
-int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color) {
+template <class Mat>
+static int greedy_coloring_blocked_t(const Mat& A, const uint8_t* free, int64_t block_rows, int32_t* color) {
   const int64_t n = A.n_rows;
   int ncol = 0;
 #pragma omp parallel
@@ -573,10 +574,14 @@ int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_ro
   return ncol;
 }
 
+int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color) { return greedy_coloring_blocked_t(A, free, block_rows, color); }
+int greedy_coloring_blocked(const CsrView& A, const uint8_t* free, int64_t block_rows, int32_t* color) { return greedy_coloring_blocked_t(A, free, block_rows, color); }
+
 // inverse of the l1-type modified diagonal of the hybrid smoother (reference CalcModDiag, hybrid_smoother_utils.hpp:35-142):
 //   ad_k = sum over the couplings of row k that leave its block of |a_kj| / sqrt(a_kk a_jj);  md_k = max(1, 0.51 (1 + ad_k)) a_kk
 // scalar matrices; non-free rows get 0
-void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag) {
+template <class Mat>
+static void hybrid_mod_dinv_t(const Mat& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag) {
   const int64_t n = A.n_rows;
   std::vector<double> d((size_t)A.n_cols, 0.0);
 #pragma omp parallel for schedule(static)
@@ -598,6 +603,9 @@ void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, dou
     dinv[i] = 1.0 / (std::max(1.0, 0.51 * (1.0 + ad)) * d[i]);
   }
 }
+
+void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag) { hybrid_mod_dinv_t(A, free, block_rows, dinv, ghost_diag); }
+void hybrid_mod_dinv(const CsrView& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag) { hybrid_mod_dinv_t(A, free, block_rows, dinv, ghost_diag); }
 
 // the same for square-block matrices (reference hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): per block row k and scalar
 // row l, ad_k(l) = sum over the couplings that leave the block of rows of sum_m |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)); the
@@ -770,8 +778,17 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       std::vector<double> cur_vs = F.vscale;
       BCSR Ptot;
       bool failed = false;
+      const bool tlog = std::getenv("NGSAMG_SETUP_LOG") != nullptr;
+      double tl = omp_get_wtime();
+      auto lap = [&](const char* what) {
+        if (!tlog) return;
+        const double t = omp_get_wtime();
+        std::fprintf(stderr, "[setup_levels] level %d  %-28s %8.1f ms\n", lev, what, 1e3 * (t - tl));
+        tl = t;
+      };
       while (true) {
         Graph G = strength_graph(*curA, cur_free, dim, o.energy);
+        lap("strength graph");
         if (o.robust_soc) { G.vs = cur_vs; G.vs.resize(G.n, 0.0); }
         const double step_target = (o.enable_multistep && target < o.aaf) ? std::max(target, o.aaf) : target;
         std::vector<int32_t> sagg;
@@ -781,12 +798,14 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         for (auto f : cur_free) cur_free_n += f;
         const int64_t snc = o.spw ? aggregate_spw(G, cur_free, o, sagg, r)
                                   : aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
+        lap("agglomeration");
         if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }
         // robust_soc: what is left are vertices that must not be merged; a level that is barely smaller than its parent costs a
         // smoother and buys nothing (the coarsest-level inverse takes over)
         if (o.robust_soc && lev > 0 && (double)snc > 0.8 * (double)cur_free_n) { failed = substeps == 0; break; }
         rounds += r;
         BCSR W = prolongation_weights(G, sagg, snc, o);
+        lap("prolongation weights");
         const int sbf = curA->br;
         std::vector<double> sxc;
         if (!cur_coords.empty()) {
@@ -798,7 +817,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         }
         BCSR Pk = block_prolongation(W, sbf, bs_c, dim, o.energy, cur_coords, sxc);
         BCSR PkT = transpose(Pk);
+        lap("block prolongation, P^T");
         BCSR nextA = restrict_matrix(PkT, *curA, Pk);
+        lap("Galerkin product");
         if (substeps == 0) { Ptot = std::move(Pk); agg = sagg; }
         else {
           Ptot = matmul(Ptot, Pk);

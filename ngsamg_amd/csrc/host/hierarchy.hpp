@@ -60,7 +60,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
 void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv);
 int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color);
 int greedy_coloring_blocked(const BCSR& A, const uint8_t* free, int64_t block_rows, int32_t* color);
+int greedy_coloring_blocked(const CsrView& A, const uint8_t* free, int64_t block_rows, int32_t* color);
 void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag = nullptr);
+void hybrid_mod_dinv(const CsrView& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag = nullptr);
 void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row = nullptr);
 int64_t compact_blocks(const BCSR& A, const uint8_t* free, int target, int max_rows, int32_t* block_of_row);
 int greedy_coloring_blockids(const BCSR& A, const uint8_t* free, const int32_t* block_of_row, int32_t* color);

@@ -51,7 +51,7 @@ SMALL = dict(AMGX_DEV_IMAGES_MIN_ROWS=0, AMGX_SELL_MAX_LANES=1)
 
 @pytest.mark.parametrize("shape,diri,mcs", [((33, 33), "left|top", 5), ((224, 224), "left|top", 5), ((17, 17, 17), "right|top", 20),
                                             ((9, 30, 13), ".*", 20), ((41, 37, 29), "right|top", 10), ((7, 5, 3), "", 4)])
-@pytest.mark.parametrize("sm", ["jacobi", "gs"])
+@pytest.mark.parametrize("sm", ["jacobi", "gs", "hgs"])
 def test_device_built_images_equal_host_built_images(shape, diri, mcs, sm):
     p, H = poisson_case(shape, diri, mcs)
     xv, dv = _apply(H, p, sm, AMGX_VERIFY_IMAGES=1, **SMALL)        # raises if any array of any image differs
@@ -61,11 +61,13 @@ def test_device_built_images_equal_host_built_images(shape, diri, mcs, sm):
     assert _formats(dd) == _formats(dh)
 
 
-def test_device_built_images_million_rows_default_settings():
-    """the path as cfg 2 takes it (no hooks): 102^3 = 1.06 M rows, level 0 built on the device and verified against the host"""
+@pytest.mark.parametrize("sm", ["jacobi", "hgs"])
+def test_device_built_images_million_rows_default_settings(sm):
+    """the path as cfg 2 takes it (no hooks): 102^3 = 1.06 M rows, level 0 built on the device and verified against the host
+    (hgs: rows of up to 27 entries, i.e. two lanes per row in the colour-sorted images)"""
     p, H = poisson_case((102, 102, 102), "right|top", 50)
-    xv, dv = _apply(H, p, "jacobi", AMGX_VERIFY_IMAGES=1)
-    xh, dh = _apply(H, p, "jacobi", AMGX_HOST_IMAGES=1)
+    xv, dv = _apply(H, p, sm, AMGX_VERIFY_IMAGES=1)
+    xh, dh = _apply(H, p, sm, AMGX_HOST_IMAGES=1)
     assert np.array_equal(xv, xh)
     assert _formats(dv) == _formats(dh)
     fi = _formats(dv)
