@@ -82,7 +82,7 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
         torch.cuda.synchronize()
         mem0 = torch.cuda.mem_get_info(device)[0]
         amg = D.DistributedAMG(comm, [st], dim=3, omega=0.9, dist_min_rows=dmin, device=device, max_coarse_size=50, max_levels=10,
-                               energy=1, regularize_cmats=0 if rot else 1, sm_type="jacobi" if args.smoother == "jacobi" else "gs", **hier_kw)
+                               energy=1, regularize_cmats=0 if rot else 1, sm_type={"jacobi": "jacobi", "gs": "hgs", "gs_mc": "gs"}[args.smoother], **hier_kw)
     else:
         st = D.assemble_poisson_owned(rank, pg, (nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1, gshape=gsh, coords=cmode)
         t1 = time.time()
@@ -366,8 +366,6 @@ def main():
     nv = args.nv if args.nv else (215 if args.config == "cfg2" else (342 if args.scaling == "strong" else 171) if args.config == "cfg4" else 126)
     if args.config == "cfg4":
         os.environ.setdefault("NGSAMG_PGRID", "box")
-    if (world > 1 or force_dist) and args.config in ("cfg3", "cfg5") and args.smoother == "gs_mc":
-        raise SystemExit("--config cfg3 / cfg5 on several ranks: --smoother jacobi | gs (gs = hybrid block Gauss-Seidel in colour order)")
     if world > 1 or force_dist:
         run_distributed(args, torch, dist, world, rank, device, nv)
         return

@@ -1220,16 +1220,18 @@ struct Handle {
   }
 
   // one block-hybrid Gauss-Seidel sweep on a square-block level (bgsb_sweep_kernel): ONE launch; xin == nullptr: from x = 0
-  void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b, bool lower_only = false) {
+  // blk0 / blk1: the sweep blocks [blk0, blk1) only (rank-partitioned levels: boundary blocks before, interior blocks beside the exchange)
+  void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b, bool lower_only = false, int blk0 = 0, int blk1 = -1) {
     Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
     const DevBGSB& g = L.bgsb;
-    if (g.n_blocks == 0) return;
+    if (blk1 < 0 || blk1 > g.n_blocks) blk1 = g.n_blocks;
+    if (blk1 <= blk0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
     const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double) + (size_t)g.BB * sizeof(int);
     (void)lower_only;
     // forward: colour phases over the couplings to lower colours, the upper ones stream with the sweep-start values; backward: reversed
     const BSellMat OFF = g.off.bsell.view(), IN = dir == 0 ? g.in.bsell.view() : g.upin.bsell.view(), OTH = dir == 0 ? g.upin.bsell.view() : g.in.bsell.view();
-#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(g.n_blocks), dim3(BLOCK), lds, stream, g.BB, 0, g.blk_ptr.p, g.blk_rows.p, OFF, g.off_ptr.p, IN, OTH, \
+#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(blk1 - blk0), dim3(BLOCK), lds, stream, g.BB, blk0, g.blk_ptr.p, g.blk_rows.p, OFF, g.off_ptr.p, IN, OTH, \
                                                g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, xin, xout)
     const bool fz = xin == nullptr;
     switch (L.bs) {
@@ -2114,7 +2116,9 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   DevBGSB& g = L.bgsb;
   const int BB = d.gs_block_rows;
   if (bs != 2 && bs != 3 && bs != 6) throw Err("block-hybrid Gauss-Seidel: block sizes 2, 3, 6");
-  if (d.A.n_cols != n) throw Err("block-hybrid Gauss-Seidel on block levels: square levels only");
+  if (d.A.n_cols < n) throw Err("block-hybrid Gauss-Seidel on block levels: n_cols < n_rows");
+  // (n_cols > n_rows: trailing ghost columns of a rank-partitioned level; they belong to no sweep block, so their couplings sit in
+  //  `off` / `rest` with global column ids and multiply whatever the caller's exchange left behind the owned entries)
   if (BB < RB || BB > 2048 || (int64_t)2 * BB * bs * 8 > 96 * 1024) throw Err("block-hybrid Gauss-Seidel: gs_block_rows out of range for this block size");
   if (n == 0) { g.BB = BB; return; }
   if (!d.color || d.n_colors <= 0) throw Err("block-hybrid Gauss-Seidel needs a blocked colouring");
@@ -2130,7 +2134,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
       const int64_t b0 = (i / BB) * BB, b1 = b0 + BB;
       for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
         const int64_t j = d.A.col[k];
-        if (j != i && j >= b0 && j < b1 && d.color[j] == ci) { bad[t] = 2; return; }
+        if (j != i && j >= b0 && j < b1 && j < n && d.color[j] == ci) { bad[t] = 2; return; }
       }
     }
   });
@@ -2162,7 +2166,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
         if (ci < 0) continue;
         for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
           const int64_t j = d.A.col[k];
-          if (j != i && blk_of[j] == blk_of[i] && d.color[j] == ci) { bad2[t] = 1; return; }
+          if (j != i && j < n && blk_of[j] == blk_of[i] && d.color[j] == ci) { bad2[t] = 1; return; }
         }
       }
     });
@@ -2177,7 +2181,7 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
     while (rows_off.size() % RB) rows_off.push_back(-1);
     off_ptr[blk + 1] = (int32_t)(rows_off.size() / RB);
   }
-  auto same_block = [&blk_of](int64_t i, int64_t j) { return blk_of[i] == blk_of[j]; };
+  auto same_block = [&blk_of, n](int64_t i, int64_t j) { return j < n && blk_of[i] == blk_of[j]; };
   // Only the in-block couplings to the colours a sweep has ALREADY visited need its new values; everything else -- couplings
   // that leave the block, the diagonal block, in-block couplings to the colours still to come -- multiplies sweep-start values
   // and goes into the streaming phase 0, where all waves work.  The colour phases, which run one after the other inside a

@@ -399,11 +399,12 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
         if (s.color[hd.send_idx[i]] >= g[2]) { D->stage[l] = {g[0], g[1], nc, nc}; break; }
     }
     D->send_early.push_back(1);
-    if (D->top->lev[l].gsb.on()) {
+    if (D->top->lev[l].gsb.on() || D->top->lev[l].bgsb.on()) {
       // block-hybrid form: the boundary blocks [n_int / B, end) are swept first, then x travels beside the interior blocks
       const amgx_halo_desc& hd = d->halo[l];
       const int64_t ns = hd.n_peers > 0 ? hd.send_ptr[hd.n_peers] : 0;
-      const int64_t B = D->top->lev[l].gsb.B;
+      if (D->top->lev[l].bgsb.on() && s.gs_block_ids) throw Err("amgx_dist_create: rank-partitioned block levels sweep runs of consecutive rows (no gs_block_ids)");
+      const int64_t B = D->top->lev[l].gsb.on() ? D->top->lev[l].gsb.B : D->top->lev[l].bgsb.BB;
       const int64_t first_bnd = (D->halo[l].n_int / B) * B;
       for (int64_t i = 0; i < ns; ++i)
         if (hd.send_idx[i] < first_bnd) { D->send_early[l] = 0; break; }
@@ -415,7 +416,7 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   }
   if (D->sm_type == AMGX_SM_GS) {
     int on = 0;
-    for (int l = 0; l < k; ++l) on += D->top->lev[l].gsb.on() ? 1 : 0;
+    for (int l = 0; l < k; ++l) on += (D->top->lev[l].gsb.on() || D->top->lev[l].bgsb.on()) ? 1 : 0;
     if (on != 0 && on != k) throw Err("amgx_dist_create: either all or none of the rank-partitioned Gauss-Seidel levels use gs_block_rows");
     D->gsb = on == k;
   }
@@ -586,27 +587,39 @@ struct DistCycle {
     const int k = M[0]->k;
     auto bl = [&](Dist* d, size_t i, int l) { return l == 0 ? b0[i] : (const double*)d->bext[l].p; };
     // (a level with a sent row inside an interior block sweeps all its blocks before the exchange: see Dist::send_early)
-    auto nbi = [&](Dist* d, int l) { return d->send_early[l] ? (int)(d->halo[l].n_int / d->top->lev[l].gsb.B) : 0; };
+    auto nbi = [&](Dist* d, int l) {
+      const DevLevel& L = d->top->lev[l];
+      return d->send_early[l] ? (int)(d->halo[l].n_int / (L.gsb.on() ? L.gsb.B : L.bgsb.BB)) : 0;
+    };
+    // scalar levels: gsb_sweep_kernel; square-block levels: bgsb_sweep_kernel (same block ranges, same stages)
+    auto sweep_zero = [&](Dist* d, int l, double* xout, const double* b, int q0, int q1) {
+      DevLevel& L = d->top->lev[l];
+      if (L.bgsb.on()) d->top->bgsb_sweep(L, 0, nullptr, xout, b, L.bgsb.has_split, q0, q1);
+      else d->top->gsb_sweep(L, 0, L.gsb.has_split ? L.gsb.lowin : L.gsb.full, nullptr, xout, b, q0, q1);
+    };
+    auto sweep_back = [&](Dist* d, int l, const double* xin, double* xout, const double* b, int q0, int q1) {
+      DevLevel& L = d->top->lev[l];
+      if (L.bgsb.on()) d->top->bgsb_sweep(L, 1, xin, xout, b, false, q0, q1);
+      else d->top->gsb_sweep(L, 1, L.gsb.full, xin, xout, b, q0, q1);
+    };
     for (int l = 0; l < k; ++l) {
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
-        DevLevel& L = d->top->lev[l];
-        const DevMatrix::Sell& cp = L.gsb.has_split ? L.gsb.lowin : L.gsb.full;
         d->top->zero(d->xext[l].p + d->n(l), d->next(l) - d->n(l));
-        d->top->gsb_sweep(L, 0, cp, nullptr, d->xext[l].p, bl(d, i, l), nbi(d, l), -1);
+        sweep_zero(d, l, d->xext[l].p, bl(d, i, l), nbi(d, l), -1);
       }
       const int tk = c.exchange_begin(items(l, 1));
-      for (size_t i = 0; i < M.size(); ++i) {
-        Dist* d = M[i];
-        DevLevel& L = d->top->lev[l];
-        d->top->gsb_sweep(L, 0, L.gsb.has_split ? L.gsb.lowin : L.gsb.full, nullptr, d->xext[l].p, bl(d, i, l), 0, nbi(d, l));
-      }
+      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep_zero(d, l, d->xext[l].p, bl(d, i, l), 0, nbi(d, l)); }
       c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
         DevLevel& L = d->top->lev[l];
-        if (L.gsb.has_split) d->top->gsb_residual_restrict(l, d->xext[l].p, d->rl[l].p, bnext(d, l));
-        else { d->top->residual(L.A, d->xext[l].p, bl(d, i, l), d->rl[l].p); d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l)); }
+        if (L.gsb.on() && L.gsb.has_split) d->top->gsb_residual_restrict(l, d->xext[l].p, d->rl[l].p, bnext(d, l));
+        else {
+          if (L.bgsb.on() && L.bgsb.has_split) d->top->mult(L.bgsb.rest, d->xext[l].p, d->rl[l].p);      // r = rest x (see DevBGSB)
+          else d->top->residual(L.A, d->xext[l].p, bl(d, i, l), d->rl[l].p);
+          d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l));
+        }
       }
     }
     gather_level_k();
@@ -618,17 +631,9 @@ struct DistCycle {
         d->top->mult_add(d->top->lev[l].P, 1.0, xc, d->xext[l].p, d->text[l].p);
       }
       const int tk = c.exchange_begin(items(l, 2));
-      for (size_t i = 0; i < M.size(); ++i) {
-        Dist* d = M[i];
-        DevLevel& L = d->top->lev[l];
-        d->top->gsb_sweep(L, 1, L.gsb.full, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), 0, nbi(d, l));
-      }
+      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep_back(d, l, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), 0, nbi(d, l)); }
       c.exchange_end(tk);
-      for (size_t i = 0; i < M.size(); ++i) {
-        Dist* d = M[i];
-        DevLevel& L = d->top->lev[l];
-        d->top->gsb_sweep(L, 1, L.gsb.full, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), nbi(d, l), -1);
-      }
+      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep_back(d, l, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), nbi(d, l), -1); }
     }
   }
 

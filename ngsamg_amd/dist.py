@@ -707,6 +707,9 @@ def _hybrid_gsb_data(comm, states, block_rows=None):
     columns (their diagonal entries come from the owners)"""
     from .device import gs_block_rows
     lib = _lib.host()
+    bs = _bs(states[0])
+    if bs > 1:
+        return _hybrid_bgsb_data(comm, states, block_rows)
     diags = [np.asarray(s.A[:, :s.n].diagonal()) for s in states]
     gdiag = _exchange_ghost_values(comm, states, diags)
     Bs = []
@@ -729,6 +732,49 @@ def _hybrid_gsb_data(comm, states, block_rows=None):
         _lib.hcheck(lib.amgh_hybrid_dinv_ext(C.byref(d), _lib.ptr(fr, C.c_uint8), B, _lib.ptr(gd, C.c_double) if gd.size else None, _lib.ptr(dinv, C.c_double)))
         s.color, s.n_colors, s.dinv_gs_ext, s.gs_B = color, int(nc.value), dinv, B
         # the same sweep for the serial oracle / CPU stage backend: visiting order (block, colour), blocks never see each other's updates
+        rows = np.nonzero(color >= 0)[0]
+        key = (rows // B).astype(np.int64) * (int(nc.value) + 1) + color[rows]
+        s.gs_order = rows[np.argsort(key, kind="stable")].astype(np.int32)
+        s.gs_blockid = (np.arange(s.n) // B).astype(np.int32)
+
+
+def _hybrid_bgsb_data(comm, states, block_rows=None):
+    """_hybrid_gsb_data for square-block levels (bgsb_sweep_kernel): sweep blocks of BB consecutive owned block rows, blocked
+    colouring of the block graph, block diagonal inverse divided by max(1, max_l 0.51 (1 + ad_k(l))) where ad_k(l) sums
+    |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)) over every coupling that leaves the sweep block -- to another block of the rank or to
+    a ghost column, whose diagonal entries come from the owner (hybrid_smoother_utils.hpp:55-68, 86-98, 128-141 with sweep
+    blocks in the role of the reference's ranks)"""
+    from .device import gs_block_rows
+    lib = _lib.host()
+    bs = _bs(states[0])
+    diags = [np.asarray(sp.csr_matrix(s.A)[:, :s.n * bs].diagonal()).reshape(s.n, bs) for s in states]
+    gdiag = _exchange_ghost_values(comm, states, diags)
+    mats = [_mat(s.A, bs) for s in states]
+    Bs = [int(block_rows) if block_rows else gs_block_rows(_mat(sp.csr_matrix(s.A)[:, :s.n * bs], bs)) for s in states]
+    votes = [x for lst in comm.allgather([b if s.n > 0 else -1 for b, s in zip(Bs, states)]) for x in lst if x >= 0]
+    B = min(votes) if votes else 0
+    rb = 64 // bs
+    B = (B // rb) * rb                                   # a whole number of BSELL slices
+    for s, M, d, gd in zip(states, mats, diags, gdiag):
+        if B <= 0:
+            raise NgsAMGError("hgs: a rank-partitioned block level cannot use the block-hybrid form (level too small); use sm_type = gs")
+        dsc = M.desc()
+        fr = np.ascontiguousarray(s.free, dtype=np.uint8)
+        color = np.full(s.n, -1, dtype=np.int32)
+        nc = C.c_int32()
+        _lib.hcheck(lib.amgh_coloring_blocked(C.byref(dsc), _lib.ptr(fr, C.c_uint8), B, _lib.ptr(color, C.c_int32), C.byref(nc)))
+        A = sp.coo_matrix(sp.csr_matrix(s.A))
+        dd = np.concatenate([d.reshape(-1), np.asarray(gd).reshape(-1)])
+        bi, bj = A.row // bs, A.col // bs
+        leaves = (bj >= s.n) | ((bj // B) != (bi // B))
+        dl, dm = dd[A.row], dd[A.col]
+        ok = leaves & (dl > 0) & (dm > 0)
+        ad = np.bincount(A.row[ok], weights=np.abs(A.data[ok]) / np.sqrt(dl[ok] * dm[ok]), minlength=s.n * bs)
+        fac = np.maximum(1.0, np.where(d.reshape(-1) > 0, 0.51 * (1.0 + ad), 0.0).reshape(s.n, bs).max(axis=1))
+        fac = np.where(s.free.astype(bool), fac, 1.0)
+        dinv = (s.dinv_ext[:s.n * bs * bs].reshape(s.n, bs * bs) / fac[:, None]).reshape(-1)
+        s.dinv_gs_ext = np.concatenate([dinv, np.zeros(s.ghost_owner.size * bs * bs)])
+        s.color, s.n_colors, s.gs_B = color, int(nc.value), B
         rows = np.nonzero(color >= 0)[0]
         key = (rows // B).astype(np.int64) * (int(nc.value) + 1) + color[rows]
         s.gs_order = rows[np.argsort(key, kind="stable")].astype(np.int32)
@@ -791,8 +837,10 @@ class DistributedAMG:
         # coarse block size dim + nrot); block levels run block-Jacobi in the literal stage order
         self.energy = int(opts.get("energy", 0))
         blocks = any(_bs(s) > 1 for s in states0) or self.energy == 1
-        if blocks and sm_type not in ("jacobi", "gs"):
-            raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi | gs")
+        if blocks and sm_type not in ("jacobi", "gs", "hgs"):
+            raise NgsAMGError("DistributedAMG: rank-partitioned block levels support sm_type = jacobi | gs | hgs")
+        if blocks and sm_type == "hgs" and backend is not None:
+            raise NgsAMGError("DistributedAMG: block-hybrid Gauss-Seidel on block levels runs through the device driver only (backend=None)")
         # fold: Jacobi post-smoothing folded into the prolongation (one product with Q on the way up, one halo exchange
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
         # (AMGX_NO_FOLD=1, the switch that makes the single-GPU handle run the literal kernel sequence, selects the literal
@@ -1134,7 +1182,7 @@ class DistributedAMG:
                 L.gs_order = np.concatenate(order).astype(np.int32)
                 L.gs_block = np.concatenate(block)
             if self.sm_type == "hgs":
-                pg = [(s.rank, s.dinv_gs_ext[:s.n], s.gs_order, s.gs_blockid) for s in lv]
+                pg = [(s.rank, s.dinv_gs_ext[:s.n * bf * bf], s.gs_order, s.gs_blockid) for s in lv]
                 gg = sorted(comm.allgather(pg)[0], key=lambda t: t[0])
                 L.dinv = np.concatenate([t[1] for t in gg])
                 order, block, boff = [], [], 0
@@ -1172,7 +1220,7 @@ class DistributedAMG:
             if getattr(L, "hgs_pre", None) is not None:
                 from copy import copy
                 L2 = copy(L)
-                L2.dinv = np.ascontiguousarray(L.hgs_dinv[:L.A.n_rows])
+                L2.dinv = np.ascontiguousarray(L.hgs_dinv[:L.A.n_rows * L.A.br * L.A.br])
                 tail.append(L2)
             else:
                 tail.append(L)

@@ -417,9 +417,46 @@ def test_loopback_device_elasticity_hybrid_gs(R, box, rot, stage_min):
     assert orc.pcg(np.concatenate(bh), tol=1e-8, maxit=60)[1] < 45
 
 
+@pytest.mark.parametrize("R,box,rot,B", [(2, (12, 9, 9), False, 42), (2, (12, 10, 10), True, 40), (4, (12, 12, 10), True, 20), (2, (16, 12, 12), False, None)])
+def test_loopback_device_elasticity_block_hybrid_gs(R, box, rot, B):
+    """sm_type = hgs on rank-partitioned ELASTICITY levels (3 x 3 / 6 x 6 blocks): bgsb_sweep_kernel over sweep blocks of B owned
+    block rows -- boundary blocks, exchange of x, interior blocks; one-pass pre-smoothing with the `rest` image over
+    [owned | ghost] columns; the block diagonal modified by every coupling that leaves a sweep block (other blocks of the rank and
+    ghost columns alike) -- == the oracle's serial hybrid GS with the same blocks, colours and diagonal"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_elasticity_owned(r, pg, box, rotations=rot) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=150, device=0, max_coarse_size=5, energy=1, regularize_cmats=0 if rot else 1,
+                           sm_type="hgs", **({"hgs_block_rows": B} if B else {}))
+    assert amg.k >= 1 and all(s.gs_B > 0 for s in amg.dist_levels[0])
+    bs0 = states[0].bs
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n * bs0) * np.repeat(s.free, bs0) for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n * bs0,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
+    ref = orc.apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+    assert orc.pcg(np.concatenate(bh), tol=1e-8, maxit=60)[1] < 45
+
+
 def test_rccl_world_size_one_elasticity_hybrid_gs():
     """the same through a real RCCL communicator (world size 1, child process)"""
     _run_check("--world", "1", "--box", "10", "--elast", "6", "--sm", "gs", "--dmin", "50")
+
+
+def test_rccl_world_size_one_elasticity_block_hybrid_gs():
+    """sm_type = hgs on 6 x 6 block levels through a real RCCL communicator (world size 1, child process; graph replay included)"""
+    _run_check("--world", "1", "--box", "14", "--elast", "6", "--sm", "hgs", "--dmin", "200")
 
 
 @pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (8, (12, 12, 12), 3, 100), (4, (48, 48), 2, 300),
