@@ -63,7 +63,7 @@ if [[ $PART == *c* ]]; then
   NGSAMG_FORCE_DIST=1 python bench.py --config cfg3 --steps 30 --warmup 5 > $OUT/bench_dist_world1_cfg3.json 2> /dev/null
   NGSAMG_FORCE_DIST=1 python bench.py --config cfg5 --smoother gs --steps 30 --warmup 5 > $OUT/bench_dist_world1_cfg5_gs.json 2> /dev/null; echo "bench dist" >> $OUT/progress.txt
   NGSAMG_FORCE_DIST=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_d1 -- python bench.py --nv 108 --steps 5 --warmup 3 --no-cpu-baseline > /dev/null 2> $OUT/trace_d1.log
-  f=$(find $OUT/trace_d1 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 > $OUT/trace_dist_world1_nv108.txt
+  f=$(find $OUT/trace_d1 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 60,1000 25 > $OUT/trace_dist_world1_nv108.txt
   rm -rf $OUT/trace_d1
 fi
 echo $COMMIT > $OUT/commit.txt
