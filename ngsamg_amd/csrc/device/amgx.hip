@@ -2110,7 +2110,8 @@ static void build_bsell_sel(const amgx_matrix& A, const std::vector<int32_t>& ro
 
 // Block-hybrid Gauss-Seidel data of a square-block level (bgsb_sweep_kernel); the blocked colouring is validated (two coupled
 // rows of one workgroup block sharing a colour would be a data race)
-static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
+// csr: the level matrix on the device (big levels): the images are then gathered there (devbuild.hpp, dev_build_bsell)
+static void build_bgsb(const amgx_level_desc& d, DevLevel& L, const DevBcsrSrc* csr = nullptr) {
   const int64_t n = d.A.n_rows;
   const int bs = d.A.br, RB = WAVE / bs;
   DevBGSB& g = L.bgsb;
@@ -2188,6 +2189,15 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   // workgroup, are left with ~9 % of A for line blocks (22 % for compact blocks) instead of 20 % (50 %).
   auto lower_in = [&](int32_t i, int32_t j) { return j != i && same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && d.color[j] < d.color[i]; };
   auto upper_in = [&](int32_t i, int32_t j) { return j != i && same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && d.color[j] > d.color[i]; };
+  DevBuf<int32_t> d_blk_of, d_lpos, d_color, d_rows;
+  DevBuf<double> d_fac;
+  DbBgsbMaps maps;
+  if (csr) {
+    d_blk_of.upload(blk_of); d_lpos.upload(lpos); d_color.upload(d.color, (size_t)n);
+    maps.blk_of = d_blk_of.p; maps.lpos = d_lpos.p; maps.color = d_color.p;
+    d_rows.upload(rows_off);
+    dev_build_bsell(*csr, d_rows.p, (int64_t)rows_off.size(), BB_OFF, maps, 0, 0.0, g.off);
+  } else
   build_bsell_sel(d.A, rows_off, [&](int32_t i, int32_t j) { return !lower_in(i, j) && !upper_in(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.off);
   // in: per block the swept rows by colour, every (block, colour) group padded to whole slices
   std::vector<int32_t> rows_in, in_ptr((size_t)nblk * nc + 1, 0), in_row;
@@ -2200,8 +2210,14 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   }
   in_row.resize(rows_in.size());
   for (size_t q = 0; q < rows_in.size(); ++q) in_row[q] = rows_in[q] < 0 ? -1 : lpos[rows_in[q]];
-  build_bsell_sel(d.A, rows_in, lower_in, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.in);
-  build_bsell_sel(d.A, rows_in, upper_in, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.upin);
+  if (csr) {
+    d_rows.upload(rows_in);
+    dev_build_bsell(*csr, d_rows.p, (int64_t)rows_in.size(), BB_IN, maps, 0, 0.0, g.in);
+    dev_build_bsell(*csr, d_rows.p, (int64_t)rows_in.size(), BB_UPIN, maps, 0, 0.0, g.upin);
+  } else {
+    build_bsell_sel(d.A, rows_in, lower_in, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.in);
+    build_bsell_sel(d.A, rows_in, upper_in, [&lpos](int32_t, int32_t j) { return lpos[j]; }, 0, g.upin);
+  }
   if (g.upin.n_slices != g.in.n_slices) throw Err("block-hybrid Gauss-Seidel: lower / upper slice mismatch");
   g.blk_ptr.upload(blk_ptr); g.blk_rows.upload(blk_rows);
   g.off_ptr.upload(off_ptr); g.in_ptr.upload(in_ptr); g.in_row.upload(in_row);
@@ -2233,6 +2249,12 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L) {
   std::vector<int32_t> rows_nat;
   for (int64_t i = 0; i < n; ++i) rows_nat.push_back((int32_t)i);
   while (rows_nat.size() % RB) rows_nat.push_back(-1);
+  if (csr) {
+    d_fac.upload(fac);
+    maps.fac = d_fac.p;
+    d_rows.upload(rows_nat);
+    dev_build_bsell(*csr, d_rows.p, (int64_t)rows_nat.size(), BB_REST, maps, 0, 0.0, g.rest);
+  } else
   build_bsell_sel(d.A, rows_nat, [&](int32_t i, int32_t j) { return !lower_in(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.rest,
                   [&](int32_t i, int32_t j) { return (i == j && d.color[i] >= 0) ? fac[i] - 1.0 : -1.0; });
   g.has_split = true;
@@ -2543,8 +2565,29 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       diagA = dev_diag_check(csrA, (s.dinv && s.A.n_rows <= s.A.n_cols) ? L.dinv.p : nullptr);
       clk.lap("CSR of A to the device", l);
     }
+    // big square-block levels: the block-CSR arrays go to the device once, the BSELL images (A; the block-hybrid Gauss-Seidel
+    // images) are gathered there
+    const bool keep_csr_A = s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0;
+    const bool dev_bsell = dev_bsell_wanted(s.A) && s.A.n_rows == s.A.n_cols && !keep_csr_A;
+    const bool verify_bsell = dev_bsell && std::getenv("AMGX_VERIFY_IMAGES") != nullptr;
+    DevBcsrSrc csrB;
+    if (dev_bsell) {
+      check_matrix(s.A, "A");
+      csrB.upload(s.A);
+      clk.lap("block CSR of A to the device", l);
+    }
     // block GS walks the CSR arrays of A, so keep A in CSR there
     tasks.run([&] {
+      if (dev_bsell) {
+        if (dev_build_bsell(csrB, nullptr, 0, BB_ALL, DbBgsbMaps(), 0, 1.30, L.A)) {
+          L.A.n_rows = s.A.n_rows; L.A.n_cols = s.A.n_cols; L.A.br = s.A.br; L.A.bc = s.A.bc;
+          L.A.nnz = s.A.rowptr[s.A.n_rows];
+          L.A.lanes = pick_lanes(L.A.n_rows ? (double)L.A.nnz / (double)L.A.n_rows : 0.0);
+          if (verify_bsell) { DevMatrix H; upload_matrix(s.A, H, "A", true, true, false); if (H.lanes != L.A.lanes || H.nnz != L.A.nnz) throw Err("AMGX_VERIFY_IMAGES: A: descriptors differ"); verify_same_bsell(L.A, H, "A"); }
+          return;
+        }
+        L.A = DevMatrix();
+      }
       if (dev_images && dev_upload_matrix(csrA, L.A, true, 1.35, 0, &diagA)) {
         if (verify_images) { DevMatrix H; upload_matrix(s.A, H, "A", true, true, false); verify_same_image(L.A, H, "A"); }
         return;
@@ -2576,7 +2619,20 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       }, "P, PT");
       tasks.run([&] {
         if (!dev_images) L.dinv.upload(s.dinv, (size_t)L.ncols * L.bs * L.bs);
-        if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) build_bgsb(s, L);
+        if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0 && s.A.br > 1) {
+          build_bgsb(s, L, dev_bsell ? &csrB : nullptr);
+          if (verify_bsell) {
+            DevLevel H;
+            H.n = L.n; H.ncols = L.ncols; H.bs = L.bs;
+            build_bgsb(s, H, nullptr);
+            const DevBGSB &x = L.bgsb, &y = H.bgsb;
+            if (x.BB != y.BB || x.n_blocks != y.n_blocks || x.n_colors != y.n_colors || x.has_split != y.has_split) throw Err("AMGX_VERIFY_IMAGES: block-hybrid Gauss-Seidel (blocks): the descriptors differ");
+            verify_same_bsell(x.off, y.off, "block-hybrid Gauss-Seidel: off");
+            verify_same_bsell(x.in, y.in, "block-hybrid Gauss-Seidel: in");
+            verify_same_bsell(x.upin, y.upin, "block-hybrid Gauss-Seidel: upin");
+            if (x.has_split) verify_same_bsell(x.rest, y.rest, "block-hybrid Gauss-Seidel: rest");
+          }
+        }
         else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) {
           build_gsb(s, L, &s.P, dev_images ? &csrA : nullptr);
           if (verify_images) {

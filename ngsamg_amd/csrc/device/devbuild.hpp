@@ -290,6 +290,90 @@ __global__ __launch_bounds__(BLOCK) void db_split_fill_kernel(DbSplit a, const i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// BSELL images of square-block matrices (build_bsell, build_bsell_sel) from the block-CSR arrays on the device.
+// sel: which entries of a block row an image keeps, the column it stores for them and a factor on the values --
+//   BB_ALL   every entry, global block column                                  (the level matrix A; padding column = the row itself)
+//   BB_OFF   everything but the in-block couplings to another colour            (block-hybrid Gauss-Seidel: streamed with sweep-start values)
+//   BB_IN    in-block couplings to LOWER colours, block-local column           (colour phases of a forward sweep)
+//   BB_UPIN  in-block couplings to HIGHER colours, block-local column
+//   BB_REST  everything but BB_IN, negated, diagonal blocks scaled by fac - 1  (r = rest x after the sweep from zero)
+enum : int { BB_ALL = 0, BB_OFF = 1, BB_IN = 2, BB_UPIN = 3, BB_REST = 4 };
+struct DbBsell {
+  int64_t m, n, ns;                     // list entries (padded to whole slices), block rows of the matrix, slices
+  int bs, sel;
+  const int32_t* rows;                  // block row of every list entry (-1: padding slot); null: natural order
+  const int64_t* rowptr; const int32_t* col; const double* val;
+  const int32_t* blk_of; const int32_t* lpos; const int32_t* color; const double* fac;
+  int64_t* sp;                          // [ns + 1] cumulative block steps
+  int32_t* ocol; double* oval;
+};
+__device__ __forceinline__ bool db_bsell_keep(const DbBsell& a, int64_t i, int64_t j) {
+  if (a.sel == BB_ALL) return true;
+  const bool same = j < a.n && j != i && a.blk_of[i] == a.blk_of[j] && a.color[i] >= 0 && a.color[j] >= 0;
+  const bool lower = same && a.color[j] < a.color[i], upper = same && a.color[j] > a.color[i];
+  switch (a.sel) {
+    case BB_OFF: return !lower && !upper;
+    case BB_IN: return lower;
+    case BB_UPIN: return upper;
+    default: return !lower;
+  }
+}
+// steps of every slice: the longest kept row among its RB = 64 / bs list entries (lane = list entry)
+__global__ __launch_bounds__(DB_BLOCK) void db_bsell_width_kernel(DbBsell a) {
+  const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (s >= a.ns) return;
+  const int RB = WAVE / a.bs;
+  int w = 0;
+  const int64_t q = s * RB + l;
+  if (l < RB && q < a.m) {
+    const int64_t i = a.rows ? (int64_t)a.rows[q] : (q < a.n ? q : -1);
+    if (i >= 0)
+      for (int64_t k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) if (db_bsell_keep(a, i, a.col[k])) ++w;
+  }
+  for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_xor(w, o));
+  if (l == 0) { a.sp[s + 1] = w; if (s == 0) a.sp[0] = 0; }
+}
+// one wave per slice, lane = (list entry rb, scalar row rr of its block row); ocol / oval hold the padding already
+__global__ __launch_bounds__(DB_BLOCK) void db_bsell_fill_kernel(DbBsell a) {
+  const int64_t s = (int64_t)blockIdx.x * (DB_BLOCK / WAVE) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (s >= a.ns) return;
+  const int bs = a.bs, RB = WAVE / bs;
+  const int rb = lane / bs, rr = lane % bs;
+  if (rb >= RB) return;
+  const int64_t q = s * RB + rb;
+  const int64_t i = q < a.m ? (a.rows ? (int64_t)a.rows[q] : (q < a.n ? q : -1)) : -1;
+  const int64_t k0 = a.sp[s];
+  const int w = (int)(a.sp[s + 1] - k0);
+  if (a.sel == BB_ALL && rr == 0) {       // build_bsell pads with a valid block column: the row itself (0 for padding slots)
+    const int32_t pc = (int32_t)min(max(i, (int64_t)0), a.n - 1);
+    int len = 0;
+    if (i >= 0) len = (int)(a.rowptr[i + 1] - a.rowptr[i]);
+    for (int k = len; k < w; ++k) a.ocol[(k0 + k) * RB + rb] = pc;
+  }
+  if (i < 0) return;
+  int64_t kk = k0;
+  for (int64_t k = a.rowptr[i]; k < a.rowptr[i + 1]; ++k) {
+    const int32_t j = a.col[k];
+    if (!db_bsell_keep(a, i, j)) continue;
+    if (rr == 0) a.ocol[kk * RB + rb] = (a.sel == BB_IN || a.sel == BB_UPIN) ? a.lpos[j] : j;
+    const double sc = a.sel == BB_REST ? ((i == j && a.color[i] >= 0) ? a.fac[i] - 1.0 : -1.0) : 1.0;
+    const double* __restrict__ blk = a.val + k * (bs * bs) + rr * bs;
+    double* __restrict__ vk = a.oval + kk * (bs * WAVE);
+    for (int c = 0; c < bs; ++c) {
+      if ((bs & 1) && c == bs - 1) vk[(bs / 2) * (2 * WAVE) + lane] = sc * blk[c];
+      else vk[(c / 2) * (2 * WAVE) + lane * 2 + (c & 1)] = sc * blk[c];
+    }
+    ++kk;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void db_fill_i32_kernel(int64_t n, int32_t v, int32_t* __restrict__ p) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host side
 
 static bool dev_images_wanted(const amgx_matrix& A) {
@@ -441,13 +525,96 @@ static bool dev_fold_prolongation(const DevCsrSrc& A, const DevCsrSrc& P, const 
   return true;
 }
 
-// AMGX_VERIFY_IMAGES: every array of two SELL images bit by bit (the 16-bit columns only where a slice uses them)
 template <class T>
 static std::vector<T> db_download(const DevBuf<T>& b, size_t count) {
   std::vector<T> h(count);
   if (count) HIPCHK(hipMemcpy(h.data(), b.p, count * sizeof(T), hipMemcpyDeviceToHost));
   return h;
 }
+
+// ---- block matrices ---------------------------------------------------------------------------------
+struct DevBcsrSrc {                      // a square-block CSR matrix on the device
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int bs = 1;
+  DevBuf<int64_t> rowptr;
+  DevBuf<int32_t> col;
+  DevBuf<double> val;
+  void upload(const amgx_matrix& A) {
+    n_rows = A.n_rows; n_cols = A.n_cols; bs = A.br; nnz = A.rowptr[A.n_rows];
+    rowptr.upload(A.rowptr, (size_t)A.n_rows + 1);
+    col.upload(A.col, (size_t)std::max<int64_t>(1, nnz));
+    val.upload(A.val, (size_t)std::max<int64_t>(1, nnz) * bs * bs);
+  }
+};
+struct DbBgsbMaps { const int32_t* blk_of = nullptr; const int32_t* lpos = nullptr; const int32_t* color = nullptr; const double* fac = nullptr; };
+
+static bool dev_bsell_wanted(const amgx_matrix& A) {
+  if (std::getenv("AMGX_HOST_IMAGES") || std::getenv("AMGX_NO_BSELL")) return false;
+  if (A.br != A.bc || (A.br != 2 && A.br != 3 && A.br != 6) || A.n_rows <= 0) return false;
+  const int64_t nnz = A.rowptr[A.n_rows];
+  if (nnz <= 0 || nnz >= (int64_t)2147483647) return false;
+  int64_t min_rows = 65536;
+  if (const char* e = std::getenv("AMGX_DEV_IMAGES_MIN_ROWS")) min_rows = std::atoll(e);
+  return A.n_rows * A.br >= min_rows;
+}
+
+// build_bsell / build_bsell_sel on the device.  d_rows [m]: list of block rows, m a multiple of 64 / bs (null: natural order, all
+// rows).  max_pad > 0: decline (false, D untouched) if the stored block steps exceed max_pad * entries (build_bsell's contract).
+static bool dev_build_bsell(const DevBcsrSrc& A, const int32_t* d_rows, int64_t m, int sel, const DbBgsbMaps& mp, int32_t padcol, double max_pad, DevMatrix& D) {
+  const int bs = A.bs, RB = WAVE / bs;
+  if (!d_rows) m = A.n_rows;
+  else if (m % RB) throw Err("dev_build_bsell: the row list must be padded to whole slices");
+  const int64_t ns = (m + RB - 1) / RB;
+  DevBuf<int64_t> sp;
+  sp.alloc((size_t)ns + 1);
+  DbBsell a{m, A.n_rows, ns, bs, sel, d_rows, A.rowptr.p, A.col.p, A.val.p, mp.blk_of, mp.lpos, mp.color, mp.fac, sp.p, nullptr, nullptr};
+  if (ns == 0) HIPCHK(hipMemset(sp.p, 0, sizeof(int64_t)));
+  else {
+    hipLaunchKernelGGL(db_bsell_width_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, a);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, 0, ns, sp.p);
+    HIPCHK(hipGetLastError());
+  }
+  int64_t steps = 0;
+  HIPCHK(hipMemcpy(&steps, sp.p + ns, sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (max_pad > 0.0 && (A.nnz == 0 || (double)steps * RB > max_pad * (double)A.nnz)) return false;
+  DevBuf<int32_t> col;
+  DevBuf<double> val;
+  const size_t ncol = (size_t)std::max<int64_t>(1, steps * RB), nval = (size_t)std::max<int64_t>(1, steps * bs * WAVE);
+  col.alloc(ncol); val.alloc(nval);
+  hipLaunchKernelGGL(db_fill_i32_kernel, dim3((unsigned)((ncol + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, (int64_t)ncol, padcol, col.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemset(val.p, 0, nval * sizeof(double)));
+  if (ns > 0) {
+    a.ocol = col.p; a.oval = val.p;
+    hipLaunchKernelGGL(db_bsell_fill_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, a);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipDeviceSynchronize());
+  D.fmt = FMT_BSELL; D.br = D.bc = bs;
+  D.n_rows = A.n_rows; D.n_cols = A.n_cols;
+  D.n_slices = (int)ns;
+  D.stored = steps * RB;
+  D.stream_bytes = steps * ((int64_t)bs * WAVE * 8 + RB * 4) + 8 * (ns + 1);
+  D.bsell.slice_ptr = std::move(sp); D.bsell.col = std::move(col); D.bsell.val = std::move(val);
+  return true;
+}
+
+static void verify_same_bsell(const DevMatrix& a, const DevMatrix& b, const char* what) {
+  auto fail = [&](const char* part) { throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built BSELL images differ in " + part); };
+  if (a.fmt != b.fmt || a.n_rows != b.n_rows || a.n_cols != b.n_cols || a.br != b.br || a.n_slices != b.n_slices || a.stored != b.stored ||
+      a.stream_bytes != b.stream_bytes) fail("the descriptor");
+  if (a.fmt != FMT_BSELL) return;
+  const size_t ns = (size_t)a.n_slices;
+  const auto sx = db_download(a.bsell.slice_ptr, ns + 1), sy = db_download(b.bsell.slice_ptr, ns + 1);
+  if (sx != sy) fail("slice_ptr");
+  const size_t steps = (size_t)sx[ns], RB = (size_t)(WAVE / a.br);
+  if (db_download(a.bsell.col, steps * RB) != db_download(b.bsell.col, steps * RB)) fail("col");
+  const auto vx = db_download(a.bsell.val, steps * a.br * WAVE), vy = db_download(b.bsell.val, steps * a.br * WAVE);
+  if (std::memcmp(vx.data(), vy.data(), vx.size() * sizeof(double)) != 0) fail("val");
+}
+
+// AMGX_VERIFY_IMAGES: every array of two SELL images bit by bit (the 16-bit columns only where a slice uses them)
 static void verify_same_sell(const DevMatrix::Sell& x, const DevMatrix::Sell& y, size_t ns, int64_t n_rows, const char* what) {
   auto fail = [&](const char* part) { throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": device-built and host-built images differ in " + part); };
   if (x.rowrel != y.rowrel || x.diag_first != y.diag_first || x.wdiag != y.wdiag || x.win != y.win) fail("the flags");

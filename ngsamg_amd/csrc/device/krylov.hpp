@@ -50,6 +50,37 @@ __global__ __launch_bounds__(BLOCK) void kr_dot_final_kernel(int nb, const doubl
   for (int o = BLOCK >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
+// dot product in ONE launch (the CG recurrences: 7 -> 5 launches per iteration next to the cycle): every workgroup leaves its
+// partial sum, takes a ticket, and the workgroup that draws the last one adds the partials exactly as kr_dot_final_kernel does
+// (same order, same tree: the same bits) and re-arms the ticket counter
+__global__ __launch_bounds__(BLOCK) void kr_dot_kernel(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ partial, unsigned int* __restrict__ ticket, double* __restrict__ out) {
+  __shared__ double red[BLOCK];
+  __shared__ bool last;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) acc += a[i] * b[i];
+#pragma unroll
+  for (int o = WAVE >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < BLOCK / WAVE; ++w) s += red[w];
+    __hip_atomic_store(partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int nb = (int)gridDim.x;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nb; i += BLOCK) t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int o = BLOCK >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) { out[0] = red[0]; *ticket = 0u; }
+}
 // CG update with alpha = sc[num] / sc[den] read on the device: x += alpha s, d -= alpha q
 __global__ __launch_bounds__(BLOCK) void kr_cg_update_kernel(int64_t n, const double* __restrict__ sc, int num, int den,
                                                              const double* __restrict__ s, const double* __restrict__ q,
@@ -86,16 +117,18 @@ struct Krylov {
   Handle& h;
   int64_t n;
   DevBuf<double> partial, sc;              // partial sums; device scalars
+  DevBuf<unsigned int> ticket;             // kr_dot_kernel's arrival counter (0 between launches)
   explicit Krylov(Handle& hh) : h(hh), n(hh.lev[0].len()) {
     if (hh.lev[0].n != hh.lev[0].ncols) throw Err("Krylov solvers need a square level-0 matrix (single rank)");
     partial.alloc((size_t)KR_BLOCKS * 64);
     sc.alloc(64);
+    ticket.alloc(1);
     HIPCHK(hipMemsetAsync(sc.p, 0, 64 * sizeof(double), h.stream));
+    HIPCHK(hipMemsetAsync(ticket.p, 0, sizeof(unsigned int), h.stream));
   }
   int nb() const { return (int)std::max<int64_t>(1, std::min<int64_t>(KR_BLOCKS, (n + BLOCK - 1) / BLOCK)); }
   void dot(const double* a, const double* b, int slot) {
-    hipLaunchKernelGGL(kr_dot_partial_kernel, dim3(nb()), dim3(BLOCK), 0, h.stream, n, a, b, partial.p);
-    hipLaunchKernelGGL(kr_dot_final_kernel, dim3(1), dim3(BLOCK), 0, h.stream, nb(), partial.p, sc.p + slot);
+    hipLaunchKernelGGL(kr_dot_kernel, dim3(nb()), dim3(BLOCK), 0, h.stream, n, a, b, partial.p, ticket.p, sc.p + slot);
     HIPCHK(hipGetLastError());
   }
   void multi_dot(int m, const double* V, const double* w, int slot0) {

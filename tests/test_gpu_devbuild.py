@@ -8,7 +8,7 @@ from contextlib import contextmanager
 import numpy as np
 import pytest
 
-from tests.problems import poisson_case, rhs
+from tests.problems import poisson_case, elasticity_case, rhs
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ def _apply(H, p, sm, **e):
     with env(**e):
         d = DeviceAMGMatrix(H, device=0, sm_type=sm)
     b = rhs(p, 3)
-    x = np.full(p.n, np.nan)
+    x = np.full(b.size, np.nan)
     d.Mult(b, x)
     return x, d
 
@@ -71,4 +71,28 @@ def test_device_built_images_million_rows_default_settings(sm):
     assert np.array_equal(xv, xh)
     assert _formats(dv) == _formats(dh)
     fi = _formats(dv)
-    assert fi[0]["A"]["fmt"] == "sell" and fi[0]["Apre"]["fmt"] == "sell" and fi[0]["Q"]["fmt"] == "sellwin"
+    assert fi[0]["A"]["fmt"] == "sell"
+    if sm == "jacobi":
+        assert fi[0]["Apre"]["fmt"] == "sell" and fi[0]["Q"]["fmt"] == "sellwin"
+
+
+@pytest.mark.parametrize("shape,rot", [((9, 8, 7), False), ((10, 9, 8), True), ((24, 23), False), ((33, 18, 18), True)])
+@pytest.mark.parametrize("sm", ["jacobi", "hgs"])
+def test_device_built_block_images_equal_host_built_images(shape, rot, sm):
+    """square-block levels (2 x 2 ... 6 x 6): the BSELL image of A and the four images of the block-hybrid Gauss-Seidel smoother
+    (off / lower-in / upper-in / rest) gathered on the device from one block-CSR upload"""
+    p, H = elasticity_case(shape, rotations=rot, max_coarse_size=10)
+    xv, dv = _apply(H, p, sm, AMGX_VERIFY_IMAGES=1, AMGX_DEV_IMAGES_MIN_ROWS=0)
+    xh, dh = _apply(H, p, sm, AMGX_HOST_IMAGES=1)
+    xd, dd = _apply(H, p, sm, AMGX_DEV_IMAGES_MIN_ROWS=0)
+    assert np.array_equal(xd, xh) and np.array_equal(xv, xh)
+    assert [dd.matrix_info(l, "A") for l in range(dd.GetNLevels() - 1)] == [dh.matrix_info(l, "A") for l in range(dh.GetNLevels() - 1)]
+
+
+def test_device_built_block_images_default_settings():
+    """the path as cfg 3 / cfg 5 take it (no hooks): 30^3 nodes with rotations = 162 k scalar rows"""
+    p, H = elasticity_case((30, 30, 30), rotations=True, max_coarse_size=20)
+    xv, dv = _apply(H, p, "hgs", AMGX_VERIFY_IMAGES=1)
+    xh, dh = _apply(H, p, "hgs", AMGX_HOST_IMAGES=1)
+    assert np.array_equal(xv, xh)
+    assert dv.matrix_info(0, "A") == dh.matrix_info(0, "A") and dv.matrix_info(0, "A")["fmt"] == "bsell"
