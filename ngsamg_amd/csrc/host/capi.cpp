@@ -187,8 +187,7 @@ int amgh_hybrid_dinv_block(const amgh_matrix* A, const uint8_t* free_or_null, in
     check_matrix(A);
     if (A->br != A->bc || A->n_rows != A->n_cols) throw amgh::Error("amgh_hybrid_dinv_block: square matrix with square blocks expected");
     if (block_rows < 1 || !dinv_out) throw amgh::Error("amgh_hybrid_dinv_block: bad arguments");
-    amgh::BCSR M = to_bcsr(A);
-    amgh::hybrid_mod_dinv_block(M, free_or_null, block_rows, pinv != 0, dinv_out);
+    amgh::hybrid_mod_dinv_block(as_view(A), free_or_null, block_rows, pinv != 0, dinv_out);
   });
 }
 
@@ -217,8 +216,7 @@ int amgh_hybrid_dinv_block_ids(const amgh_matrix* A, const uint8_t* free_or_null
   return guard([&] {
     check_matrix(A);
     if (A->br != A->bc || A->n_rows != A->n_cols || !block_of_row || !dinv_out) throw amgh::Error("amgh_hybrid_dinv_block_ids: bad arguments");
-    amgh::BCSR M = to_bcsr(A);
-    amgh::hybrid_mod_dinv_block(M, free_or_null, 1, pinv != 0, dinv_out, block_of_row);
+    amgh::hybrid_mod_dinv_block(as_view(A), free_or_null, 1, pinv != 0, dinv_out, block_of_row);
   });
 }
 

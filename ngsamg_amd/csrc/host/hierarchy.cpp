@@ -500,7 +500,8 @@ BCSR block_prolongation(const BCSR& W, int bs_f, int bs_c, int dim, int energy,
 
 }  // namespace
 
-void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv) {
+template <class Mat>
+static void calc_dinv_t(const Mat& A, const uint8_t* free, bool pinv, double* dinv) {
   const int bs = A.br, bb = bs * bs;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < A.n_rows; i++) {
@@ -516,6 +517,8 @@ void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv) {
     else if (!dense_inverse(d, bs)) pseudo_inverse_try_normal(d, bs);
   }
 }
+
+void calc_dinv(const BCSR& A, const uint8_t* free, bool pinv, double* dinv) { calc_dinv_t(A, free, pinv, dinv); }
 
 int greedy_coloring(const BCSR& A, const uint8_t* free, int32_t* color) {
   const int64_t n = A.n_rows;
@@ -610,14 +613,15 @@ void hybrid_mod_dinv(const CsrView& A, const uint8_t* free, int64_t block_rows, 
 // the same for square-block matrices (reference hybrid_smoother_utils.hpp:55-68, 86-98, 128-141): per block row k and scalar
 // row l, ad_k(l) = sum over the couplings that leave the block of rows of sum_m |a_kj(l, m)| / sqrt(d_k(l, l) d_j(m, m)); the
 // block diagonal is scaled by max(1, max_l 0.51 (1 + ad_k(l))), i.e. dinv_k = (pseudo-)inverse(A_kk) / that factor
-void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row) {
+template <class Mat>
+static void hybrid_mod_dinv_block_t(const Mat& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row) {
   const int64_t n = A.n_rows;
   const int bs = A.br, bb = bs * bs;
   std::vector<double> d((size_t)n * bs, 0.0);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++)
     for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { for (int r = 0; r < bs; r++) d[i * bs + r] = A.val[k * bb + r * bs + r]; break; }
-  calc_dinv(A, free, pinv, dinv);
+  calc_dinv_t(A, free, pinv, dinv);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
     if (free && !free[i]) continue;
@@ -640,6 +644,13 @@ void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_row
     }
     if (fac != 1.0) for (int q = 0; q < bb; q++) dinv[i * bb + q] /= fac;
   }
+}
+
+void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row) {
+  hybrid_mod_dinv_block_t(A, free, block_rows, pinv, dinv, block_of_row);
+}
+void hybrid_mod_dinv_block(const CsrView& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row) {
+  hybrid_mod_dinv_block_t(A, free, block_rows, pinv, dinv, block_of_row);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

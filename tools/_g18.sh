@@ -1,5 +1,8 @@
-O=gpurun_out/r03q; mkdir -p $O
+O=gpurun_out/r03v; mkdir -p $O
 export NGSAMG_NO_BUILD=1
-NGSAMG_SETUP_LOG=1 AMGX_SETUP_LOG=1 timeout -k 10 300 python bench.py --steps 50 --warmup 5 --smoother gs --no-cpu-baseline > $O/cfg2_gs.json 2> $O/cfg2_gs.log
-timeout -k 10 400 python -m pytest tests/test_gpu_devbuild.py -x -q 2>&1 | tail -3
-grep -o '"value": [0-9.]*' $O/cfg2_gs.json
+AMGX_SETUP_LOG=1 timeout -k 10 500 python bench.py --config cfg5 --smoother gs --steps 30 --warmup 5 --no-cpu-baseline --no-reference-defaults > $O/cfg5_gs.json 2> $O/cfg5_gs.log
+AMGX_SETUP_LOG=1 timeout -k 10 300 python bench.py --config cfg3 --smoother gs --steps 30 --warmup 5 --no-cpu-baseline --no-reference-defaults > $O/cfg3_gs.json 2> $O/cfg3_gs.log
+AMGX_SETUP_LOG=1 timeout -k 10 300 python bench.py --config cfg3 --steps 30 --warmup 5 --no-cpu-baseline --no-reference-defaults > $O/cfg3_j.json 2> $O/cfg3_j.log
+timeout -k 10 300 python bench.py --steps 100 --warmup 10 --cpu-seconds 5 --no-reference-defaults > $O/cfg2_j.json 2> $O/cfg2_j.log
+grep -o '"value": [0-9.]*' $O/*.json
+grep "\[bench\] assembly" $O/*.log
