@@ -96,3 +96,31 @@ def test_device_built_block_images_default_settings():
     xh, dh = _apply(H, p, "hgs", AMGX_HOST_IMAGES=1)
     assert np.array_equal(xv, xh)
     assert dv.matrix_info(0, "A") == dh.matrix_info(0, "A") and dv.matrix_info(0, "A")["fmt"] == "bsell"
+
+
+@pytest.mark.parametrize("sm", ["jacobi", "hgs"])
+def test_device_built_images_on_rank_partitioned_levels(sm):
+    """levels with ghost columns (n_cols > n_rows: two virtual ranks): the device builders must reproduce the host images there too
+    (rest / off images carry [owned | ghost] column ids), and the collective cycle must equal the oracle"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    R = 2
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_poisson_owned(r, pg, (18, 16, 16)) for r in range(R)]
+    with env(AMGX_VERIFY_IMAGES=1, **SMALL):
+        amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=200, device=0, max_coarse_size=10, sm_type=sm,
+                               **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
