@@ -190,7 +190,8 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
                                       f"coarse hierarchy replicated from n = {amg.tail_hier.levels[0].n}; "
                                       + ("value = steps / time = applications of the GLOBAL preconditioner per second" if strong else
                                          "value = ranks x steps / time (one unit = one V-cycle over one rank's share); global_applies_per_s = steps / time"),
-                       "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(ndof_glob.item()), "dist_min_rows": int(dmin)},
+                       "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(ndof_glob.item()), "dist_min_rows": int(dmin),
+                       "whole_cycle_graph": amg._dev.graph_info()},
             "x_norm": float(xn.item()) ** 0.5,
             "device_memory": {"per_rank_bytes": hier_bytes},
             "roofline": {"bound": "hbm", "kernel": k_name,

@@ -58,6 +58,12 @@ typedef struct amgh_options {
                              /*   carried through the rounds, orphan round.  0: the target-driven pairwise rounds of earlier builds       */
   int32_t spw_rounds;        /* ngs_amg_spw_rounds           (3, spw_agg.hpp:28)                                                        */
   int32_t spw_orphan_round;  /* ngs_amg_spw_orphan_treatment (1, spw_agg.hpp:32)                                                        */
+  int32_t prol_type;         /* ngs_amg_prol_type (vertex_factory_impl.hpp:63-69, 849-853): 0 piecewise, 1 aux_smoothed, 2 semi_aux_smoothed   */
+                             /*   (the reference's default: rows whose algebraic neighbours map to <= sp_max_per_row_classic coarse vertices   */
+                             /*   are smoothed with the level matrix, the others with the replacement matrix of the edge weights,             */
+                             /*   vertex_factory_impl.hpp:1836-2290); 3: the weight rule of rounds 1-2 of this build.  Scalar levels; block     */
+                             /*   levels keep rule 3.  Default: 2 with spw = 1, 3 with spw = 0                                                 */
+  int32_t sp_max_per_row_classic;  /* ngs_amg_sp_max_per_row_classic (5, vertex_factory_impl.hpp:71)                                        */
 } amgh_options;
 
 typedef struct amgh_level {

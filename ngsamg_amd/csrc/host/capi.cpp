@@ -89,6 +89,8 @@ void amgh_default_options(amgh_options* o, int dim, int energy) {
   o->spw = d.spw;
   o->spw_rounds = d.spw_rounds;
   o->spw_orphan_round = d.spw_orphan_round;
+  o->prol_type = d.prol_type;
+  o->sp_max_per_row_classic = d.sp_max_per_row_classic;
 }
 
 int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
@@ -104,6 +106,8 @@ int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* 
     o.soc_thresh = opts->soc_thresh; o.max_rounds = opts->max_rounds; o.regularize_cmats = opts->regularize_cmats;
     o.dim = opts->dim; o.energy = opts->energy; o.log_level = opts->log_level; o.enable_multistep = opts->enable_multistep; o.robust_soc = opts->robust_soc;
     o.spw = opts->spw; o.spw_rounds = opts->spw_rounds; o.spw_orphan_round = opts->spw_orphan_round;
+    o.prol_type = opts->prol_type; o.sp_max_per_row_classic = opts->sp_max_per_row_classic;
+    if (o.prol_type < -1 || o.prol_type > 3) throw amgh::Error("amgh_setup: prol_type must be -1 (default), 0, 1, 2 or 3");
     if (o.max_levels < 1) throw amgh::Error("amgh_setup: max_levels must be >= 1");
     if (o.dim != 2 && o.dim != 3) throw amgh::Error("amgh_setup: dim must be 2 or 3");
     amgh::BCSR A0 = to_bcsr(A);

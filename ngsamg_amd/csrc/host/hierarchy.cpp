@@ -461,6 +461,116 @@ BCSR prolongation_weights(const Graph& G0, const std::vector<int32_t>& agg, int6
   return W;
 }
 
+// Smoothed prolongation of the reference for scalar levels (VertexAMGFactory::SemiAuxSProlMap, vertex_factory_impl.hpp:1836-2290,
+// and its aux-only form): per fine vertex i in aggregate I
+//   * no edge neighbour in I: the piecewise row (1 at I);
+//   * "classic" (semi_aux only, :1919-1950, :2060-2135): if every algebraic neighbour of row i of the level matrix is in an
+//     aggregate and they cover at most sp_max_per_row_classic aggregates, the row of (I - omega D^-1 A) P_pw;
+//   * else "aux" (:1952-2017, :2137-2262): columns = I plus the aggregates of the edge neighbours in order of decreasing summed
+//     edge weight while weight > sp_min_frac * (0.2 in-weight + weights so far) and >= sp_min_frac * (largest edge weight at i),
+//     at most sp_max_per_row; values = the row of (I - omega Dr^-1 R) P_pw with the replacement matrix R of the edges to the
+//     used neighbours (R_ij = -w_ij, R_ii = their sum).
+// The reference sorts the candidate columns with an unstable sort; ties are broken here by first appearance.
+BCSR prolongation_weights_ref(const BCSR* A, const Graph& G, const std::vector<int32_t>& agg, int64_t nc, const Options& o) {
+  const int64_t n = G.n;
+  const int maxr = std::max(1, o.sp_max_per_row), maxc = std::max(1, o.sp_max_per_row_classic), cap = std::max(maxr, maxc);
+  const double minf = o.sp_min_frac, omega = o.sp_omega;
+  BCSR W;
+  W.n_rows = n; W.n_cols = nc; W.br = W.bc = 1;
+  std::vector<int32_t> cols((size_t)n * cap);
+  std::vector<double> vals((size_t)n * cap);
+  std::vector<int32_t> len(n, 0);
+#pragma omp parallel
+  {
+    std::vector<std::pair<int32_t, double>> trow;
+    std::vector<int32_t> cc;
+    std::vector<double> vv;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+      const int32_t I = agg[i];
+      if (I < 0) continue;
+      int32_t* oc = &cols[(size_t)i * cap];
+      double* ov = &vals[(size_t)i * cap];
+      int nniscv = 0;
+      for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) if (agg[G.adj[k]] == I) nniscv++;
+      if (nniscv == 0 || !o.enable_sp) { oc[0] = I; ov[0] = 1.0; len[i] = 1; continue; }
+      cc.clear();
+      bool classic = false;
+      if (A) {
+        classic = true;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+          const int32_t cj = agg[A->col[k]];
+          if (cj < 0) { classic = false; break; }
+          auto it = std::lower_bound(cc.begin(), cc.end(), cj);
+          if (it == cc.end() || *it != cj) cc.insert(it, cj);
+        }
+        classic = classic && (int)cc.size() <= maxc;
+      }
+      if (classic) {
+        if (cc.size() == 1) { oc[0] = cc[0]; ov[0] = 1.0; len[i] = 1; continue; }
+        vv.assign(cc.size(), 0.0);
+        double aii = 0.0;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) if (A->col[k] == i) { aii = A->val[k]; break; }
+        const double d = 1.0 / aii;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+          const int32_t j = A->col[k];
+          const size_t ci = std::lower_bound(cc.begin(), cc.end(), agg[j]) - cc.begin();
+          if (j == i) vv[ci] += 1.0;
+          vv[ci] -= omega * d * A->val[k];
+        }
+      } else {
+        trow.clear();
+        double in_wt = 0.0, dgwt = 0.0;
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          dgwt = std::max(dgwt, G.w[k]);
+          const int32_t J = agg[G.adj[k]];
+          if (J < 0) continue;
+          if (J == I) { in_wt += G.w[k]; continue; }
+          bool found = false;
+          for (auto& t : trow) if (t.first == J) { t.second += G.w[k]; found = true; break; }
+          if (!found) trow.push_back({J, G.w[k]});
+        }
+        std::stable_sort(trow.begin(), trow.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+        double cw_sum = 0.2 * in_wt;
+        cc.assign(1, I);
+        const size_t max_adds = std::min<size_t>((size_t)(maxr - 1), trow.size());
+        for (size_t j = 0; j < max_adds; j++) {
+          cw_sum += trow[j].second;
+          if (!(trow[j].second > minf * cw_sum) || trow[j].second < minf * dgwt) break;
+          cc.push_back(trow[j].first);
+        }
+        std::sort(cc.begin(), cc.end());
+        if (cc.size() == 1) { oc[0] = I; ov[0] = 1.0; len[i] = 1; continue; }
+        vv.assign(cc.size(), 0.0);
+        double rii = 0.0;
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          const int32_t J = agg[G.adj[k]];
+          if (J >= 0 && std::binary_search(cc.begin(), cc.end(), J)) rii += G.w[k];
+        }
+        const double d = 1.0 / rii;
+        const size_t cI = std::lower_bound(cc.begin(), cc.end(), I) - cc.begin();
+        vv[cI] += 1.0;
+        vv[cI] -= omega * d * rii;
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          const int32_t J = agg[G.adj[k]];
+          if (J < 0 || !std::binary_search(cc.begin(), cc.end(), J)) continue;
+          vv[std::lower_bound(cc.begin(), cc.end(), J) - cc.begin()] -= omega * d * (-G.w[k]);
+        }
+      }
+      for (size_t q = 0; q < cc.size(); q++) { oc[q] = cc[q]; ov[q] = vv[q]; }
+      len[i] = (int32_t)cc.size();
+    }
+  }
+  W.rowptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; i++) W.rowptr[i + 1] = W.rowptr[i] + len[i];
+  W.col.resize(W.rowptr[n]);
+  W.val.resize(W.rowptr[n]);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int q = 0; q < len[i]; q++) { W.col[W.rowptr[i] + q] = cols[(size_t)i * cap + q]; W.val[W.rowptr[i] + q] = vals[(size_t)i * cap + q]; }
+  return W;
+}
+
 // block prolongation from scalar weights
 BCSR block_prolongation(const BCSR& W, int bs_f, int bs_c, int dim, int energy,
                         const std::vector<double>& xf, const std::vector<double>& xc) {
@@ -815,7 +925,13 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         // smoother and buys nothing (the coarsest-level inverse takes over)
         if (o.robust_soc && lev > 0 && (double)snc > 0.8 * (double)cur_free_n) { failed = substeps == 0; break; }
         rounds += r;
-        BCSR W = prolongation_weights(G, sagg, snc, o);
+        // prolongation rule (amgh.h: prol_type): the reference's smoothed prolongations exist for scalar levels; block levels and
+        // spw = 0 hierarchies keep the weight rule of the earlier rounds
+        const int ptype = o.prol_type >= 0 ? o.prol_type : (o.spw ? 2 : 3);
+        Options op = o;
+        if (ptype == 0) op.enable_sp = 0;
+        BCSR W = (curA->br == 1 && ptype != 3) ? prolongation_weights_ref(ptype == 2 ? curA : nullptr, G, sagg, snc, op)
+                                               : prolongation_weights(G, sagg, snc, op);
         lap("prolongation weights");
         const int sbf = curA->br;
         std::vector<double> sxc;

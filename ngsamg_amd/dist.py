@@ -535,6 +535,11 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         kw["first_aaf"] = o.get("first_aaf", dflt) if first else o.get("aaf", 2.0 ** -dim)
         kw["max_levels"] = 2
         kw["max_coarse_size"] = 1
+        # prolongation rule: the reference smooths vertices shared between ranks with the replacement matrix only
+        # (get_cols_classic: "if (eqc != 0) return false", vertex_factory_impl.hpp:1920); the rank-local setup sees the owned x owned
+        # block of A, whose rows at the interface are incomplete, so every row takes that branch here (aux_smoothed)
+        if "prol_type" not in kw:
+            kw["prol_type"] = 1 if int(kw.get("spw", 1)) else 3
         H = Hierarchy(_mat(A_oo, bf), s.free, s.coords, dim=dim, energy=energy, **{k: v for k, v in kw.items() if k not in _SETUP_ONLY_KEYS})
         if H.n_levels < 2:
             stuck = True

@@ -91,8 +91,9 @@ _OPTION_KEYS = {
     "max_levels": int, "max_coarse_size": int, "first_aaf": float, "aaf": float, "enable_sp": int,
     "sp_omega": float, "sp_max_per_row": int, "sp_min_frac": float, "soc_thresh": float, "max_rounds": int,
     "regularize_cmats": int, "log_level": int, "enable_multistep": int, "robust_soc": int,
-    "spw": int, "spw_rounds": int, "spw_orphan_round": int,
+    "spw": int, "spw_rounds": int, "spw_orphan_round": int, "prol_type": int, "sp_max_per_row_classic": int,
 }
+_PROL_TYPES = {"piecewise": 0, "aux_smoothed": 1, "semi_aux_smoothed": 2, "own": 3}        # vertex_factory_impl.hpp:123-125
 _OPTION_ALIASES = {"spw_orphan_treatment": "spw_orphan_round"}        # the reference's flag name (spw_agg.hpp:60)
 
 
@@ -106,6 +107,10 @@ def make_options(dim, energy, **kw):
         if key in _OPTION_KEYS and v is not None:
             if key == "log_level" and isinstance(v, str):
                 v = {"none": 0, "basic": 1, "normal": 2, "extra": 3, "debug": 4}.get(v, 0)
+            if key == "prol_type" and isinstance(v, str):
+                if v not in _PROL_TYPES:
+                    raise NgsAMGError(f"ngs_amg_prol_type: '{v}' (piecewise | aux_smoothed | semi_aux_smoothed | own)")
+                v = _PROL_TYPES[v]
             setattr(o, key, _OPTION_KEYS[key](v))
     return o
 
