@@ -720,7 +720,14 @@ def _hybrid_gsb_data(comm, states, block_rows=None):
     Bs = []
     for s in states:
         M = _mat(s.A)
-        Bs.append(int(block_rows) if block_rows else gs_block_rows(M))
+        if block_rows:
+            # a caller's block size is capped by what the longest row allows: G lanes share a row (16 entries each, + 1 for G = 1)
+            # and a workgroup has at most 1024 lanes (build_gsb)
+            mx = int(np.diff(M.rowptr).max()) if M.n_rows else 0
+            G = next((g for g in (1, 2, 4, 8, 16) if mx <= 16 * g + (1 if g == 1 else 0)), 0)
+            Bs.append(min(int(block_rows), 1024 // G) if G else 0)
+        else:
+            Bs.append(gs_block_rows(M))
     votes = [x for lst in comm.allgather([b if s.n > 0 else -1 for b, s in zip(Bs, states)]) for x in lst if x >= 0]
     B = min(votes) if votes else 0                       # (0 if any non-empty rank cannot use the block form)
     for s, gd in zip(states, gdiag):

@@ -162,7 +162,9 @@ def test_smoother_map_and_cinv_surface():
         ref = up
     assert np.linalg.norm(sol - ref) < 1e-9 * np.linalg.norm(ref)
     bf = c.GetBF(level=1, dof=3, comp=0)
-    assert abs(bf.max() - 1.0) < 0.5 and bf.min() >= -1e-12       # a hat-like, non-negative coarse basis function
+    # a hat-like coarse basis function (rows smoothed with the level matrix may carry small negative weights where the matrix
+    # has positive off-diagonal entries, as in the reference's classic branch)
+    assert abs(bf.max() - 1.0) < 0.5 and bf.min() > -0.25 and bf.sum() > 0.0
     # stand-alone smoothers
     A = _mat(p)
     js = NgsAMG.CreateJacobiSmoother(A, p.free)
