@@ -39,18 +39,20 @@ def _properties(dev, n, free_s, rng):
 
 def test_cfg1_2d_poisson_50k_gauss_seidel_iterations():
     """cfg 1: 2D H1 Poisson, 224^2 = 50 176 DOF, default (Gauss-Seidel) smoother, PCG to 1e-12, the reference's budget of
-    30 iterations (tests/h1/test_2d_poisson.py, SURVEY.md 8d "expect < 30") with the default (SPW) hierarchy; the GPU's
-    sweep order needs at most 15 % more iterations than the reference's sequential order on the same hierarchy"""
+    30 iterations (tests/h1/test_2d_poisson.py, SURVEY.md 8d "expect < 30") with the default hierarchy (SPW agglomeration, semi-aux
+    smoothed prolongation) -- met by the GPU's own sweep order, which needs at most 15 % more iterations than the reference's
+    sequential order on the same hierarchy"""
     from ngsamg_amd import fem, ngs_amg, Matrix
     from ngsamg_amd.harness import Solve
     from oracle.pyoracle import Oracle
     p = fem.poisson_fast((224, 224), dirichlet="left|top")
     A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
     c = ngs_amg.Preconditioner(A, "ngs_amg.h1_scal", freedofs=p.free, ngs_amg_max_coarse_size=5, ngs_amg_dim=2)
-    sol, cg = Solve(c, p.load, ms=35, tol=1e-12, quiet=True)
+    sol, cg = Solve(c, p.load, ms=30, tol=1e-12, quiet=True)        # ms = 30: Solve asserts cg.iterations < 30, the reference's budget
     _, it_seq, _ = Oracle(c.GetHierarchy().levels, sm_type="gs", threads=_threads()).pcg(p.load, tol=1e-12, maxit=100)
-    assert it_seq < 30, it_seq                        # the reference's budget, in the reference's (sequential) sweep order: 28
-    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)      # the GPU's block-hybrid order: 30
+    print("cfg 1 iterations: GPU (block-hybrid order)", cg.iterations, "sequential order", it_seq)
+    assert it_seq < 30, it_seq                        # the same budget in the reference's (sequential) sweep order: 24
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)
     f = p.free.astype(bool)
     assert np.linalg.norm((p.to_scipy() @ sol - p.load)[f]) < 1e-9 * np.linalg.norm(p.load)
 
