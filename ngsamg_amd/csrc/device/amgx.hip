@@ -214,6 +214,7 @@ struct DevRestrict {                    // column-blocked P^T (see restrict_chun
   DevBuf<int32_t> chunk_slot, slot_ptr, optr, oidx, dest;     // dest = inverse of oidx (empty: partials stay in slot order)
   DevBuf<double> w, part;
   DevBuf<uint16_t> fi;
+  int ept = 4;                          // entries of P per thread of the fused kernels (4 or 6: the fullest chunk decides)
   bool empty() const { return n_chunks == 0; }
 };
 
@@ -810,6 +811,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   // pass 1 (parallel over chunks): slots (= distinct coarse columns) per chunk; a chunk's entries are the P entries of its rows
   std::vector<int32_t> chunk_slot(nch + 1, 0);
   std::vector<char> too_long(setup_threads(), 0);
+  std::vector<int64_t> fullest(setup_threads(), 0);
   struct Trip { int32_t J; uint16_t i; double w; };
   auto chunk_trips = [&](int64_t c, std::vector<Trip>& t) {
     t.clear();
@@ -823,6 +825,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
     for (int64_t c = c0; c < c1; ++c) {
       chunk_trips(c, t);
       if ((int64_t)t.size() > max_entries) { too_long[tid] = 1; return; }
+      fullest[tid] = std::max<int64_t>(fullest[tid], (int64_t)t.size());
       int32_t nsl = 0;
       for (size_t q = 0; q < t.size(); ++q) if (q == 0 || t[q].J != t[q - 1].J) nsl++;
       chunk_slot[c + 1] = nsl;
@@ -856,6 +859,10 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   std::vector<int32_t> pos(optr.begin(), optr.end() - 1);
   for (int64_t sidx = 0; sidx < ns; ++sidx) oidx[pos[slot_col[sidx]]++] = (int32_t)sidx;   // ascending chunk order per row
   R.n_chunks = (int)nch; R.n_slots = ns;
+  int64_t mx_chunk = 0;
+  for (int64_t v : fullest) mx_chunk = std::max(mx_chunk, v);
+  R.ept = mx_chunk <= (int64_t)4 * CH ? 4 : 6;
+  if (const char* e = std::getenv("AMGX_FUSED_EPT_MAX")) if (R.ept > std::atoi(e)) { R = DevRestrict(); return; }     // (A/B hook: keep the separate kernels instead)
   R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr);
   // Measured NON-win (profiles/r01/restrict_fused.txt): storing the partial sums row by row (scattered stores in the
   // producer, streaming loads in restrict_sum_kernel) makes the cycle 2-4 % slower at cfg 2; off unless AMGX_RSUM_SORT=1.
@@ -1455,15 +1462,12 @@ struct Handle {
       const bool probe = probe_level == l && probe_kind == 8 && probe_e0;
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       if (grid > 0) {
-        if (FB == 256)
-          hipLaunchKernelGGL((sell_pre_restrict_kernel<256>), dim3(grid), dim3(256), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
-                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-        else if (FB == 512)
-          hipLaunchKernelGGL((sell_pre_restrict_kernel<512>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
-                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-        else
-          hipLaunchKernelGGL((sell_pre_restrict_kernel<1024>), dim3(grid), dim3(1024), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices,
-                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+#define LAUNCH_PRF(FB_, EPT_) hipLaunchKernelGGL((sell_pre_restrict_kernel<FB_, 0, EPT_>), dim3(grid), dim3(FB_), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+        if (FB == 256) { if (R.ept == 4) LAUNCH_PRF(256, 4); else LAUNCH_PRF(256, 6); }
+        else if (FB == 512) { if (R.ept == 4) LAUNCH_PRF(512, 4); else LAUNCH_PRF(512, 6); }
+        else { if (R.ept == 4) LAUNCH_PRF(1024, 4); else LAUNCH_PRF(1024, 6); }
+#undef LAUNCH_PRF
       }
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
       if (!skip_rsum && sp.part != PART_INT)
@@ -1496,12 +1500,14 @@ struct Handle {
       const DevMatrix& M = L.gsb.rest;
       const int nch = (M.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
       if (nch != R.n_chunks) throw Err("fused Gauss-Seidel residual: chunk / slice mismatch");
-      if (M.sell.win)
-        hipLaunchKernelGGL((sell_win_cres_restrict_kernel<SELL_WIN>), dim3(nch), dim3(SELL_WIN), 0, stream, M.n_rows, M.sell.view(), M.sell.rowloc.p,
-                           (const double*)x, (const double*)L.gsb.cvec.p, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
-      else
-      hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 1>), dim3(nch), dim3(512), 0, stream, M.n_rows, 0, M.n_slices, M.sell.view(), (const double*)x,
-                         (const double*)L.gsb.cvec.p, 0.0, 0, (double*)nullptr, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p);
+#define LAUNCH_WCR(EPT_) hipLaunchKernelGGL((sell_win_cres_restrict_kernel<SELL_WIN, EPT_>), dim3(nch), dim3(SELL_WIN), 0, stream, M.n_rows, M.sell.view(), M.sell.rowloc.p, \
+                           (const double*)x, (const double*)L.gsb.cvec.p, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+#define LAUNCH_PCR(EPT_) hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 1, EPT_>), dim3(nch), dim3(512), 0, stream, M.n_rows, 0, M.n_slices, M.sell.view(), (const double*)x, \
+                         (const double*)L.gsb.cvec.p, 0.0, 0, (double*)nullptr, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+      if (M.sell.win) { if (R.ept == 4) LAUNCH_WCR(4); else LAUNCH_WCR(6); }
+      else { if (R.ept == 4) LAUNCH_PCR(4); else LAUNCH_PCR(6); }
+#undef LAUNCH_WCR
+#undef LAUNCH_PCR
       hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
@@ -1953,7 +1959,7 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
     g.has_split = true;
     if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
         P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
-      build_restrict(*P, L.RG, 512, 4 * 512);
+      build_restrict(*P, L.RG, 512, 6 * 512);
     return;
   }
   {
@@ -2028,7 +2034,7 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
     g.has_split = true;
     if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
         P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
-      build_restrict(*P, L.RG, 512, 4 * 512);
+      build_restrict(*P, L.RG, 512, 6 * 512);
   }
 }
 
@@ -2666,7 +2672,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           {
             L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
             if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
-            build_restrict(s.P, L.RF, L.fused_block, 4 * L.fused_block);
+            build_restrict(s.P, L.RF, L.fused_block, 6 * L.fused_block);
           }
         };
         // (device builder: A' = A diag(omega Dinv) from the CSR of A that is already there; the diagonal slot carries omega*Dinv_i

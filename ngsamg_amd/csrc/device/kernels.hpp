@@ -1082,7 +1082,9 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 // FB = workgroup size = rows per chunk (1024 or 512); 4 entries of P per row at most
 // MODE 0: Jacobi pre-smoothing as described above.  MODE 1: residual after a block-hybrid Gauss-Seidel sweep from zero,
 // r = c .* x - A_rest x (EP_CRES; b = the swept x, dinv = c, nothing written to x), with the same chunk-local restriction.
-template <int FUSED_BLOCK, int MODE = 0>
+// EPT: entries of P per thread the chunk may hold (4: prolongations with <= 3 entries per row; 6: the up to 5 of the reference's
+// "classic" rows; chosen per level by build_restrict from the fullest chunk)
+template <int FUSED_BLOCK, int MODE = 0, int EPT = 4>
 __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
                                                                         double omega, int nt, double* __restrict__ x, double* r_out,
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
                                                                         const double* __restrict__ w, const uint16_t* __restrict__ fi,
                                                                         double* __restrict__ part,
                                                                         const int32_t* __restrict__ dest) {
-  constexpr int FUSED_MAX_ENTRIES = 4 * FUSED_BLOCK;
+  constexpr int FUSED_MAX_ENTRIES = EPT * FUSED_BLOCK;
   __shared__ double rl[FUSED_BLOCK];
   __shared__ double pr[FUSED_MAX_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
@@ -1179,13 +1181,13 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
 // The residual after a block-hybrid Gauss-Seidel sweep from zero, r = c .* x - A_rest x, fused with the chunk-local
 // restriction like sell_pre_restrict_kernel<.., 1>, for the WINDOWED SELL form (rows of a 512-row window stored by
 // decreasing length): A_rest has ragged rows (each row lost its in-block lower-colour couplings), plain slices pad ~27 %.
-template <int WB>
+template <int WB, int EPT = 4>
 __global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_rows, SellMat M, const uint16_t* __restrict__ rowloc,
                                                                     const double* __restrict__ x, const double* __restrict__ cvec,
                                                                     const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ slot_ptr,
                                                                     const double* __restrict__ w, const uint16_t* __restrict__ fi,
                                                                     double* __restrict__ part, const int32_t* __restrict__ dest) {
-  constexpr int MAXE = 4 * WB;
+  constexpr int MAXE = EPT * WB;
   __shared__ double buf[WB];
   __shared__ double pr[MAXE];
   const int lane = threadIdx.x & (WAVE - 1);

@@ -1,13 +1,9 @@
-O=gpurun_out/r03t; mkdir -p $O
+O=gpurun_out/r03z; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export NGSAMG_NO_BUILD=1
-NGSAMG_FORCE_DIST=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_d1 -- python bench.py --nv 108 --steps 5 --warmup 3 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $O/trace_d1.log
-f=$(find $O/trace_d1 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 60,1000 25 > $O/trace_dist_world1_nv108.txt
-rm -rf $O/trace_d1
-AMGX_DIST_GRAPH=0 NGSAMG_FORCE_DIST=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_d2 -- python bench.py --nv 108 --steps 5 --warmup 3 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $O/trace_d2.log
-f=$(find $O/trace_d2 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 60,1000 25 > $O/trace_dist_world1_nv108_direct.txt
-rm -rf $O/trace_d2
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_p -- python bench.py --nv 108 --steps 5 --warmup 3 --no-cpu-baseline --no-reference-defaults > /dev/null 2> $O/trace_p.log
-f=$(find $O/trace_p -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/trace_gaps.py $f 2 60,1000 25 > $O/trace_plain_nv108.txt
-rm -rf $O/trace_p
-wc -l $O/*.txt
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python bench.py --hierarchy spw --steps 50 --warmup 10 --no-cpu-baseline --no-reference-defaults > $O/bench_spw_rocprof.json 2> $O/kt.log
+f=$(find $O/kt -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/stats_after_setup.py $f $O/kernel_stats_jacobi_spw_after_setup.csv
+[ -n "$f" ] && python tools/trace_gaps.py $f 2 500,5000 100 > $O/trace_spw.txt
+rm -rf $O/kt
+head -20 $O/kernel_stats_jacobi_spw_after_setup.csv | cut -c1-80,250-
+cat $O/trace_spw.txt | cut -c1-130
