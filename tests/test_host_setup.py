@@ -311,3 +311,41 @@ def test_compact_sweep_blocks_colouring_and_l1_block_diagonal():
                 ad += np.sum(np.abs(val[k][l]) / np.sqrt(diag[i, l] * diag[j]))
             fac = max(fac, 0.51 * (1.0 + ad))
         assert np.allclose(dinv[i * 36:(i + 1) * 36].reshape(6, 6), np.linalg.inv(D[i]) / fac, rtol=1e-10, atol=1e-14)
+
+
+def test_prolongation_types_of_the_reference():
+    """ngs_amg_prol_type (vertex_factory_impl.hpp:63-69): piecewise = one unit entry per free row; aux_smoothed = at most
+    sp_max_per_row entries, non-negative, rows sum to 1; semi_aux_smoothed (default) = rows whose algebraic neighbours cover at most
+    sp_max_per_row_classic aggregates are the rows of (I - omega D^-1 A) P_pw (checked entry by entry), the others are aux rows"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    p = fem.poisson_fast((23, 19, 17), dirichlet="right|top", jitter=0.2, seed=1)
+    A = to_matrix(p)
+    free = p.free.astype(bool)
+    Hp = Hierarchy(A, p.free, p.coords, dim=3, max_coarse_size=20, prol_type="piecewise")
+    Pp = Hp.levels[0].P.to_scipy()
+    assert np.all(np.diff(Pp.indptr)[free] == 1) and np.all(Pp.data == 1.0)
+    Ha = Hierarchy(A, p.free, p.coords, dim=3, max_coarse_size=20, prol_type="aux_smoothed")
+    Pa = Ha.levels[0].P.to_scipy()
+    assert np.diff(Pa.indptr).max() <= 3 and Pa.data.min() >= 0.0
+    assert np.allclose(np.asarray(Pa.sum(axis=1)).ravel()[free], 1.0, atol=1e-14)
+    Hs = Hierarchy(A, p.free, p.coords, dim=3, max_coarse_size=20)                     # default: semi_aux_smoothed
+    Hs2 = Hierarchy(A, p.free, p.coords, dim=3, max_coarse_size=20, prol_type="semi_aux_smoothed", sp_max_per_row_classic=5)
+    Ps = Hs.levels[0].P.to_scipy()
+    assert abs(Ps - Hs2.levels[0].P.to_scipy()).max() == 0.0
+    agg = np.asarray(Hs.levels[0].agg)
+    assert np.array_equal(agg, np.asarray(Ha.levels[0].agg))                           # same agglomerates, other weights
+    As = A.to_scipy().tocsr()
+    nc = Ps.shape[1]
+    Ppw = sp.csr_matrix((np.ones(free.sum()), (np.nonzero(free)[0], agg[free])), shape=(p.n, nc))
+    classic = sp.csr_matrix(Ppw - sp.diags(1.0 / As.diagonal()) @ (As @ Ppw))         # omega = 1 (h1_impl.hpp:324)
+    n_classic = 0
+    for i in np.nonzero(free)[0]:
+        nb = As.indices[As.indptr[i]:As.indptr[i + 1]]
+        if np.all(agg[nb] >= 0) and np.unique(agg[nb]).size <= 5 and np.any(agg[nb[nb != i]] == agg[i]):
+            n_classic += 1
+            assert abs(Ps[i] - classic[i]).max() < 1e-13
+        else:
+            assert Ps[i].nnz <= 3 and Ps[i].data.min() >= 0.0 and abs(Ps[i].sum() - 1.0) < 1e-14
+    assert n_classic > 100                      # (3D: most vertices see more than 5 aggregates and take the aux branch)
+    with pytest.raises(NgsAMGError):
+        Hierarchy(A, p.free, p.coords, dim=3, prol_type="smoothest")
