@@ -6,7 +6,7 @@ import pytest
 import scipy.sparse as sp
 
 from ngsamg_amd import fem
-from ngsamg_amd._lib import Matrix
+from ngsamg_amd._lib import Matrix, NgsAMGError
 from tests.problems import poisson_case, elasticity_case, to_matrix
 
 
