@@ -22,11 +22,11 @@ def mean(path, needle):
 def main():
     d, commit, date = sys.argv[1], sys.argv[2], sys.argv[3]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    jobs = [("jacobi", "sell_pre_restrict_kernel<512, 0>", "traffic_pre_restrict_l0.json", "sell_pre_restrict_kernel<512> level 0 (cfg 2)"),
+    jobs = [("jacobi", "sell_pre_restrict_kernel<512, 0", "traffic_pre_restrict_l0.json", "sell_pre_restrict_kernel<512> level 0 (cfg 2)"),
             ("jacobi", "sell_win_spmv_kernel<512, 2>", "traffic_q_l0.json", "sell_win_spmv_kernel<512, EP_AXPY> on Q, level 0 (cfg 2)"),
             ("gs", "sell_spmv_kernel<1, 1>", "traffic_spmv_l0.json", "sell_spmv_kernel<1, EP_RES> level 0 (cfg 2)"),
             ("gs", "gsb_sweep_kernel<256, 1, false", "traffic_gsb_sweep_l0.json", "gsb_sweep_kernel<256, 1, false, 8> level 0 (cfg 2)"),
-            ("gs", "sell_win_cres_restrict_kernel<512>", "traffic_gs_res_restrict_l0.json", "sell_win_cres_restrict_kernel<512> level 0 (cfg 2)"),
+            ("gs", "sell_win_cres_restrict_kernel<512", "traffic_gs_res_restrict_l0.json", "sell_win_cres_restrict_kernel<512> level 0 (cfg 2)"),
             ("cfg3_jacobi", "bsell_spmv_kernel<3, 1>", "traffic_bsell_res_cfg3.json", "bsell_spmv_kernel<3, EP_RES> level 0 (cfg 3: r = b - A x, 3x3 blocks)"),
             ("cfg5_jacobi", "bsell_spmv_kernel<6, 1>", "traffic_bsell_res_cfg5.json", "bsell_spmv_kernel<6, EP_RES> level 0 (cfg 5: r = b - A x, 6x6 blocks)"),
             ("cfg5_jacobi", "bsell_spmv_kernel<6, 3>", "traffic_bsell_jac_cfg5.json", "bsell_spmv_kernel<6, EP_JAC> level 0 (cfg 5: folded block-Jacobi pre-smoothing pass)"),
