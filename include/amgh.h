@@ -61,8 +61,8 @@ typedef struct amgh_options {
   int32_t prol_type;         /* ngs_amg_prol_type (vertex_factory_impl.hpp:63-69, 849-853): 0 piecewise, 1 aux_smoothed, 2 semi_aux_smoothed   */
                              /*   (the reference's default: rows whose algebraic neighbours map to <= sp_max_per_row_classic coarse vertices   */
                              /*   are smoothed with the level matrix, the others with the replacement matrix of the edge weights,             */
-                             /*   vertex_factory_impl.hpp:1836-2290); 3: the weight rule of rounds 1-2 of this build.  Scalar levels; block     */
-                             /*   levels keep rule 3.  Default: 2 with spw = 1, 3 with spw = 0                                                 */
+                             /*   vertex_factory_impl.hpp:1836-2290); 3: the weight rule of rounds 1-2 of this build.  Block levels take the   */
+                             /*   aux rule on their scalar edge weights for 1 and 2 (rigid-body blocks w Q(t)).  Default: 2 with spw = 1, else 3 */
   int32_t sp_max_per_row_classic;  /* ngs_amg_sp_max_per_row_classic (5, vertex_factory_impl.hpp:71)                                        */
 } amgh_options;
 

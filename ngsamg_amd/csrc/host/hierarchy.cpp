@@ -925,13 +925,15 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         // smoother and buys nothing (the coarsest-level inverse takes over)
         if (o.robust_soc && lev > 0 && (double)snc > 0.8 * (double)cur_free_n) { failed = substeps == 0; break; }
         rounds += r;
-        // prolongation rule (amgh.h: prol_type): the reference's smoothed prolongations exist for scalar levels; block levels and
-        // spw = 0 hierarchies keep the weight rule of the earlier rounds
+        // prolongation rule (amgh.h: prol_type); spw = 0 hierarchies keep the weight rule of the earlier rounds
         const int ptype = o.prol_type >= 0 ? o.prol_type : (o.spw ? 2 : 3);
         Options op = o;
         if (ptype == 0) op.enable_sp = 0;
-        BCSR W = (curA->br == 1 && ptype != 3) ? prolongation_weights_ref(ptype == 2 ? curA : nullptr, G, sagg, snc, op)
-                                               : prolongation_weights(G, sagg, snc, op);
+        // block (elasticity) levels: the aux rule on the scalar edge weights for both smoothed types -- column selection and
+        // replacement-matrix weights as in the reference, the blocks of P stay rigid-body transformations w Q(t); its matrix-valued
+        // classic / aux formulas need the energy's edge matrices, which this setup does not carry
+        BCSR W = ptype == 3 ? prolongation_weights(G, sagg, snc, op)
+                            : prolongation_weights_ref((ptype == 2 && curA->br == 1) ? curA : nullptr, G, sagg, snc, op);
         lap("prolongation weights");
         const int sbf = curA->br;
         std::vector<double> sxc;
