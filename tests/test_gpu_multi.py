@@ -46,3 +46,14 @@ def test_rccl_elasticity_ranks_match_serial_oracle(world, elast):
     if _ngpu() < world:
         pytest.skip(f"needs {world} GPUs")
     _run("--world", str(world), "--box", "12", "--elast", elast, "--dmin", "50")
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("sm", ["hgs"])
+def test_rccl_block_hybrid_gauss_seidel_ranks_match_serial_oracle(world, sm):
+    """sm_type = hgs over RCCL: scalar levels (gsb_sweep_kernel) and 6 x 6 elasticity levels (bgsb_sweep_kernel) swept as boundary
+    blocks, exchange, interior blocks; the whole cycle replayed from its graph"""
+    if _ngpu() < world:
+        pytest.skip(f"needs {world} GPUs")
+    _run("--world", str(world), "--box", "28", "--sm", sm)
+    _run("--world", str(world), "--box", "14", "--elast", "6", "--sm", sm, "--dmin", "200")
