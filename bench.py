@@ -705,7 +705,7 @@ def main():
                 cg1.Solve(b)
                 stream.synchronize()
             cb2, _ = vcycle_bytes(H2)
-            ref_def = {"hierarchy": "library default = the reference's agglomeration: one SPW step (3 pairing rounds + orphan round) per level",
+            ref_def = {"hierarchy": "library default = the reference's setup rules: one SPW step (3 pairing rounds + orphan round) per level, semi-aux smoothed prolongation",
                        "value": round(args.steps / el2, 2), "unit": "applies/s", "ms_per_step": round(1e3 * el2 / args.steps, 4),
                        "levels": H2.n_levels, "level_sizes": [int(l.n) for l in H2.levels], "OC": round(H2.operator_complexity(), 3),
                        "pcg_iterations": int(cg2.iterations), "pcg_iterations_measured_line": int(cg1.iterations),
