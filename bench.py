@@ -54,6 +54,11 @@ def emit(line):
         os.write(_RESULT_FD, data)
 
 
+def sp_nnz(A):
+    """stored (block) entries of a level matrix held as scipy matrix (scalar-expanded blocks count once per scalar entry)"""
+    return A.nnz if hasattr(A, "nnz") else int(A.rowptr[-1])
+
+
 def run_distributed(args, torch, dist, world, rank, device, nv):
     """N > 1: rank-partitioned V-cycle, RCCL through the C ABI.  strong: the nv^3 grid of the N = 1 run cut into N pieces;
     weak: one nv^3 box per rank."""
@@ -144,14 +149,52 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     xn = torch.tensor([xn_loc], dtype=torch.float64)
     dist.all_reduce(xn)
     ms_per_step = 1e3 * elapsed / args.steps
-    k_probe = None
-    if args.smoother == "jacobi" and not elast:
-        try:          # every rank times its own level-0 kernel (no collectives inside), so that all ranks leave together
+    # the dominant kernel timed INSIDE the collective cycle (amgx_dist_time_kernel: every rank runs whole cycles with direct
+    # launches, HIP events around the level-0 launch over the interior rows, the halo exchange in flight beside it)
+    k_probe, k_in_cycle, k_op = None, False, (8 if args.smoother == "jacobi" and not elast else 9 if args.smoother == "gs" else 0)
+    if k_op:
+        ok = 1
+        try:
             with torch.cuda.stream(stream):
-                k_probe = amg.ops[0].top.time_op(0, 7, reps=50)
-        except Exception:
-            k_probe = None
+                k_probe = amg._dev.time_kernel(0, k_op, reps=20)
+                k_in_cycle = True
+        except Exception as e:       # (a rank without such a kernel raises before the first collective: all ranks agree below)
+            ok, k_probe = 0, None
+            if rank == 0:
+                log(f"in-cycle kernel timing unavailable: {e!r}")
+        okt = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if not int(okt.item()):
+            k_probe, k_in_cycle = None, False
+    # PCG to 1e-8 through the rank-partitioned preconditioner (amgx_dist_pcg): iteration count of THIS hierarchy
+    dpcg = None
+    try:
+        with torch.cuda.stream(stream):
+            bb = b[:st.n * bs0].clone()
+            xx = torch.zeros_like(bb)
+            its, errs = amg.pcg([bb], [xx], tol=1e-8, maxsteps=200)
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            xx.zero_()
+            its, errs = amg.pcg([bb], [xx], tol=1e-8, maxsteps=200)
+            torch.cuda.synchronize()
+            dpcg = {"tol": 1e-8, "iterations": int(its), "solve_ms": round(1e3 * (time.perf_counter() - t_s), 3),
+                    "rel_err_estimate": float(errs[-1] / errs[0]) if len(errs) and errs[0] else None}
+    except Exception as e:
+        if rank == 0:
+            log(f"distributed PCG failed: {e!r}")
     dist.barrier()
+    # the hierarchy the ranks built together: global level sizes / entries, operator complexity
+    lvl_n = torch.tensor([lv[0].n for lv in amg.dist_levels], dtype=torch.int64)
+    lvl_nnz = torch.tensor([int(sp_nnz(lv[0].A)) // max(1, int(getattr(lv[0], "bs", 1))) ** 2 for lv in amg.dist_levels], dtype=torch.int64)
+    dist.all_reduce(lvl_n)
+    dist.all_reduce(lvl_nnz)
+    tail_n = [int(l.n) for l in amg.tail_hier.levels]
+    tail_nnz = [int(l.A.nnz) for l in amg.tail_hier.levels]
+    sizes = [int(v) for v in lvl_n.tolist()[:amg.k]] + tail_n
+    nnzs = [int(v) for v in lvl_nnz.tolist()[:amg.k]] + tail_nnz
+    hier_info = {"level_sizes": sizes, "operator_complexity": round(sum(nnzs) / max(1, nnzs[0]), 3),
+                 "rank_partitioned_levels": int(amg.k), "pcg": dpcg}
     # strong scaling (default): a step applies the GLOBAL preconditioner of the fixed problem once: value = steps / time.
     # weak scaling: the unit is one V-cycle over one rank's nv^3 share, a step is `world` such units
     applies_per_s = (1 if strong else world) * args.steps / elapsed
@@ -163,9 +206,15 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
     spmv_bytes = matrix_bytes(lv0.A) + 3 * 8 * lv0.A.n_rows * lv0.A.br
     k_name = "sell_spmv_kernel<EP_RES> (level 0 owned rows, rank 0)" if not elast else f"block residual kernel {lv0.A.br}x{lv0.A.br} (level 0 owned rows x [owned | ghost], rank 0)"
     k_ms = k_probe
-    if k_ms is not None:   # the dominant kernel of the folded cycle (same accounting as the single-GPU line), back to back
-        spmv_bytes = matrix_bytes(lv0.A) + matrix_bytes(lv0.PT) + 7 * 8 * lv0.A.n_rows + 8 * amg.tops[0].levels[1].A.n_rows
-        k_name = "sell_pre_restrict_kernel<512> (level 0 owned rows, rank 0: x = w Dinv b, r = b - A x, b_c = P^T r in one pass)"
+    n_int0 = int(getattr(amg.dist_levels[0][0], "n_interior", lv0.A.n_rows))
+    frac_int = n_int0 / max(1, lv0.A.n_rows)
+    if k_ms is not None and k_op == 8:   # the dominant kernel of the folded cycle (same accounting as the single-GPU line), interior rows
+        spmv_bytes = int(frac_int * (matrix_bytes(lv0.A) + matrix_bytes(lv0.PT) + 7 * 8 * lv0.A.n_rows + 8 * amg.tops[0].levels[1].A.n_rows))
+        k_name = (f"sell_pre_restrict_kernel<512> (level 0, the {n_int0} interior rows of rank 0's {lv0.A.n_rows}: x = w Dinv b, r = b - A x, "
+                  "b_c = P^T r in one pass, beside the halo exchange)")
+    elif k_ms is not None and k_op == 9:
+        spmv_bytes = int(frac_int * (matrix_bytes(lv0.A) + 4 * 8 * lv0.A.n_rows * lv0.A.br + (8 * lv0.A.br * lv0.A.br * lv0.A.n_rows if lv0.A.br > 1 else 0)))
+        k_name = f"backward block-hybrid Gauss-Seidel sweep (level 0, interior blocks of rank 0: {n_int0} of {lv0.A.n_rows} rows, beside the halo exchange)"
     else:
         k_ms = amg.ops[0].top.time_op(0, 0, reps=50)
     achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
@@ -193,10 +242,15 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
                        "levels": amg.k + amg.tail_hier.n_levels, "global_dof": int(ndof_glob.item()), "dist_min_rows": int(dmin),
                        "whole_cycle_graph": amg._dev.graph_info()},
             "x_norm": float(xn.item()) ** 0.5,
+            "hierarchy": hier_info,
             "device_memory": {"per_rank_bytes": hier_bytes},
             "roofline": {"bound": "hbm", "kernel": k_name,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(k_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "traffic_note": "PMC counters need a profiler pass per rank; the single-GPU line carries the counter traffic of the same kernel",
+                         "kernel_ms": round(k_ms, 4),
+                         "kernel_ms_timing": ("HIP events around the kernel inside the running collective cycle (amgx_dist_time_kernel)" if k_in_cycle
+                                              else "HIP events, back-to-back repetitions"),
                          "algorithmic_bytes": int(spmv_bytes), "cycle_algorithmic_bytes_per_rank": int(per_rank),
                          "algorithmic_model_GBs_per_gpu": round(per_rank / (ms_per_step * 1e-3) / 1e9, 1)},
         }
@@ -294,10 +348,12 @@ def main():
                     help="--gpus N > 1: strong (default for cfg2 / cfg4: the SAME nv^3 problem cut into N pieces, value = steps / time) or "
                          "weak (default for cfg3 / cfg5: one nv^3 box per rank, value = ranks x steps / time)")
     ap.add_argument("--dist-min-rows", type=int, default=0, help="a level stays rank-partitioned while every rank has at least this many rows")
-    ap.add_argument("--hierarchy", default="aaf", choices=["aaf", "spw"],
-                    help="aaf (measured line): target-driven agglomeration of rounds 1-2 (OC 1.09 at cfg 2); spw: the reference's / the library's "
-                         "default, one SPW step per level (OC 1.45); the aaf run reports the spw hierarchy beside it as reference_defaults")
-    ap.add_argument("--no-reference-defaults", action="store_true", help="skip the second (default / reference) hierarchy")
+    ap.add_argument("--hierarchy", default="spw", choices=["aaf", "spw"],
+                    help="spw (measured line): the reference's and the library's default setup -- one SPW step (3 pairing rounds + orphan round) per "
+                         "level, semi-aux smoothed prolongation (OC 1.54 at cfg 2); aaf: the target-driven agglomeration of rounds 1-3 (OC 1.09), a "
+                         "hierarchy the reference would not build; the spw run reports it beside the measured line as `continuity`")
+    ap.add_argument("--no-continuity", "--no-reference-defaults", dest="no_continuity", action="store_true",
+                    help="skip the second hierarchy (the round-1..3 continuity line)")
     ap.add_argument("--multistep", action="store_true", help="cfg2, one GPU: hierarchy with ngs_amg_enable_multistep (the reference's H1 default; "
                     "not the measured configuration: denser P, fewer iterations)")
     args = ap.parse_args()
@@ -372,14 +428,13 @@ def main():
         return
 
     # ---- host setup (cold path, not timed) -------------------------------------------------------------
-    # Two hierarchies (VERDICT r02 "emit BOTH"):
-    #  * the measured line keeps the hierarchy of rounds 1-2 (--hierarchy aaf: agglomerate until the level has shrunk to
-    #    first_aaf / aaf, what the reference's option comments describe, base_factory.hpp:100-101; OC 1.09 at cfg 2), so that
-    #    `value` stays comparable from round to round;
-    #  * "reference_defaults" (below) = what a default-constructed ngs_amg preconditioner builds now and what the reference
-    #    builds: ONE SPW step of 3 pairing rounds + orphan round per level (spw_agg_impl.hpp; base_factory.cpp:356-424 takes
-    #    exactly one TryCoarseStep per level, enable_multistep is parsed but not used in that version: base_factory.cpp:27,
-    #    nodal_factory_impl.hpp:84) -- ~8x per level, OC 1.45 at cfg 2, fewer PCG iterations per solve.
+    # The measured line runs on the hierarchy a default-constructed ngs_amg preconditioner builds and the reference builds
+    # (--hierarchy spw): ONE SPW step of 3 pairing rounds + orphan round per level (spw_agg_impl.hpp; base_factory.cpp:356-424
+    # takes exactly one TryCoarseStep per level, enable_multistep is parsed but not used in that version: base_factory.cpp:27,
+    # nodal_factory_impl.hpp:84) with the semi-aux smoothed prolongation (vertex_factory_impl.hpp:1836-2290) -- ~8x per level,
+    # 8 levels, OC 1.54 at cfg 2.  `value`, `roofline`, `cpu_baseline` and the PCG parity block all belong to it.
+    # "continuity" (below) = the hierarchy of rounds 1-3 (--hierarchy aaf: agglomerate until the level has shrunk to
+    # first_aaf / aaf; OC 1.09), kept only so that the rounds stay comparable.
     hier_kw = {"spw": 1} if args.hierarchy == "spw" else {"spw": 0, "enable_multistep": int(args.multistep)}
     t0 = time.time()
     if args.config == "cfg2":
@@ -502,6 +557,8 @@ def main():
             tname = f"traffic_bsell_res_{args.config}.json"
     achieved = spmv_bytes / (k_ms * 1e-3) / 1e9
     traffic = traffic_src = None
+    if args.hierarchy == "spw":          # (the counters were collected per hierarchy: the level-0 kernels stream different P^T / Q)
+        tname = tname.replace(".json", "_spw.json")
     tpath = os.path.join(ROOT, "profiles", tname)
     if os.path.exists(tpath) and nv == (215 if args.config == "cfg2" else 126):
         try:
@@ -565,7 +622,7 @@ def main():
                 M = H.levels[l].A if op < 2 else (H.levels[l].PT if op == 2 else H.levels[l].P)
                 by = matrix_bytes(M) + 8 * H.levels[l].n * H.levels[l].bs * (3 if op == 0 else 4 if op == 1 else 1 if op == 2 else 2)
                 info = amg.matrix_info(l, "A" if op < 2 else ("PT" if op == 2 else "P"))
-                log(f"level {l} {names[op]:18s} {ms * 1e3:9.1f} us  {by / ms / 1e6:8.1f} GB/s  fmt={info['fmt']} lanes={info['lanes']}")
+                log(f"level {l} {names[op]:18s} {ms * 1e3:9.1f} us  {by / ms / 1e6:8.1f} GB/s  fmt={info['fmt']} lanes={info['lanes']} stream={info['stream_bytes'] / 1e6:.1f} MB")
         log(f"whole cycle (graph) {amg.time_op(0, 4, reps=50) * 1e3:.1f} us")
 
     # ---- CPU baseline: the oracle (restatement of the reference's cycle) on this box's cores ----------
@@ -677,15 +734,15 @@ def main():
                "GBs_algorithmic": round(cycle_bytes / cpu_t / 1e9, 1), "gpu_vs_oracle_rel_err": parity, "pcg": pcg}
         log(f"cpu baseline: {1.0 / cpu_t:.2f} applies/s on {cores} threads; GPU-vs-oracle rel. error {parity:.2e}")
 
-    # ---- the default (= reference) hierarchy beside the measured one -------------------------------------------------
-    ref_def = None
-    if rank == 0 and args.hierarchy == "aaf" and not args.no_reference_defaults and not args.multistep:
+    # ---- continuity: the hierarchy of rounds 1-3 beside the measured (default = reference) one ---------------------------
+    cont = None
+    if rank == 0 and args.hierarchy == "spw" and not args.no_continuity and not args.multistep:
         try:
             tr0 = time.time()
             if args.config == "cfg2":
-                H2 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10)
+                H2 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10, spw=0)
             else:
-                H2 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=1, max_coarse_size=50, regularize_cmats=0 if args.config == "cfg5" else 1)
+                H2 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=1, max_coarse_size=50, regularize_cmats=0 if args.config == "cfg5" else 1, spw=0)
             amg2 = DeviceAMGMatrix(H2, sm_type=dev_sm, omega=0.9, mg_cycle="V", clev="inv", device=device, use_graph=not args.no_graph)
             tr1 = time.time()
             with torch.cuda.stream(stream):
@@ -705,18 +762,18 @@ def main():
                 cg1.Solve(b)
                 stream.synchronize()
             cb2, _ = vcycle_bytes(H2)
-            ref_def = {"hierarchy": "library default = the reference's setup rules: one SPW step (3 pairing rounds + orphan round) per level, semi-aux smoothed prolongation",
-                       "value": round(args.steps / el2, 2), "unit": "applies/s", "ms_per_step": round(1e3 * el2 / args.steps, 4),
-                       "levels": H2.n_levels, "level_sizes": [int(l.n) for l in H2.levels], "OC": round(H2.operator_complexity(), 3),
-                       "pcg_iterations": int(cg2.iterations), "pcg_iterations_measured_line": int(cg1.iterations),
-                       "pcg_time_model_ms": {"reference_defaults": round(cg2.iterations * 1e3 * el2 / args.steps, 2),
-                                             "measured_line": round(cg1.iterations * ms_per_step, 2),
-                                             "note": "iterations x cycle time (the cycle's share of a PCG solve to 1e-8)"},
-                       "algorithmic_cycle_bytes": int(cb2), "setup_s": round(tr1 - tr0, 1)}
-            log(f"reference_defaults: {ref_def['value']} applies/s, OC {ref_def['OC']}, levels {ref_def['level_sizes']}, PCG {cg2.iterations} vs {cg1.iterations} iterations")
+            cont = {"hierarchy": "aaf-driven agglomeration of rounds 1-3 (spw = 0): a hierarchy the reference would not build; round-to-round continuity only",
+                    "value": round(args.steps / el2, 2), "unit": "applies/s", "ms_per_step": round(1e3 * el2 / args.steps, 4),
+                    "levels": H2.n_levels, "level_sizes": [int(l.n) for l in H2.levels], "OC": round(H2.operator_complexity(), 3),
+                    "pcg_iterations": int(cg2.iterations), "pcg_iterations_measured_line": int(cg1.iterations),
+                    "pcg_time_model_ms": {"continuity": round(cg2.iterations * 1e3 * el2 / args.steps, 2),
+                                          "measured_line": round(cg1.iterations * ms_per_step, 2),
+                                          "note": "iterations x cycle time (the cycle's share of a PCG solve to 1e-8)"},
+                    "algorithmic_cycle_bytes": int(cb2), "setup_s": round(tr1 - tr0, 1)}
+            log(f"continuity (aaf hierarchy): {cont['value']} applies/s, OC {cont['OC']}, levels {cont['level_sizes']}, PCG {cg2.iterations} vs {cg1.iterations} iterations")
             del amg2, x2
         except Exception as e:
-            log(f"reference_defaults block failed: {e!r}")
+            log(f"continuity block failed: {e!r}")
 
     # what an unmodified host-pointer caller gets (vectors cross PCIe in both directions inside the call): never `value`
     host_rate = None
@@ -750,8 +807,10 @@ def main():
                       else f"V-cycle applies/sec (3D elasticity {nv}^3 nodes, block size {bs0}, block-{args.smoother} V(1,1))",
             "value": round(applies_per_s, 2), "unit": "applies/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # (one GPU: the N = 1 point of the strong-scaling series bench.py --gpus N runs for cfg 2 / cfg 4, of the weak one for cfg 3 / cfg 5)
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl + (" [enable_multistep]" if args.multistep else ""),
+                       "level_sizes": [int(l.n) for l in H.levels],
                        "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
                        "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
                        "post_smoothing": ("folded into the prolongation: x' = z + (I - w Dinv A) P x_c, same result up to rounding "
@@ -765,10 +824,11 @@ def main():
         }
         if gs_its is not None:
             out["gs_iterations"] = gs_its
-        if ref_def is not None:
-            out["reference_defaults"] = ref_def
-        out["config"]["hierarchy"] = ("aaf-driven agglomeration of rounds 1-2 (spw = 0): kept for round-to-round comparability; see reference_defaults"
-                                      if args.hierarchy == "aaf" else "library default (SPW, one step per level)")
+        if cont is not None:
+            out["continuity"] = cont
+        out["config"]["hierarchy"] = ("aaf-driven agglomeration of rounds 1-3 (spw = 0): NOT the reference's hierarchy, continuity only"
+                                      if args.hierarchy == "aaf" else
+                                      "library default = the reference's setup rules: one SPW step (3 pairing rounds + orphan round) per level, semi-aux smoothed prolongation")
         if cpu is not None:
             out["cpu_baseline"] = cpu
             if cpu.get("pcg") is not None:

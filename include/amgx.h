@@ -326,6 +326,12 @@ int amgx_dist_apply(amgx_comm c, const double* const* b, double* const* x, int b
  * per local rank; x holds the initial guess.  err_k, tol, errs, iters as amgx_pcg. */
 int amgx_dist_pcg(amgx_comm c, const double* const* b, double* const* x, double tol, int maxit, int use_precond, int flags, double* errs,
                   int32_t* iters);
+/* Measurement hook, collective (every rank calls it with the same arguments): `reps` whole cycles with direct launches, HIP
+ * events around ONE kernel of the first local rank's level `level` -- op 8: the fused Jacobi pre-smoothing + residual +
+ * restriction kernel over the INTERIOR rows (the launch that runs beside the halo exchange); op 9: the backward block-hybrid
+ * Gauss-Seidel sweep over the interior blocks.  The counterpart of amgx_time_op(op 8 / 9) for rank-partitioned hierarchies:
+ * the kernel is timed where it runs, with the exchange in flight next to it. */
+int amgx_dist_time_kernel(amgx_comm c, int level, int op, int reps, double* avg_ms);
 /* the level-0 right-hand-side buffer of a rank ([owned | ghost], device): filling it in place saves the copy of b */
 int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_ext);
 /* borrowed handles of the rank-partitioned levels and of the replicated tail, for queries / measurement only */

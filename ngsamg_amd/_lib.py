@@ -237,7 +237,7 @@ AMGX_SYMBOLS = [
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_cycle_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op", "amgx_pcg", "amgx_gmres",
     "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
-    "amgx_comm_synchronize", "amgx_comm_info", "amgx_comm_graph_info", "amgx_comm_graph_note", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply", "amgx_dist_pcg",
+    "amgx_comm_synchronize", "amgx_comm_info", "amgx_comm_graph_info", "amgx_comm_graph_note", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply", "amgx_dist_time_kernel", "amgx_dist_pcg",
     "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
     "amgx_gss4_create", "amgx_gss4_destroy", "amgx_gss4_last_error", "amgx_gss4_set_stream", "amgx_gss4_synchronize",
     "amgx_gss4_info", "amgx_gss4_smooth", "amgx_gss4_smooth_res", "amgx_gss4_mult_add",
@@ -302,6 +302,7 @@ def hip():
     lib.amgx_dist_create.argtypes = [vp, C.POINTER(amgx_dist_desc), C.POINTER(vp)]
     lib.amgx_dist_destroy.argtypes = [vp]
     lib.amgx_dist_apply.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_int, C.c_int]
+    lib.amgx_dist_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
     lib.amgx_dist_pcg.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_int, C.c_int, C.c_int, c_f64p, c_i32p]
     lib.amgx_dist_rhs_buffer.argtypes = [vp, C.POINTER(dp), c_i64p, c_i64p]
     lib.amgx_dist_handles.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

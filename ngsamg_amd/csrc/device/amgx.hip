@@ -119,11 +119,12 @@ struct DevMatrix {
     DevBuf<uint16_t> col16;
     DevBuf<double> val;
     int rowrel = 0, diag_first = 0, wdiag = 0;
+    int xcd = 0;                       // workgroup -> rows mapping of the streaming kernels: see SellMat::xcd
     // windowed form (sell_win_spmv_kernel): inside every window of `win` consecutive rows the rows are stored in order
     // of decreasing length (slice padding 1.42 -> 1.08 on Q at cfg 2); rowloc[slot] = row of the slot inside its window
     int win = 0;
     DevBuf<uint16_t> rowloc;
-    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first, wdiag}; }
+    SellMat view() const { return SellMat{slice_ptr.p, col32.p, col16.p, cbase.p, val.p, rowrel, diag_first, wdiag, xcd}; }
   } sell;
   struct Rb {                          // rigid-body transfer blocks (kernels.hpp, RbMat): P_ik = w_ik Q(t_ik), or its transpose
     int dim = 0, bf = 0, bc = 0;       // spatial dimension of Q (0: w I), fine / coarse block size
@@ -366,6 +367,16 @@ static int pick_lanes(double avg_len) {
     if (eff > best_eff) { best_eff = eff; best = g; }
   }
   return best;
+}
+
+// Long rows (coarse levels of a reference-shaped hierarchy: 50-100 entries per row, ragged): with one thread per row the 64
+// lanes of a wave gather entry k of 64 DIFFERENT rows per step -- 64 unrelated cache lines, the kernel is bound by the
+// address path (0.45 T gathers/s measured at the 1.24 M-row level of cfg 2, 4.5 TB/s) -- while G lanes per row walk G
+// consecutive (ascending, hence neighbouring) columns of ONE row.  Lanes per row for rows of this average length:
+static int sell_long_row_lanes(double avg) {
+  int g = avg >= 24.0 ? 4 : 1;
+  if (const char* e = std::getenv("AMGX_SELL_LONG_ROW_LANES")) g = avg >= 24.0 ? std::max(1, std::atoi(e)) : 1;
+  return g;
 }
 
 // SELL-64-pair image of the rows `rows[0..m)` of a scalar CSR matrix (row id < 0 => empty padding row).
@@ -695,15 +706,25 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
   if (allow_sell && A.br == 1 && A.bc == 1 && D.n_rows > 0 && D.nnz > 0) {
     int G = 1;
     while (G < 16 && D.n_rows * G < ((int64_t)1 << 20) && avg > 3.0 * G) G <<= 1;
+    G = std::max(G, sell_long_row_lanes(avg));
     if (const char* e = std::getenv("AMGX_SELL_MAX_LANES")) G = std::max(1, std::min(G, std::atoi(e)));   // test hook
     for (int g = G; g >= 1; g >>= 1)
       if ((double)sell_stored(A, g) <= max_pad * (double)D.nnz) { sellG = g; break; }
   }
-  // one thread per row with ragged rows: length-sorted windows instead of padding every slice to its longest row
-  const bool windowed = win > 0 && sellG == 1 && (double)sell_stored(A, 1) > 1.10 * (double)D.nnz && !std::getenv("AMGX_NO_SELL_WINDOW");
-  if (windowed) {
-    std::vector<int32_t> rows((size_t)A.n_rows);
-    std::vector<uint16_t> rowloc((size_t)A.n_rows);
+  // one thread per row with ragged rows: length-sorted windows instead of padding every slice to its longest row.  Short ragged
+  // rows whose plain slices pad beyond max_pad (prolongations of the reference's setup: 1 ... 6 entries, 3.3 on average) take the
+  // windowed form too if ITS padding is acceptable -- the CSR-vector kernel runs such a P at 2.3 TB/s (263 us at cfg 2)
+  // (win < 0: the windowed form only as that fallback, never instead of an acceptable plain SELL image)
+  const bool win_fallback_only = win < 0;
+  if (win < 0) win = -win;
+  bool windowed = win > 0 && !win_fallback_only && sellG == 1 && (double)sell_stored(A, 1) > 1.10 * (double)D.nnz && !std::getenv("AMGX_NO_SELL_WINDOW");
+  const bool try_win = win > 0 && sellG == 0 && allow_sell && A.br == 1 && A.bc == 1 && D.n_rows >= 4 * win && D.nnz > 0 && avg <= 12.0 &&
+                       !std::getenv("AMGX_NO_SELL_WINDOW") && !std::getenv("AMGX_NO_SELL_WINDOW_SHORT");
+  std::vector<int32_t> rows;
+  std::vector<uint16_t> rowloc;
+  if (windowed || try_win) {
+    rows.resize((size_t)A.n_rows);
+    rowloc.resize((size_t)A.n_rows);
     par_for((A.n_rows + win - 1) / win, [&](int64_t q0, int64_t q1, int) {
       for (int64_t q = q0; q < q1; ++q) {
         const int64_t w0 = q * win, w1 = std::min<int64_t>(A.n_rows, w0 + win);
@@ -713,6 +734,16 @@ static void upload_matrix(const amgx_matrix& A, DevMatrix& D, const char* what, 
         for (int64_t i = w0; i < w1; ++i) rowloc[i] = (uint16_t)(rows[i] - w0);
       }
     }, 8);
+    if (try_win) {
+      int64_t stored = 0;
+      for (int64_t sl = 0; sl * WAVE < A.n_rows; ++sl) {           // (sorted windows: the first row of a slice is its longest)
+        const int32_t r = rows[sl * WAVE];
+        stored += (int64_t)(A.rowptr[r + 1] - A.rowptr[r]) * WAVE;
+      }
+      windowed = (double)stored <= max_pad * (double)D.nnz;
+    }
+  }
+  if (windowed) {
     HostSell S;
     build_sell(A, rows.data(), A.n_rows, false, 1, S, false);
     D.fmt = FMT_SELL;
@@ -805,7 +836,9 @@ static void build_bgs(const amgx_level_desc& d, DevLevel& L) {
   g.val.upload(d.A.val, (size_t)nnz * bs * bs);
 }
 
-static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES) {
+// CH = fine rows per chunk; threads = workgroup size of the kernel that consumes the chunk (= CH unless several lanes share a row)
+static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES, int threads = 0) {
+  if (threads <= 0) threads = CH;
   const int64_t nf = P.n_rows, nc = P.n_cols;
   const int64_t nch = (nf + CH - 1) / CH;
   // pass 1 (parallel over chunks): slots (= distinct coarse columns) per chunk; a chunk's entries are the P entries of its rows
@@ -861,7 +894,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   R.n_chunks = (int)nch; R.n_slots = ns;
   int64_t mx_chunk = 0;
   for (int64_t v : fullest) mx_chunk = std::max(mx_chunk, v);
-  R.ept = mx_chunk <= (int64_t)4 * CH ? 4 : 6;
+  R.ept = mx_chunk <= (int64_t)4 * threads ? 4 : 6;
   if (const char* e = std::getenv("AMGX_FUSED_EPT_MAX")) if (R.ept > std::atoi(e)) { R = DevRestrict(); return; }     // (A/B hook: keep the separate kernels instead)
   R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr);
   // Measured NON-win (profiles/r01/restrict_fused.txt): storing the partial sums row by row (scattered stores in the
@@ -1454,19 +1487,28 @@ struct Handle {
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty()) {
       const DevRestrict& R = L.RF;
       const int FB = L.fused_block;
+      const int G = L.Apre.lanes;
       const int nch = (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
       if (nch != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
       int64_t ca, cb;
-      unit_range(sp, FB, nch, ca, cb);
+      unit_range(sp, FB / G, nch, ca, cb);
       const int grid = (int)(cb - ca), c0 = (int)ca;
-      const bool probe = probe_level == l && probe_kind == 8 && probe_e0;
+      // (rank-partitioned level: the events go around the interior launch, which runs beside the halo exchange)
+      const bool probe = probe_level == l && probe_kind == 8 && probe_e0 && sp.part != PART_BND;
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       if (grid > 0) {
 #define LAUNCH_PRF(FB_, EPT_) hipLaunchKernelGGL((sell_pre_restrict_kernel<FB_, 0, EPT_>), dim3(grid), dim3(FB_), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
                              L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
-        if (FB == 256) { if (R.ept == 4) LAUNCH_PRF(256, 4); else LAUNCH_PRF(256, 6); }
+#define LAUNCH_PRG(G_) hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 0, 4, G_>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+        if (G > 1) {
+          if (FB != 512 || R.ept != 4) throw Err("fused restriction with several lanes per row: unexpected chunk shape");
+          if (G == 2) LAUNCH_PRG(2); else if (G == 4) LAUNCH_PRG(4); else LAUNCH_PRG(8);
+        }
+        else if (FB == 256) { if (R.ept == 4) LAUNCH_PRF(256, 4); else LAUNCH_PRF(256, 6); }
         else if (FB == 512) { if (R.ept == 4) LAUNCH_PRF(512, 4); else LAUNCH_PRF(512, 6); }
         else { if (R.ept == 4) LAUNCH_PRF(1024, 4); else LAUNCH_PRF(1024, 6); }
+#undef LAUNCH_PRG
 #undef LAUNCH_PRF
       }
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
@@ -2613,7 +2655,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         throw Err("PT does not match P");
       if (!s.dinv) throw Err("dinv missing");
       tasks.run([&] {
-        upload_matrix(s.P, L.P, "P", true, false, false, 1.35, 0, nullptr, 1);
+        upload_matrix(s.P, L.P, "P", true, false, false, 1.35, s.P.br == 1 && s.P.bc == 1 ? -SELL_WIN : 0, nullptr, 1);
         upload_matrix(s.PT, L.PT, "PT", true, false, false, 1.35, 0, nullptr, 2);
         // big scalar levels restrict through the column-blocked form (the P^T gather is TA/L2-bound there)
         // Measured non-win (profiles/r01/restrict_blocked.txt): 121 + 22 us vs 134 us for the P^T gather at cfg 2,
@@ -2667,12 +2709,14 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
           // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
           // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
-          if (L.Apre.fmt == FMT_SELL && L.Apre.lanes == 1 && s.P.br == 1 && s.P.bc == 1 &&
-              s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
+          const int G = L.Apre.lanes;
+          if (L.Apre.fmt == FMT_SELL && !L.Apre.sell.win && (G == 1 || G == 2 || G == 4 || G == 8) && s.P.br == 1 && s.P.bc == 1 &&
+              s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT") && !(G > 1 && std::getenv("AMGX_NO_FUSED_RESTRICT_MULTI")))
           {
             L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
             if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
-            build_restrict(s.P, L.RF, L.fused_block, 6 * L.fused_block);
+            if (G > 1) L.fused_block = 512;        // (several lanes per row: the chunk holds 512 / G rows)
+            build_restrict(s.P, L.RF, L.fused_block / G, 6 * L.fused_block, L.fused_block);
           }
         };
         // (device builder: A' = A diag(omega Dinv) from the CSR of A that is already there; the diagonal slot carries omega*Dinv_i
@@ -2799,6 +2843,15 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       if (s.sm_type == AMGX_SM_BGS && s.bgs_n_blocks > 0) build_bgs(s, L);
     }
     tasks.wait();
+    {
+      // workgroup -> rows mapping of the streaming kernels on this level (SellMat::xcd)
+      int mode = 1;
+      if (const char* e = std::getenv("AMGX_XCD")) mode = std::atoi(e);
+      const double avg = s.A.n_rows ? (double)s.A.rowptr[s.A.n_rows] / (double)s.A.n_rows : 0.0;
+      const int on = mode >= 2 || (mode == 1 && avg >= 24.0 && s.A.n_rows >= 200000);
+      L.A.sell.xcd = L.Apre.sell.xcd = L.Q.sell.xcd = L.gsb.rest.sell.xcd = on;
+      if (mode >= 3) L.P.sell.xcd = L.PT.sell.xcd = on;
+    }
     const size_t len = (size_t)std::max<int64_t>(1, L.ext_len());
     L.x.alloc(len); L.rhs.alloc(len); L.res.alloc(len); L.tmp.alloc(len);
     HIPCHK(hipMemset(L.x.p, 0, len * sizeof(double)));

@@ -388,6 +388,7 @@ static bool dev_images_wanted(const amgx_matrix& A) {
   const double avg = (double)nnz / (double)A.n_rows;
   int G = 1;
   while (G < 16 && A.n_rows * G < ((int64_t)1 << 20) && avg > 3.0 * G) G <<= 1;
+  G = std::max(G, sell_long_row_lanes(avg));
   if (const char* e = std::getenv("AMGX_SELL_MAX_LANES")) G = std::max(1, std::min(G, std::atoi(e)));
   return G == 1;
 }

@@ -631,7 +631,14 @@ struct DistCycle {
         d->top->mult_add(d->top->lev[l].P, 1.0, xc, d->xext[l].p, d->text[l].p);
       }
       const int tk = c.exchange_begin(items(l, 2));
-      for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep_back(d, l, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), 0, nbi(d, l)); }
+      for (size_t i = 0; i < M.size(); ++i) {
+        Dist* d = M[i];
+        // (amgx_dist_time_kernel, op 9: HIP events around the interior blocks' launch of the first local rank)
+        const bool probe = i == 0 && d->top->probe_level == l && d->top->probe_kind == 9 && d->top->probe_e0;
+        if (probe) HIPCHK(hipEventRecord(d->top->probe_e0, c.compute));
+        sweep_back(d, l, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), 0, nbi(d, l));
+        if (probe) HIPCHK(hipEventRecord(d->top->probe_e1, c.compute));
+      }
       c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; sweep_back(d, l, d->text[l].p, l == 0 ? x[i] : d->xext[l].p, bl(d, i, l), nbi(d, l), -1); }
     }
@@ -1018,6 +1025,46 @@ int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail) {
 
 int amgx_dist_apply(amgx_comm cc, const double* const* b, double* const* x, int b_status, int flags) {
   return cguard(cc, [&](amgx::Comm& c) { amgx::dist_apply(c, b, x, b_status, flags); });
+}
+
+int amgx_dist_time_kernel(amgx_comm cc, int level, int op, int reps, double* avg_ms) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    using namespace amgx;
+    if (c.members.empty() || (c.kind == AMGX_COMM_LOCAL && (int)c.members.size() != c.nranks)) throw Err("amgx_dist_time_kernel: not all ranks have a hierarchy");
+    if (reps < 1 || !avg_ms || (op != 8 && op != 9)) throw Err("amgx_dist_time_kernel: bad arguments (op 8: fused Jacobi down kernel, op 9: backward block-hybrid sweep)");
+    Dist* d0 = c.members[0];
+    if (level < 0 || level >= d0->k) throw Err("amgx_dist_time_kernel: not a rank-partitioned level");
+    Handle& h = *d0->top;
+    DevLevel& L = h.lev[level];
+    if (op == 8 && (L.RF.empty() || !(h.plain(L) && L.sm_type == AMGX_SM_JACOBI) || !d0->fold)) throw Err("amgx_dist_time_kernel: level has no fused pre-smoothing + restriction kernel");
+    if (op == 9 && !(d0->gsb && (L.gsb.on() || L.bgsb.on()))) throw Err("amgx_dist_time_kernel: level has no block-hybrid Gauss-Seidel sweep");
+    std::vector<const double*> bb;
+    std::vector<double*> xx;
+    for (Dist* d : c.members) {
+      if (d->n(0)) hipLaunchKernelGGL(fill_kernel, dim3(Handle::grid_for(d->n(0))), dim3(BLOCK), 0, c.compute, d->n(0), (uint64_t)2, d->bext[0].p);
+      bb.push_back(d->bext[0].p); xx.push_back(d->x0.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventCreate(&h.probe_e0));
+    HIPCHK(hipEventCreate(&h.probe_e1));
+    h.probe_kind = op;
+    double tot = 0.0;
+    try {
+      dist_apply(c, bb.data(), xx.data(), 1, AMGX_DEVICE_PTR | AMGX_NO_GRAPH);        // warm-up (and RCCL's lazy connections)
+      h.probe_level = level;
+      for (int i = 0; i < reps; ++i) {
+        dist_apply(c, bb.data(), xx.data(), 1, AMGX_DEVICE_PTR | AMGX_NO_GRAPH);
+        HIPCHK(hipStreamSynchronize(c.compute));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, h.probe_e0, h.probe_e1));
+        tot += ms;
+      }
+    } catch (...) { h.probe_level = -1; (void)hipEventDestroy(h.probe_e0); (void)hipEventDestroy(h.probe_e1); h.probe_e0 = h.probe_e1 = nullptr; throw; }
+    h.probe_level = -1;
+    (void)hipEventDestroy(h.probe_e0); (void)hipEventDestroy(h.probe_e1);
+    h.probe_e0 = h.probe_e1 = nullptr;
+    *avg_ms = tot / reps;
+  });
 }
 
 int amgx_dist_pcg(amgx_comm cc, const double* const* b, double* const* x, double tol, int maxit, int use_precond, int flags, double* errs,

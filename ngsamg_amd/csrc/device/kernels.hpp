@@ -151,7 +151,11 @@ struct SellMat {
   int diag_first;             // G == 1 only: entry 0 of every row is its diagonal, so the gathered x[row] comes for free
   int wdiag;                  // pre-smoothing image A' only (implies diag_first): the diagonal slot holds omega*Dinv_i instead of
                               //   A'_ii (which is omega for a free row, 0 otherwise), so the epilogue needs no dinv stream
+  int xcd;                    // 1: workgroup b of the launch works on unit xcd_remap(b): every XCD (= every L2) walks ONE contiguous
+                              //   eighth of the rows.  For long-row levels whose gathered vector does not fit an L2 next to the rows in flight
+                              //   (the 1.24 M x 52 level of cfg 2: 10 MB of x, 40 % of the rows in flight at once); level 0 keeps 0 (xcd_remap)
 };
+__device__ __forceinline__ int sell_unit(const SellMat& M) { return M.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x; }
 
 // SELL row product, software-pipelined in batches of K pair-steps: the matrix loads (values + packed indices) of batch
 // i+1 are requested BEFORE the gathers of batch i are consumed, so a wave always has a matrix batch in flight while it
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void sell_spmv_kernel(int64_t n_rows, int sl
   const int lane = threadIdx.x & (WAVE - 1);
   // the slice index is wave-uniform: tell the compiler, so slice pointers and column bases use scalar loads
   // (slice0 .. n_slices: the launch covers a range of slices -- interior / boundary rows of a rank-partitioned level)
-  const int s = __builtin_amdgcn_readfirstlane(slice0 + blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+  const int s = __builtin_amdgcn_readfirstlane(slice0 + sell_unit(M) * WAVES_PER_BLOCK + (threadIdx.x >> 6));
   if (s >= n_slices) return;
   const int row = s * (WAVE / G) + lane / G;
   double xd[2] = {0.0, 0.0};
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(WB) void sell_win_spmv_kernel(int64_t n_rows, int w
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
   __shared__ double buf[WB];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int wb = win0 + blockIdx.x;            // window index (win0: first window of the launch, see sell_spmv_kernel)
+  const int wb = win0 + sell_unit(M);          // window index (win0: first window of the launch, see sell_spmv_kernel)
   const int s = __builtin_amdgcn_readfirstlane(wb * (WB / WAVE) + (threadIdx.x >> 6));
   const int64_t slot = (int64_t)s * WAVE + lane;
   const int64_t row = (int64_t)wb * WB + threadIdx.x;
@@ -1084,7 +1088,9 @@ __global__ __launch_bounds__(BLOCK) void restrict_chunk_kernel(int64_t n_fine, c
 // r = c .* x - A_rest x (EP_CRES; b = the swept x, dinv = c, nothing written to x), with the same chunk-local restriction.
 // EPT: entries of P per thread the chunk may hold (4: prolongations with <= 3 entries per row; 6: the up to 5 of the reference's
 // "classic" rows; chosen per level by build_restrict from the fullest chunk)
-template <int FUSED_BLOCK, int MODE = 0, int EPT = 4>
+// G = lanes per row (SELL-G image, long rows of the coarser levels): the chunk then holds FUSED_BLOCK / G rows, the G partial
+// row sums are combined by a wave shuffle and the first lane of every group runs the epilogue
+template <int FUSED_BLOCK, int MODE = 0, int EPT = 4, int G = 1>
 __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                         const double* __restrict__ b, const double* __restrict__ dinv,
                                                                         double omega, int nt, double* __restrict__ x, double* r_out,
@@ -1094,12 +1100,15 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
                                                                         double* __restrict__ part,
                                                                         const int32_t* __restrict__ dest) {
   constexpr int FUSED_MAX_ENTRIES = EPT * FUSED_BLOCK;
-  __shared__ double rl[FUSED_BLOCK];
+  constexpr int RPC = FUSED_BLOCK / G;         // rows per chunk
+  __shared__ double rl[RPC];
   __shared__ double pr[FUSED_MAX_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int c = chunk0 + blockIdx.x;           // chunk0: first chunk of the launch (interior / boundary chunks of a rank-partitioned level)
+  const int c = chunk0 + sell_unit(M);         // chunk0: first chunk of the launch (interior / boundary chunks of a rank-partitioned level)
   const int s = __builtin_amdgcn_readfirstlane(c * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));
-  const int row = s * WAVE + lane;
+  const int row = s * (WAVE / G) + lane / G;
+  const int lrow = (threadIdx.x >> 6) * (WAVE / G) + lane / G;     // row inside the chunk
+  const bool writer = (lane % G) == 0;
   // the chunk-local restriction data of this thread is requested FIRST, so that it arrives while the row product
   // streams A'; the epilogue after the barriers then touches LDS only
   // (nothing in this prologue is CONSUMED before the row product: a subtraction on a freshly loaded slot pointer here made
@@ -1129,25 +1138,30 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
   if (MODE == 1) {
     if (s < n_slices) {
       double ci = 0.0, xi = 0.0;
-      if (row < n_rows) { ci = dinv[row]; xi = b[row]; }
+      if (writer && row < n_rows) { ci = dinv[row]; xi = b[row]; }
       double xdd[2];
-      const double acc = sell_row_dot_sp(M, sp0, sp1, lane, row, b, xdd);
-      if (row < n_rows) { r = ci * xi - acc; if (r_out) r_out[row] = r; }
+      double acc = sell_row_dot_sp(M, sp0, sp1, lane, row, b, xdd);
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+      if (writer && row < n_rows) { r = ci * xi - acc; if (r_out) r_out[row] = r; }
     }
   } else if (s < n_slices) {
     double bi = 0.0, di = 0.0;
     double xd[2] = {0.0, 0.0};
-    const bool wdiag = M.wdiag && M.diag_first;
-    if (!wdiag && (nt & EPF_HOIST) && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+    const bool wdiag = G == 1 && M.wdiag && M.diag_first;
+    const bool hoist = G > 1 || (nt & EPF_HOIST);
+    if (!wdiag && hoist && writer && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
     double acc = sell_row_dot_sp(M, sp0, sp1, lane, row, b, xd);
-    if (row < n_rows) {
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+    if (writer && row < n_rows) {
       if (wdiag) {
         // diagonal slot = omega*Dinv_i (no dinv stream, b_i from the gather): see sell_spmv_kernel
         bi = xd[0];
         const double wd = xd[1];
         acc = acc - wd * bi + (wd != 0.0 ? omega * bi : 0.0);
         di = wd / omega;
-      } else if (!(nt & EPF_HOIST)) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+      } else if (!hoist) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
       r = bi - acc;
       double xi = omega * (di * bi);
       if (nt & EPF_FOLD) xi += omega * (di * r);
@@ -1156,7 +1170,7 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
       if (r_out) r_out[row] = r;
     }
   }
-  rl[threadIdx.x] = r;
+  if (writer) rl[lrow] = r;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < FUSED_MAX_ENTRIES / FUSED_BLOCK; ++q) {
@@ -1191,7 +1205,7 @@ __global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_ro
   __shared__ double buf[WB];
   __shared__ double pr[MAXE];
   const int lane = threadIdx.x & (WAVE - 1);
-  const int c = blockIdx.x;
+  const int c = sell_unit(M);
   const int s = __builtin_amdgcn_readfirstlane(c * (WB / WAVE) + (threadIdx.x >> 6));
   const int64_t slot = (int64_t)s * WAVE + lane;
   const int64_t row = (int64_t)c * WB + threadIdx.x;

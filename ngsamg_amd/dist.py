@@ -1424,6 +1424,13 @@ class _DeviceDist:
         self._ck(self._lib.amgx_dist_apply(self._comm, pb, px, int(b_status), _lib.AMGX_DEVICE_PTR))
         return xs
 
+    def time_kernel(self, level, op=8, reps=20):
+        """amgx_dist_time_kernel (collective): average ms of the level's dominant kernel inside the running cycle"""
+        self._bind_stream()
+        ms = C.c_double()
+        self._ck(self._lib.amgx_dist_time_kernel(self._comm, int(level), int(op), int(reps), C.byref(ms)))
+        return ms.value
+
     def n_exchanges(self):
         ne = C.c_int64()
         self._ck(self._lib.amgx_comm_info(self._comm, None, None, None, C.byref(ne)))
