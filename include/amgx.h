@@ -89,6 +89,13 @@ typedef struct amgx_level_desc {
                               /*   compact blocks (amgh_compact_blocks) freeze fewer couplings, like the mesh-partitioner        */
                               /*   subdomains of the reference's hybrid smoother; colours from amgh_coloring_blockids, dinv     */
                               /*   from amgh_hybrid_dinv_block_ids                                                              */
+  const int32_t* gs_block_color;/* optional, square-block levels with gs_block_rows = B > 0: [n] colour of the SWEEP BLOCK of every  */
+                              /*   block row (a colouring of the block graph, amgh_bgs_coloring: coupled blocks differ; constant     */
+                              /*   inside a block).  A sweep is then one launch per block colour, in place: exact Gauss-Seidel in    */
+                              /*   the order (block colour, block, in-block colour) -- GSS3's loop (gssmoother.cpp:196-257) in a      */
+                              /*   parallel order -- instead of the hybrid form's frozen couplings between blocks; `dinv` is then     */
+                              /*   the plain (pseudo-)inverse of the diagonal blocks (amgh_calc_dinv), no l1 modification.            */
+  int32_t gs_n_block_colors;  /*   number of block colours (0: none, hybrid form)                                                    */
 } amgx_level_desc;
 
 typedef struct amgx_hierarchy_desc {
@@ -326,6 +333,11 @@ int amgx_dist_apply(amgx_comm c, const double* const* b, double* const* x, int b
  * per local rank; x holds the initial guess.  err_k, tol, errs, iters as amgx_pcg. */
 int amgx_dist_pcg(amgx_comm c, const double* const* b, double* const* x, double tol, int maxit, int use_precond, int flags, double* errs,
                   int32_t* iters);
+/* Restarted GMRES(restart), left-preconditioned, on the rank-partitioned level-0 operator, collectively (reference driver:
+ * ngsolve.krylovspace.GMRes on ParallelVectors): Arnoldi inner products = one fused local pass + one ncclAllReduce of j + 1
+ * scalars per Gram-Schmidt pass, Givens rotations on every rank alike.  Arguments as amgx_dist_pcg / amgx_gmres. */
+int amgx_dist_gmres(amgx_comm c, const double* const* b, double* const* x, double tol, int maxit, int restart, int use_precond, int flags,
+                    double* errs, int32_t* iters);
 /* Measurement hook, collective (every rank calls it with the same arguments): `reps` whole cycles with direct launches, HIP
  * events around ONE kernel of the first local rank's level `level` -- op 8: the fused Jacobi pre-smoothing + residual +
  * restriction kernel over the INTERIOR rows (the launch that runs beside the halo exchange); op 9: the backward block-hybrid

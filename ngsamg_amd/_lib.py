@@ -197,7 +197,8 @@ class amgx_level_desc(C.Structure):
                 ("sm_symm", C.c_int32), ("color", c_i32p), ("n_colors", C.c_int32),
                 ("bgs_n_blocks", C.c_int32), ("bgs_block_ptr", c_i32p), ("bgs_block_rows", c_i32p),
                 ("bgs_dinv_ptr", c_i64p), ("bgs_dinv", c_f64p), ("bgs_color", c_i32p), ("bgs_n_colors", C.c_int32),
-                ("Q", amgx_matrix), ("gs_block_rows", C.c_int32), ("gs_block_ids", c_i32p)]
+                ("Q", amgx_matrix), ("gs_block_rows", C.c_int32), ("gs_block_ids", c_i32p),
+                ("gs_block_color", c_i32p), ("gs_n_block_colors", C.c_int32)]
 
 
 class amgx_hierarchy_desc(C.Structure):
@@ -237,7 +238,7 @@ AMGX_SYMBOLS = [
     "amgx_add_c2f", "amgx_coarse_solve", "amgx_n_levels", "amgx_level_info", "amgx_cycle_info", "amgx_matrix_info",
     "amgx_matrix_stream_bytes", "amgx_time_op", "amgx_pcg", "amgx_gmres",
     "amgx_comm_unique_id", "amgx_comm_create", "amgx_comm_destroy", "amgx_comm_last_error", "amgx_comm_set_stream",
-    "amgx_comm_synchronize", "amgx_comm_info", "amgx_comm_graph_info", "amgx_comm_graph_note", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply", "amgx_dist_time_kernel", "amgx_dist_pcg",
+    "amgx_comm_synchronize", "amgx_comm_info", "amgx_comm_graph_info", "amgx_comm_graph_note", "amgx_dist_create", "amgx_dist_destroy", "amgx_dist_apply", "amgx_dist_time_kernel", "amgx_dist_pcg", "amgx_dist_gmres",
     "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
     "amgx_gss4_create", "amgx_gss4_destroy", "amgx_gss4_last_error", "amgx_gss4_set_stream", "amgx_gss4_synchronize",
     "amgx_gss4_info", "amgx_gss4_smooth", "amgx_gss4_smooth_res", "amgx_gss4_mult_add",
@@ -304,6 +305,7 @@ def hip():
     lib.amgx_dist_apply.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_int, C.c_int]
     lib.amgx_dist_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_f64p]
     lib.amgx_dist_pcg.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_int, C.c_int, C.c_int, c_f64p, c_i32p]
+    lib.amgx_dist_gmres.argtypes = [vp, C.POINTER(dp), C.POINTER(dp), C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, c_f64p, c_i32p]
     lib.amgx_dist_rhs_buffer.argtypes = [vp, C.POINTER(dp), c_i64p, c_i64p]
     lib.amgx_dist_handles.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.amgx_halo_create.argtypes = [vp, C.POINTER(amgx_halo_desc), C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(vp)]

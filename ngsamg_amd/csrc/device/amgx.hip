@@ -195,6 +195,16 @@ struct DevBGSB {                        // block-hybrid Gauss-Seidel on square-b
   // blocks scaled by (1 - fac_k), stored negated in `rest` (natural order BSELL): r = rest * x
   DevMatrix rest;
   bool has_split = false;
+  // block-COLOURED form (amgx_level_desc.gs_block_color, bgsb_sweep_kernel): the sweep blocks listed by block colour; a sweep =
+  // one in-place launch per block colour.  `offlo` = the part of `off` a sweep from zero needs: the couplings to swept rows of blocks
+  // with a LOWER block colour (the diagonal blocks and the couplings to rows that are never swept multiply zeros there); `rest` then
+  // holds -(couplings to higher block colours + `upin`): after the sweep from zero r_k = -sum_{j swept after k} A_kj x_j, so sweep
+  // + residual still read A once in total
+  bool bc = false;
+  int n_bcolors = 0;
+  std::vector<int> bc_ptr;              // [n_bcolors + 1] ranges of blk_list
+  DevBuf<int32_t> blk_list;
+  DevMatrix offlo;
   bool on() const { return BB > 0; }
 };
 
@@ -374,7 +384,7 @@ static int pick_lanes(double avg_len) {
 // address path (0.45 T gathers/s measured at the 1.24 M-row level of cfg 2, 4.5 TB/s) -- while G lanes per row walk G
 // consecutive (ascending, hence neighbouring) columns of ONE row.  Lanes per row for rows of this average length:
 static int sell_long_row_lanes(double avg) {
-  int g = avg >= 24.0 ? 4 : 1;
+  int g = 1;        // measured at that level (same box, 1 / 2 / 4 / 8 lanes): 193 / 176 / 188 / 204 us -- no win, the default stays one lane
   if (const char* e = std::getenv("AMGX_SELL_LONG_ROW_LANES")) g = avg >= 24.0 ? std::max(1, std::atoi(e)) : 1;
   return g;
 }
@@ -943,6 +953,7 @@ struct Handle {
   std::string err;
   struct GraphKey { const double* b; double* x; int kind; bool operator<(const GraphKey& o) const { return std::tie(b, x, kind) < std::tie(o.b, o.x, o.kind); } };
   std::map<GraphKey, hipGraphExec_t> graphs;
+  std::vector<GraphKey> graph_age;      // capture order
   // staging for host-pointer calls
   DevBuf<double> stage[3];
   DevBuf<double> stage_raw[3];          // host vectors of permuted levels: raw copy before / after the renumbering
@@ -1264,22 +1275,47 @@ struct Handle {
   void bgsb_sweep(const DevLevel& L, int dir, const double* xin, double* xout, const double* b, bool lower_only = false, int blk0 = 0, int blk1 = -1) {
     Range rg("GSS3<bs=" + std::to_string(L.bs) + ">::SmoothRHS");
     const DevBGSB& g = L.bgsb;
+    const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double) + (size_t)g.BB * sizeof(int);
+    // forward: colour phases over the couplings to lower colours, the upper ones stream with the sweep-start values; backward: reversed
+    const BSellMat IN = dir == 0 ? g.in.bsell.view() : g.upin.bsell.view(), OTH = dir == 0 ? g.upin.bsell.view() : g.in.bsell.view();
+#define LAUNCH_BGSB(BS_, MODE_, OFF_, LIST_, B0_, NB_, XIN_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, MODE_>), dim3(NB_), dim3(BLOCK), lds, stream, g.BB, B0_, LIST_, \
+                                               g.blk_ptr.p, g.blk_rows.p, OFF_, g.off_ptr.p, IN, OTH, g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, XIN_, xout)
+#define LAUNCH_BGSB_BS(MODE_, OFF_, LIST_, B0_, NB_, XIN_)                                       \
+    switch (L.bs) {                                                                              \
+      case 2: LAUNCH_BGSB(2, MODE_, OFF_, LIST_, B0_, NB_, XIN_); break;                         \
+      case 3: LAUNCH_BGSB(3, MODE_, OFF_, LIST_, B0_, NB_, XIN_); break;                         \
+      case 6: LAUNCH_BGSB(6, MODE_, OFF_, LIST_, B0_, NB_, XIN_); break;                         \
+      default: throw Err("block-hybrid Gauss-Seidel: unsupported block size");                   \
+    }
+    if (g.bc) {
+      // block-coloured form: one in-place launch per block colour; from zero (xin == nullptr) the first colour reads nothing
+      // outside its blocks, the later ones the finished blocks of lower colours through `offlo` (lower_only: the split exists)
+      if (blk0 != 0 || (blk1 >= 0 && blk1 != g.n_blocks)) throw Err("block-coloured Gauss-Seidel sweeps cover the whole level");
+      if (xin != nullptr && xin != xout) throw Err("block-coloured Gauss-Seidel sweeps work in place");
+      const bool fz = xin == nullptr;
+      if (fz && dir != 0) throw Err("block-coloured Gauss-Seidel: the sweep from zero is a forward sweep");
+      if (fz && !(lower_only && g.has_split)) throw Err("block-coloured Gauss-Seidel from zero needs the split images (zero x and sweep in place instead)");
+      const BSellMat OFFA = g.off.bsell.view(), OFFL = g.offlo.bsell.view();
+      for (int q = 0; q < g.n_bcolors; ++q) {
+        const int c = dir ? g.n_bcolors - 1 - q : q;
+        const int b0 = g.bc_ptr[c], nb = g.bc_ptr[c + 1] - b0;
+        if (nb <= 0) continue;
+        if (!fz) { LAUNCH_BGSB_BS(0, OFFA, g.blk_list.p, b0, nb, (const double*)xout); }
+        else if (q == 0) { LAUNCH_BGSB_BS(1, OFFL, g.blk_list.p, b0, nb, (const double*)nullptr); }
+        else { LAUNCH_BGSB_BS(2, OFFL, g.blk_list.p, b0, nb, (const double*)xout); }
+      }
+      HIPCHK(hipGetLastError());
+      return;
+    }
     if (blk1 < 0 || blk1 > g.n_blocks) blk1 = g.n_blocks;
     if (blk1 <= blk0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
-    const size_t lds = (size_t)2 * g.BB * L.bs * sizeof(double) + (size_t)g.BB * sizeof(int);
     (void)lower_only;
-    // forward: colour phases over the couplings to lower colours, the upper ones stream with the sweep-start values; backward: reversed
-    const BSellMat OFF = g.off.bsell.view(), IN = dir == 0 ? g.in.bsell.view() : g.upin.bsell.view(), OTH = dir == 0 ? g.upin.bsell.view() : g.in.bsell.view();
-#define LAUNCH_BGSB(BS_, FZ_) hipLaunchKernelGGL((bgsb_sweep_kernel<BS_, FZ_>), dim3(blk1 - blk0), dim3(BLOCK), lds, stream, g.BB, blk0, g.blk_ptr.p, g.blk_rows.p, OFF, g.off_ptr.p, IN, OTH, \
-                                               g.in_ptr.p, g.in_row.p, g.n_colors, dir, L.dinv.p, b, xin, xout)
+    const BSellMat OFF = g.off.bsell.view();
     const bool fz = xin == nullptr;
-    switch (L.bs) {
-      case 2: if (fz) LAUNCH_BGSB(2, true); else LAUNCH_BGSB(2, false); break;
-      case 3: if (fz) LAUNCH_BGSB(3, true); else LAUNCH_BGSB(3, false); break;
-      case 6: if (fz) LAUNCH_BGSB(6, true); else LAUNCH_BGSB(6, false); break;
-      default: throw Err("block-hybrid Gauss-Seidel: unsupported block size");
-    }
+    if (fz) { LAUNCH_BGSB_BS(1, OFF, (const int32_t*)nullptr, blk0, blk1 - blk0, xin); }
+    else { LAUNCH_BGSB_BS(0, OFF, (const int32_t*)nullptr, blk0, blk1 - blk0, xin); }
+#undef LAUNCH_BGSB_BS
 #undef LAUNCH_BGSB
     HIPCHK(hipGetLastError());
   }
@@ -1351,8 +1387,11 @@ struct Handle {
       bgs_sweep(L, dir, x, b);
       if (update_res) residual(L.A, x, b, res);
     } else if (L.bgsb.on()) {
-      copy(L.tmp.p, x, L.ext_len());
-      bgsb_sweep(L, dir, L.tmp.p, x, b);
+      if (L.bgsb.bc) bgsb_sweep(L, dir, x, x, b);           // block-coloured form: in place
+      else {
+        copy(L.tmp.p, x, L.ext_len());
+        bgsb_sweep(L, dir, L.tmp.p, x, b);
+      }
       if (update_res) residual(L.A, x, b, res);
     } else if (L.gsb.on()) {
       // block-hybrid sweep (out of place: the off-block values are those from the start of the sweep)
@@ -1420,6 +1459,10 @@ struct Handle {
       if (L.bgsb.has_split) {
         bgsb_sweep(L, 0, nullptr, x, b, true);
         mult(L.bgsb.rest, x, r);
+      } else if (L.bgsb.bc) {
+        zero(x, L.len());                      // (pseudo-inverted diagonal blocks: no split images)
+        bgsb_sweep(L, 0, x, x, b);
+        residual(L.A, x, b, r);
       } else {
         bgsb_sweep(L, 0, nullptr, x, b);
         residual(L.A, x, b, r);
@@ -1501,7 +1544,14 @@ struct Handle {
                              L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
 #define LAUNCH_PRG(G_) hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 0, 4, G_>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
                              L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
-        if (G > 1) {
+        if (L.Apre.sell.win) {
+          if (FB != SELL_WIN || G != 1) throw Err("fused restriction on a windowed image: unexpected chunk shape");
+#define LAUNCH_WPR(EPT_) hipLaunchKernelGGL((sell_win_pre_restrict_kernel<SELL_WIN, EPT_>), dim3(grid), dim3(SELL_WIN), 0, stream, L.Apre.n_rows, c0, L.Apre.sell.view(), \
+                             L.Apre.sell.rowloc.p, b, L.dinv.p, L.omega, epf, x, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+          if (R.ept == 4) LAUNCH_WPR(4); else LAUNCH_WPR(6);
+#undef LAUNCH_WPR
+        }
+        else if (G > 1) {
           if (FB != 512 || R.ept != 4) throw Err("fused restriction with several lanes per row: unexpected chunk shape");
           if (G == 2) LAUNCH_PRG(2); else if (G == 4) LAUNCH_PRG(4); else LAUNCH_PRG(8);
         }
@@ -1568,11 +1618,18 @@ struct Handle {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       jacobi_fused(L, L.tmp.p, b, x);      // x = tmp + omega * Dinv * (b - A tmp); res is not needed afterwards
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.bgsb.on()) {
-      mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
+      if (L.bgsb.bc) {
+        mult_add(L.P, 1.0, xc, x, x);      // x += P x_c
+        if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
+        bgsb_sweep(L, 1, x, x, b);         // backward block-coloured sweep, in place (one launch per block colour)
+        if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
+      } else {
+      mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       bgsb_sweep(L, 1, L.tmp.p, x, b);     // backward block-hybrid sweep, tmp -> x
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
+      }
     } else if (plain(L) && L.sm_type == AMGX_SM_GS && L.gsb.on() && L.n == L.ncols) {
       mult_add(L.P, 1.0, xc, x, L.tmp.p);  // tmp = x + P x_c
       const bool probe = probe_level == l && probe_kind == 9 && probe_e0;
@@ -1707,8 +1764,13 @@ struct Handle {
       hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (e != hipSuccess) throw Err(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
-      if (graphs.size() >= 16) { for (auto& q : graphs) (void)hipGraphExecDestroy(q.second); graphs.clear(); }
+      if (graphs.size() >= 16 && !graph_age.empty()) {       // the oldest capture goes, the hot ones stay
+        auto old = graphs.find(graph_age.front());
+        graph_age.erase(graph_age.begin());
+        if (old != graphs.end()) { (void)hipGraphExecDestroy(old->second); graphs.erase(old); }
+      }
       it = graphs.emplace(key, ge).first;
+      graph_age.push_back(key);
     }
     HIPCHK(hipGraphLaunch(it->second, stream));
   }
@@ -1716,6 +1778,7 @@ struct Handle {
   void drop_graphs() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
     graphs.clear();
+    graph_age.clear();
   }
 };
 
@@ -2222,6 +2285,39 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L, const DevBcsrSrc* 
     for (char c : bad2) if (c) throw Err("invalid blocked colouring: two coupled block rows of one sweep block share a colour");
   }
   g.BB = BB; g.n_blocks = nblk; g.n_colors = nc;
+  // block-coloured form: colour of every sweep block (constant inside a block, coupled blocks differ)
+  std::vector<int32_t> bcol;
+  if (d.gs_block_color && d.gs_n_block_colors > 0) {
+    if (d.A.n_cols != n) throw Err("block-coloured Gauss-Seidel: square levels only (rank-partitioned levels sweep in the hybrid form)");
+    const int nbc = d.gs_n_block_colors;
+    bcol.assign((size_t)nblk, -1);
+    for (int64_t i = 0; i < n; ++i) {
+      const int c = d.gs_block_color[i];
+      if (c < 0 || c >= nbc) throw Err("gs_block_color: colour out of range");
+      if (bcol[blk_of[i]] < 0) bcol[blk_of[i]] = c;
+      else if (bcol[blk_of[i]] != c) throw Err("gs_block_color: not constant inside a sweep block");
+    }
+    std::vector<char> bad3(setup_threads(), 0);
+    par_for(n, [&](int64_t i0, int64_t i1, int t) {
+      for (int64_t i = i0; i < i1; ++i) {
+        if (d.color[i] < 0) continue;
+        for (int64_t k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; ++k) {
+          const int64_t j = d.A.col[k];
+          if (d.color[j] >= 0 && blk_of[j] != blk_of[i] && bcol[blk_of[j]] == bcol[blk_of[i]]) { bad3[t] = 1; return; }
+        }
+      }
+    });
+    for (char c : bad3) if (c) throw Err("invalid block colouring: two coupled sweep blocks share a colour (an in-place sweep would race)");
+    std::vector<int32_t> list((size_t)nblk);
+    g.bc_ptr.assign((size_t)nbc + 1, 0);
+    for (int q = 0; q < nblk; ++q) g.bc_ptr[bcol[q] + 1]++;
+    for (int c = 0; c < nbc; ++c) g.bc_ptr[c + 1] += g.bc_ptr[c];
+    std::vector<int> pos(g.bc_ptr.begin(), g.bc_ptr.end() - 1);
+    for (int q = 0; q < nblk; ++q) list[pos[bcol[q]]++] = q;
+    g.blk_list.upload(list);
+    g.bc = true;
+    g.n_bcolors = nbc;
+  }
   // off: block by block in list order, every block padded to whole slices
   std::vector<int32_t> rows_off, off_ptr(nblk + 1, 0);
   rows_off.reserve((size_t)n + (size_t)nblk * RB);
@@ -2247,6 +2343,17 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L, const DevBcsrSrc* 
     dev_build_bsell(*csr, d_rows.p, (int64_t)rows_off.size(), BB_OFF, maps, 0, 0.0, g.off);
   } else
   build_bsell_sel(d.A, rows_off, [&](int32_t i, int32_t j) { return !lower_in(i, j) && !upper_in(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.off);
+  // block-coloured form: which entries of `off` couple to a sweep block that a FORWARD sweep visits later (the "high" part);
+  // everything else of `off` (diagonal blocks, couplings to earlier blocks, couplings to rows that are never swept) is "low"
+  auto off_high = [&](int32_t i, int32_t j) { return j != i && j < n && !same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && bcol[blk_of[j]] > bcol[blk_of[i]]; };
+  auto off_low = [&](int32_t i, int32_t j) { return j != i && j < n && !same_block(i, j) && d.color[i] >= 0 && d.color[j] >= 0 && bcol[blk_of[j]] < bcol[blk_of[i]]; };
+  DevBuf<int32_t> d_bcol;
+  if (g.bc && csr) {
+    std::vector<int32_t> bcr((size_t)n);
+    for (int64_t i = 0; i < n; ++i) bcr[i] = bcol[blk_of[i]];
+    d_bcol.upload(bcr);
+    maps.bcolor = d_bcol.p;
+  }
   // in: per block the swept rows by colour, every (block, colour) group padded to whole slices
   std::vector<int32_t> rows_in, in_ptr((size_t)nblk * nc + 1, 0), in_row;
   for (int blk = 0; blk < nblk; ++blk) {
@@ -2297,6 +2404,22 @@ static void build_bgsb(const amgx_level_desc& d, DevLevel& L, const DevBcsrSrc* 
   std::vector<int32_t> rows_nat;
   for (int64_t i = 0; i < n; ++i) rows_nat.push_back((int32_t)i);
   while (rows_nat.size() % RB) rows_nat.push_back(-1);
+  if (g.bc) {
+    // block-coloured form: the plain inverse is expected (fac = 1 everywhere), otherwise no split (sweep + full residual)
+    for (int64_t i = 0; i < n; ++i) if (d.color[i] >= 0 && std::fabs(fac[i] - 1.0) > 1e-10) return;
+    if (csr) {
+      d_rows.upload(rows_off);
+      dev_build_bsell(*csr, d_rows.p, (int64_t)rows_off.size(), BB_OFFLO, maps, 0, 0.0, g.offlo);
+      d_rows.upload(rows_nat);
+      dev_build_bsell(*csr, d_rows.p, (int64_t)rows_nat.size(), BB_RESTBC, maps, 0, 0.0, g.rest);
+    } else {
+      build_bsell_sel(d.A, rows_off, off_low, [](int32_t, int32_t j) { return j; }, 0, g.offlo);
+      build_bsell_sel(d.A, rows_nat, [&](int32_t i, int32_t j) { return upper_in(i, j) || off_high(i, j); }, [](int32_t, int32_t j) { return j; }, 0, g.rest,
+                      [](int32_t, int32_t) { return -1.0; });
+    }
+    g.has_split = true;
+    return;
+  }
   if (csr) {
     d_fac.upload(fac);
     maps.fac = d_fac.p;
@@ -2600,12 +2723,16 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     L.sm_type = s.sm_type; L.omega = s.omega; L.sm_steps = s.sm_steps; L.sm_symm = s.sm_symm;
     if (s.sm_type != AMGX_SM_JACOBI && s.sm_type != AMGX_SM_GS && s.sm_type != AMGX_SM_BGS) throw Err("unknown smoother type");
     const bool last = (l + 1 == d->n_levels);
+    check_matrix(s.A, "A");            // (before anything reads rowptr[n_rows]: a NULL / garbage descriptor is an error, not a crash)
+    // (declared BEFORE the task pool: its worker lambdas capture these by reference, and an exception between tasks.run() and
+    //  tasks.wait() must join the workers -- ~SetupTasks -- before the buffers they read are freed)
+    DevCsrSrc csrA;
+    DbDiagInfo diagA;
+    DevBcsrSrc csrB;
     SetupTasks tasks(d->device);
     // big scalar levels: the CSR arrays go to the device once and kernels write the images of A, A' and Q there (devbuild.hpp)
     const bool dev_images = dev_images_wanted(s.A);
     const bool verify_images = dev_images && std::getenv("AMGX_VERIFY_IMAGES") != nullptr;
-    DevCsrSrc csrA;
-    DbDiagInfo diagA;
     if (dev_images) {
       check_matrix(s.A, "A");
       csrA.upload(s.A);
@@ -2618,7 +2745,6 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
     const bool keep_csr_A = s.sm_type == AMGX_SM_GS && s.A.br > 1 && s.gs_block_rows == 0;
     const bool dev_bsell = dev_bsell_wanted(s.A) && s.A.n_rows == s.A.n_cols && !keep_csr_A;
     const bool verify_bsell = dev_bsell && std::getenv("AMGX_VERIFY_IMAGES") != nullptr;
-    DevBcsrSrc csrB;
     if (dev_bsell) {
       check_matrix(s.A, "A");
       csrB.upload(s.A);
@@ -2679,6 +2805,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             verify_same_bsell(x.in, y.in, "block-hybrid Gauss-Seidel: in");
             verify_same_bsell(x.upin, y.upin, "block-hybrid Gauss-Seidel: upin");
             if (x.has_split) verify_same_bsell(x.rest, y.rest, "block-hybrid Gauss-Seidel: rest");
+            if (x.bc != y.bc || x.n_bcolors != y.n_bcolors) throw Err("AMGX_VERIFY_IMAGES: block-coloured Gauss-Seidel: the descriptors differ");
+            if (x.bc && x.has_split) verify_same_bsell(x.offlo, y.offlo, "block-coloured Gauss-Seidel: offlo");
           }
         }
         else if (s.sm_type == AMGX_SM_GS && s.gs_block_rows > 0) {
@@ -2710,7 +2838,13 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
           // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
           const int G = L.Apre.lanes;
-          if (L.Apre.fmt == FMT_SELL && !L.Apre.sell.win && (G == 1 || G == 2 || G == 4 || G == 8) && s.P.br == 1 && s.P.bc == 1 &&
+          if (L.Apre.fmt == FMT_SELL && L.Apre.sell.win == SELL_WIN && G == 1 && SELL_WIN == 512 && s.P.br == 1 && s.P.bc == 1 &&
+              s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
+          {
+            L.fused_block = SELL_WIN;              // windowed A': a chunk = a window (sell_win_pre_restrict_kernel)
+            build_restrict(s.P, L.RF, SELL_WIN, 6 * SELL_WIN, SELL_WIN);
+          }
+          else if (L.Apre.fmt == FMT_SELL && !L.Apre.sell.win && (G == 1 || G == 2 || G == 4 || G == 8) && s.P.br == 1 && s.P.bc == 1 &&
               s.P.rowptr[s.P.n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT") && !(G > 1 && std::getenv("AMGX_NO_FUSED_RESTRICT_MULTI")))
           {
             L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
@@ -2722,7 +2856,10 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         // (device builder: A' = A diag(omega Dinv) from the CSR of A that is already there; the diagonal slot carries omega*Dinv_i
         //  under the same conditions as below)
         const bool dev_wdiag = s.omega != 0.0 && !std::getenv("AMGX_NO_WDIAG") && diagA.plain;
-        if (dev_images && !verify_images && dev_upload_matrix(csrA, L.Apre, true, 1.35, 0, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) {
+        // levels >= 1 of a reference-shaped hierarchy have ragged long rows: A' takes the length-sorted windowed form there when
+        // plain slices would pad more than 10 % (level 0's FEM rows are uniform and keep the diagonal-first plain form)
+        const int apre_win = (l >= 1 && s.A.n_rows == s.A.n_cols && !std::getenv("AMGX_NO_APRE_WINDOW")) ? SELL_WIN : 0;
+        if (dev_images && !verify_images && dev_upload_matrix(csrA, L.Apre, true, 1.35, apre_win, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) {
           fused_restrict();
           return;
         }
@@ -2756,12 +2893,12 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         }
         if (dev_images && verify_images) {
           DevMatrix H;
-          upload_matrix(As, H, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
-          if (dev_upload_matrix(csrA, L.Apre, true, 1.35, 0, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) verify_same_image(L.Apre, H, "A'");
+          upload_matrix(As, H, "A (pre-smoothing image)", true, true, false, 1.35, apre_win, wdv.empty() ? nullptr : wdv.data());
+          if (dev_upload_matrix(csrA, L.Apre, true, 1.35, apre_win, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) verify_same_image(L.Apre, H, "A'");
           else if (H.fmt == FMT_SELL && H.lanes == 1) throw Err("AMGX_VERIFY_IMAGES: the device builder declined A' where the host builder forms a SELL image");
           else L.Apre = std::move(H);
         } else
-          upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, 0, wdv.empty() ? nullptr : wdv.data());
+          upload_matrix(As, L.Apre, "A (pre-smoothing image)", true, true, false, 1.35, apre_win, wdv.empty() ? nullptr : wdv.data());
         fused_restrict();
         }, "A' + fused restriction");
         // post-smoothing folded into the prolongation (V-cycle).  Square levels: Q is built here.  Rank-partitioned

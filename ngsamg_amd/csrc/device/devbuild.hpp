@@ -297,13 +297,18 @@ __global__ __launch_bounds__(BLOCK) void db_split_fill_kernel(DbSplit a, const i
 //   BB_IN    in-block couplings to LOWER colours, block-local column           (colour phases of a forward sweep)
 //   BB_UPIN  in-block couplings to HIGHER colours, block-local column
 //   BB_REST  everything but BB_IN, negated, diagonal blocks scaled by fac - 1  (r = rest x after the sweep from zero)
-enum : int { BB_ALL = 0, BB_OFF = 1, BB_IN = 2, BB_UPIN = 3, BB_REST = 4 };
+//   block-coloured form (bcolor = block colour of every row's sweep block):
+//   BB_OFFLO  the couplings to swept rows of OTHER blocks with a LOWER block colour (no diagonal blocks, no couplings to rows that are
+//             never swept: in a sweep from zero both multiply zeros -- or stale values of blocks the sweep has not reached yet)
+//   BB_RESTBC the couplings to swept rows of blocks with a HIGHER block colour + BB_UPIN, negated, global columns
+//             (r = rest x after that sweep)
+enum : int { BB_ALL = 0, BB_OFF = 1, BB_IN = 2, BB_UPIN = 3, BB_REST = 4, BB_OFFLO = 5, BB_RESTBC = 6 };
 struct DbBsell {
   int64_t m, n, ns;                     // list entries (padded to whole slices), block rows of the matrix, slices
   int bs, sel;
   const int32_t* rows;                  // block row of every list entry (-1: padding slot); null: natural order
   const int64_t* rowptr; const int32_t* col; const double* val;
-  const int32_t* blk_of; const int32_t* lpos; const int32_t* color; const double* fac;
+  const int32_t* blk_of; const int32_t* lpos; const int32_t* color; const double* fac; const int32_t* bcolor;
   int64_t* sp;                          // [ns + 1] cumulative block steps
   int32_t* ocol; double* oval;
 };
@@ -311,10 +316,14 @@ __device__ __forceinline__ bool db_bsell_keep(const DbBsell& a, int64_t i, int64
   if (a.sel == BB_ALL) return true;
   const bool same = j < a.n && j != i && a.blk_of[i] == a.blk_of[j] && a.color[i] >= 0 && a.color[j] >= 0;
   const bool lower = same && a.color[j] < a.color[i], upper = same && a.color[j] > a.color[i];
+  const bool other = (a.sel == BB_OFFLO || a.sel == BB_RESTBC) && j < a.n && j != i && a.blk_of[i] != a.blk_of[j] && a.color[i] >= 0 && a.color[j] >= 0;
+  const bool high = other && a.bcolor[j] > a.bcolor[i], low = other && a.bcolor[j] < a.bcolor[i];
   switch (a.sel) {
     case BB_OFF: return !lower && !upper;
     case BB_IN: return lower;
     case BB_UPIN: return upper;
+    case BB_OFFLO: return low;
+    case BB_RESTBC: return upper || high;
     default: return !lower;
   }
 }
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(DB_BLOCK) void db_bsell_fill_kernel(DbBsell a) {
     const int32_t j = a.col[k];
     if (!db_bsell_keep(a, i, j)) continue;
     if (rr == 0) a.ocol[kk * RB + rb] = (a.sel == BB_IN || a.sel == BB_UPIN) ? a.lpos[j] : j;
-    const double sc = a.sel == BB_REST ? ((i == j && a.color[i] >= 0) ? a.fac[i] - 1.0 : -1.0) : 1.0;
+    const double sc = a.sel == BB_REST ? ((i == j && a.color[i] >= 0) ? a.fac[i] - 1.0 : -1.0) : (a.sel == BB_RESTBC ? -1.0 : 1.0);
     const double* __restrict__ blk = a.val + k * (bs * bs) + rr * bs;
     double* __restrict__ vk = a.oval + kk * (bs * WAVE);
     for (int c = 0; c < bs; ++c) {
@@ -547,7 +556,7 @@ struct DevBcsrSrc {                      // a square-block CSR matrix on the dev
     val.upload(A.val, (size_t)std::max<int64_t>(1, nnz) * bs * bs);
   }
 };
-struct DbBgsbMaps { const int32_t* blk_of = nullptr; const int32_t* lpos = nullptr; const int32_t* color = nullptr; const double* fac = nullptr; };
+struct DbBgsbMaps { const int32_t* blk_of = nullptr; const int32_t* lpos = nullptr; const int32_t* color = nullptr; const double* fac = nullptr; const int32_t* bcolor = nullptr; };
 
 static bool dev_bsell_wanted(const amgx_matrix& A) {
   if (std::getenv("AMGX_HOST_IMAGES") || std::getenv("AMGX_NO_BSELL")) return false;
@@ -568,7 +577,7 @@ static bool dev_build_bsell(const DevBcsrSrc& A, const int32_t* d_rows, int64_t 
   const int64_t ns = (m + RB - 1) / RB;
   DevBuf<int64_t> sp;
   sp.alloc((size_t)ns + 1);
-  DbBsell a{m, A.n_rows, ns, bs, sel, d_rows, A.rowptr.p, A.col.p, A.val.p, mp.blk_of, mp.lpos, mp.color, mp.fac, sp.p, nullptr, nullptr};
+  DbBsell a{m, A.n_rows, ns, bs, sel, d_rows, A.rowptr.p, A.col.p, A.val.p, mp.blk_of, mp.lpos, mp.color, mp.fac, mp.bcolor, sp.p, nullptr, nullptr};
   if (ns == 0) HIPCHK(hipMemset(sp.p, 0, sizeof(int64_t)));
   else {
     hipLaunchKernelGGL(db_bsell_width_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, a);

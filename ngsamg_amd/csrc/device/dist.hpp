@@ -148,7 +148,20 @@ struct Comm {
   int64_t n_direct_runs = 0;             // applications launched directly; the first one always is (see dist_apply)
   int64_t n_graph_replays = 0;
   std::string graph_note;
-  void drop_graphs() { for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec); graphs.clear(); }
+  void drop_graphs() { for (auto& g : graphs) (void)hipGraphExecDestroy(g.second.exec); graphs.clear(); graph_age.clear(); }
+  std::vector<GKey> graph_age;           // capture order: at 16 graphs the OLDEST one goes, not the hot ones
+  void evict_oldest_graph() {
+    while (!graph_age.empty()) {
+      auto it = graphs.find(graph_age.front());
+      graph_age.erase(graph_age.begin());
+      if (it != graphs.end()) { (void)hipGraphExecDestroy(it->second.exec); graphs.erase(it); return; }
+    }
+    drop_graphs();
+  }
+  // workspace of amgx_dist_pcg / amgx_dist_gmres (DistKrylov), kept across solves so that its vector addresses -- the key of the
+  // preconditioner's whole-cycle graph -- stay the same
+  std::shared_ptr<void> krylov_ws;
+  size_t krylov_members = 0;
 
   Comm() { for (int i = 0; i < NEV; ++i) { ev_ready[i] = nullptr; ev_done[i] = nullptr; } }
   ~Comm() {
@@ -314,6 +327,8 @@ struct Dist {
   bool fold = true;
   bool overlap = true;
   bool gsb = false;                      // Gauss-Seidel levels in the block-hybrid form
+  bool generic = false;                  // sm_steps > 1 / sm_symm on a rank-partitioned level, or a W-cycle: the step-by-step driver
+  int cycle = AMGX_CYCLE_V;              //   (DistCycle::generic_cycle) instead of the specialised V(1,1) stage sequences
   std::vector<HaloTable> halo;           // [k]
   std::vector<std::array<int, 4>> stage; // [k] colour ranges of the hybrid Gauss-Seidel stages: [s0,s1) first local part,
                                          //     [s1,s2) boundary ("EX") rows, [s2,s3) second local part (gssmoother.cpp:721-782)
@@ -353,9 +368,14 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   if (!d->halo || !d->counts || !d->kmap) throw Err("amgx_dist_create: halo tables / level-k tables missing");
   D->sm_type = d->top.levels[0].sm_type;
   D->fold = d->fold != 0;
+  D->cycle = d->top.cycle;
+  if (D->cycle != AMGX_CYCLE_V && D->cycle != AMGX_CYCLE_W) throw Err("amgx_dist_create: rank-partitioned hierarchies run V and W cycles");
+  if (d->tail.cycle != d->top.cycle) throw Err("amgx_dist_create: the replicated tail must run the same cycle as the rank-partitioned levels");
+  if (D->cycle == AMGX_CYCLE_W) D->generic = true;
   D->overlap = !std::getenv("AMGX_DIST_NO_OVERLAP");
   amgx_hierarchy_desc td = d->top;
   td.device = c->device; td.use_graph = 0; td.clev = AMGX_CLEV_NONE; td.coarse_n = 0; td.coarse_inv = nullptr;
+  td.cycle = AMGX_CYCLE_V;                 // (the top handle is driven stage by stage: its own cycle type plays no role)
   D->top.reset(create(&td, -1));           // (driven stage by stage: no collapsed coarse levels)
   amgx_hierarchy_desc ld = d->tail;
   ld.device = c->device;
@@ -368,7 +388,8 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   for (int l = 0; l < k; ++l) {
     const amgx_level_desc& s = d->top.levels[l];
     if (s.sm_type != D->sm_type) throw Err("amgx_dist_create: all rank-partitioned levels must use the same smoother");
-    if (s.sm_steps > 1 || s.sm_symm) throw Err("amgx_dist_create: sm_steps / sm_symm are not supported on rank-partitioned levels");
+    if (s.sm_steps > 1 || s.sm_symm) D->generic = true;      // ProxySmoother on a rank-partitioned level (base_smoother.hpp:169-229)
+    if (s.sm_steps != d->top.levels[0].sm_steps || s.sm_symm != d->top.levels[0].sm_symm) throw Err("amgx_dist_create: all rank-partitioned levels must use the same sm_steps / sm_symm");
     D->halo[l].build(d->halo[l], s.A.n_rows, s.A.n_cols, s.A.br, c->nranks, self);
     dist_check_interior(s.A, D->halo[l].n_int);
     if (D->fold && s.Q.rowptr) {           // the way up splits the same way: interior rows of Q must not read coarse ghosts
@@ -404,12 +425,14 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
       const amgx_halo_desc& hd = d->halo[l];
       const int64_t ns = hd.n_peers > 0 ? hd.send_ptr[hd.n_peers] : 0;
       if (D->top->lev[l].bgsb.on() && s.gs_block_ids) throw Err("amgx_dist_create: rank-partitioned block levels sweep runs of consecutive rows (no gs_block_ids)");
+      if (D->top->lev[l].bgsb.bc) throw Err("amgx_dist_create: rank-partitioned block levels sweep in the hybrid form (no gs_block_color)");
       const int64_t B = D->top->lev[l].gsb.on() ? D->top->lev[l].gsb.B : D->top->lev[l].bgsb.BB;
       const int64_t first_bnd = (D->halo[l].n_int / B) * B;
       for (int64_t i = 0; i < ns; ++i)
         if (hd.send_idx[i] < first_bnd) { D->send_early[l] = 0; break; }
     }
   }
+  if (D->fold && D->generic) throw Err("amgx_dist_create: fold is the V(1,1) Jacobi form (no sm_steps / sm_symm / W-cycle)");
   if (D->fold) {
     if (D->sm_type != AMGX_SM_JACOBI) throw Err("amgx_dist_create: fold needs Jacobi levels");
     for (int l = 0; l < k; ++l) if (!D->top->folded(D->top->lev[l])) throw Err("amgx_dist_create: fold requested but level " + std::to_string(l) + " has no Q");
@@ -424,7 +447,7 @@ static Dist* dist_create(Comm* c, const amgx_dist_desc* d) {
   auto zalloc = [&](DevBuf<double>& b, int64_t len) { b.alloc((size_t)std::max<int64_t>(1, len)); HIPCHK(hipMemset(b.p, 0, std::max<int64_t>(1, len) * sizeof(double))); };
   for (int l = 0; l < k; ++l) {
     zalloc(D->bext[l], D->next(l)); zalloc(D->xext[l], D->next(l)); zalloc(D->rl[l], D->n(l));
-    if ((!D->fold && D->sm_type == AMGX_SM_JACOBI) || D->gsb) zalloc(D->text[l], D->next(l));
+    if ((!D->fold && D->sm_type == AMGX_SM_JACOBI) || D->gsb || D->generic) zalloc(D->text[l], D->next(l));
   }
   // level k: gathered in rank order
   D->counts.assign(d->counts, d->counts + c->nranks);
@@ -683,6 +706,97 @@ struct DistCycle {
       }
     }
   }
+
+  // ---- step-by-step driver: sm_steps / sm_symm (ProxySmoother, base_smoother.hpp:169-229: k x Smooth, or k x (Smooth + SmoothBack)
+  //      for the pre- AND the post-smoothing) and the W-cycle (AMGMatrix::SmoothW, amg_matrix.cpp:37-107) on rank-partitioned
+  //      levels.  Every smoothing step is one step of the parallel smoother (hybrid_base_smoother.cpp:246-289): owner -> ghost
+  //      exchange of x, then the local step with the ghost values frozen (Jacobi: x + w Dinv (b - (M + G) x); Gauss-Seidel: the
+  //      staged / block-hybrid sweep).  No interior / boundary overlap here: one exchange, one launch per step.
+  struct GenState { std::vector<double*> cur, oth; };        // per level: the [owned | ghost] buffer that holds x, and the spare one
+  std::vector<GenState> gx;
+  std::vector<const double*> gb0;
+  const double* gbl(size_t i, int l) { return l == 0 ? gb0[i] : (const double*)M[i]->bext[l].p; }
+  void gen_exchange(int l) {
+    std::vector<Comm::Item> it;
+    for (size_t i = 0; i < M.size(); ++i) it.push_back({&M[i]->halo[l], gx[l].cur[i]});
+    c.exchange_end(c.exchange_begin(it));
+  }
+  void gen_step(int l, int dir, bool x_zero) {
+    if (!x_zero) gen_exchange(l);                              // (from x = 0 the ghost values are zeros already)
+    for (size_t i = 0; i < M.size(); ++i) {
+      Dist* d = M[i];
+      Handle& h = *d->top;
+      DevLevel& L = h.lev[l];
+      double*& cur = gx[l].cur[i];
+      double*& oth = gx[l].oth[i];
+      const double* b = gbl(i, l);
+      if (d->sm_type == AMGX_SM_JACOBI) { h.jacobi_fused(L, cur, b, oth); std::swap(cur, oth); }
+      else if (L.bgsb.on()) { h.bgsb_sweep(L, dir, cur, oth, b); std::swap(cur, oth); }
+      else if (L.gsb.on()) { h.gsb_sweep(L, dir, L.gsb.full, cur, oth, b); std::swap(cur, oth); }
+      else if (d->sm_type == AMGX_SM_BGS) h.bgs_sweep(L, dir, cur, b);
+      else h.gs_sweep(L, dir, cur, b);
+    }
+  }
+  // k steps in direction dir, or k x (forward, backward) with sm_symm
+  void gen_smooth(int l, int dir, bool x_zero) {
+    const DevLevel& L0 = M[0]->top->lev[l];
+    const int k = std::max(1, L0.sm_steps);
+    for (int j = 0; j < k; ++j) {
+      if (L0.sm_symm) { gen_step(l, 0, x_zero && j == 0); gen_step(l, 1, false); }
+      else gen_step(l, dir, x_zero && j == 0);
+    }
+  }
+  void gen_zero(int l) { for (size_t i = 0; i < M.size(); ++i) M[i]->top->zero(gx[l].cur[i], M[i]->next(l)); }
+  void gen_residual_restrict(int l) {                          // r = b - (M + G) x, b_{l+1} = P^T r  (P is rank-local: no exchange)
+    gen_exchange(l);
+    for (size_t i = 0; i < M.size(); ++i) {
+      Dist* d = M[i];
+      d->top->residual(d->top->lev[l].A, gx[l].cur[i], gbl(i, l), d->rl[l].p);
+      d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l));
+    }
+  }
+  void gen_prolong(int l) {                                    // x_l += P x_{l+1}
+    const int k = M[0]->k;
+    for (size_t i = 0; i < M.size(); ++i) {
+      Dist* d = M[i];
+      const double* xc = l + 1 < k ? (const double*)gx[l + 1].cur[i] : (const double*)d->xk_ext.p;
+      d->top->mult_add(d->top->lev[l].P, 1.0, xc, gx[l].cur[i], gx[l].cur[i]);
+    }
+  }
+  void gen_v(int l) {
+    const int k = M[0]->k;
+    if (l == k) { gather_level_k(); tail_and_pick(); return; }
+    gen_zero(l);
+    gen_smooth(l, 0, true);
+    gen_residual_restrict(l);
+    gen_v(l + 1);
+    gen_prolong(l);
+    gen_smooth(l, 1, false);
+  }
+  void gen_w(int l) {                                          // Handle::w_rec on rank-partitioned levels
+    const int k = M[0]->k;
+    if (l == k) { gather_level_k(); tail_and_pick(); return; }
+    gen_zero(l);
+    gen_smooth(l, 0, true);
+    gen_residual_restrict(l);
+    gen_w(l + 1);
+    gen_prolong(l);
+    gen_smooth(l, 1, false);
+    gen_smooth(l, 0, false);
+    gen_residual_restrict(l);
+    gen_w(l + 1);
+    gen_prolong(l);
+    gen_smooth(l, 1, false);
+  }
+  void generic_cycle(const std::vector<const double*>& b0) {
+    const int k = M[0]->k;
+    gb0 = b0;
+    gx.assign(k, GenState());
+    for (int l = 0; l < k; ++l)
+      for (Dist* d : M) { gx[l].cur.push_back(d->xext[l].p); gx[l].oth.push_back(d->text[l].p); }
+    if (M[0]->cycle == AMGX_CYCLE_W) gen_w(0); else gen_v(0);
+    for (size_t i = 0; i < M.size(); ++i) M[i]->top->copy(x[i], gx[0].cur[i], M[i]->n(0));
+  }
 };
 
 // b_status 0 (DISTRIBUTED): b carries [owned | ghost] entries and the ghost entries are contributions to their owners
@@ -740,7 +854,8 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     for (Dist* d : M) it.push_back({&d->halo[0], d->bext[0].p});
     c.accumulate(it);
   }
-  if (M[0]->sm_type == AMGX_SM_JACOBI) { if (M[0]->fold) cy.jacobi_folded(); else cy.jacobi_literal(); }
+  if (M[0]->generic) cy.generic_cycle(b0);
+  else if (M[0]->sm_type == AMGX_SM_JACOBI) { if (M[0]->fold) cy.jacobi_folded(); else cy.jacobi_literal(); }
   else if (M[0]->gsb) cy.hybrid_gsb(b0);
   else cy.hybrid_gs(b0);
   };
@@ -754,9 +869,10 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
     hipGraphExec_t ge = nullptr;
     if (ok && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
       (void)hipGraphDestroy(g);
-      if (c.graphs.size() >= 16) c.drop_graphs();
+      if (c.graphs.size() >= 16) c.evict_oldest_graph();
       const int64_t nex = c.n_exchanges - ex0;
       c.graphs.emplace(key, Comm::GVal{ge, nex});
+      c.graph_age.push_back(key);
       HIPCHK(hipGraphLaunch(ge, c.compute));
       ++c.n_graph_replays;
       return;
@@ -785,6 +901,21 @@ static void dist_apply(Comm& c, const double* const* b, double* const* x, int b_
 // ncclAllReduce of one device scalar here, deterministic local reductions), the preconditioner is the collective cycle
 // (dist_apply, replayed from its graph).  The residual lives in the level-0 right-hand-side buffer of the cycle, so
 // the preconditioner reads it in place.  err_k = sqrt(|<C r_k, r_k>|); stop at err_k <= tol * err_0.
+// out[j] = sum over the local ranks i and their KR_BLOCKS partials of product j (partial laid out [rank][64][KR_BLOCKS]); fixed order
+__global__ __launch_bounds__(BLOCK) void kr_dist_multi_final_kernel(int n_local, const double* __restrict__ partial, double* __restrict__ out) {
+  __shared__ double red[BLOCK];
+  const int j = blockIdx.x;
+  double acc = 0.0;
+  for (int i = 0; i < n_local; ++i) {
+    const double* p = partial + ((size_t)i * 64 + j) * KR_BLOCKS;
+    for (int q = threadIdx.x; q < KR_BLOCKS; q += BLOCK) acc += p[q];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = BLOCK >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) out[j] = red[0];
+}
+
 struct DistKrylov {
   Comm& c;
   std::vector<Dist*>& M;
@@ -876,6 +1007,125 @@ struct DistKrylov {
       if (err <= tol * err0) break;
     }
     if (it > maxit) it = maxit;
+    return it;
+  }
+
+  // ---- restarted GMRES(m), left-preconditioned, over the ranks: Krylov::gmres with rank-local vectors.  The Arnoldi inner
+  // products h = V^T w are ONE fused local pass + ONE ncclAllReduce of j + 1 scalars per Gram-Schmidt pass (the reference's
+  // driver is ngsolve.krylovspace.GMRes on ParallelVectors: one MPI all-reduce per inner product); Givens rotations on the
+  // host, identically on every rank (all ranks read the same reduced values).  err_k = |C r_k|, stop at err_k <= tol * err_0.
+  std::vector<DevBuf<double>> gV, gt;      // per local rank: basis (m + 1) x n_owned, work vector
+  DevBuf<double> hdev, gpartial;
+  int g_m = 0;
+  // sc[0 .. m) = sum over all ranks of <V_j, w> (owned entries)
+  void multi_dot(int m, const std::vector<double*>& w) {
+    if (m > 48) throw Err("multi_dot: too many vectors");
+    for (size_t i = 0; i < M.size(); ++i) {
+      const int64_t n = M[i]->n(0);
+      if (n) hipLaunchKernelGGL(kr_multi_dot_partial_kernel, dim3(nb(n)), dim3(BLOCK), 0, c.compute, n, m, gV[i].p, n, w[i], gpartial.p + (size_t)i * 64 * KR_BLOCKS);
+    }
+    hipLaunchKernelGGL(kr_dist_multi_final_kernel, dim3(m), dim3(BLOCK), 0, c.compute, (int)M.size(), gpartial.p, sc.p);
+    HIPCHK(hipGetLastError());
+    if (c.kind == AMGX_COMM_RCCL && (c.nranks > 1 || M[0]->force_allgather))
+      NCCLCHK(Rccl::get().AllReduce(sc.p, sc.p, (size_t)m, ncclDouble, ncclSum, c.nccl, c.compute));
+  }
+  void read_n(int m, double* out) {
+    HIPCHK(hipMemcpyAsync(out, sc.p, m * sizeof(double), hipMemcpyDeviceToHost, c.compute));
+    HIPCHK(hipStreamSynchronize(c.compute));
+  }
+  void precond_vec(const std::vector<double*>& r, const std::vector<double*>& z, bool use_pre) {      // z = C r (r is copied into the cycle's rhs buffer)
+    for (size_t i = 0; i < M.size(); ++i) M[i]->top->copy(use_pre ? d(i) : z[i], r[i], M[i]->n(0));
+    if (!use_pre) return;
+    std::vector<const double*> bp(M.size());
+    std::vector<double*> xp(M.size());
+    for (size_t i = 0; i < M.size(); ++i) { bp[i] = d(i); xp[i] = z[i]; }
+    dist_apply(c, bp.data(), xp.data(), 1, AMGX_DEVICE_PTR);
+  }
+  void matvec(const std::vector<double*>& v, const std::vector<double*>& y) {                         // y = A v (level 0, ghosts of v exchanged)
+    for (size_t i = 0; i < M.size(); ++i) M[i]->top->copy(sext[i].p, v[i], M[i]->n(0));
+    with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->mult(M[i]->top->lev[0].A, sext[i].p, y[i], sp); });
+  }
+  int gmres(const double* const* b, double* const* x, double tol, int maxit, int restart, bool use_pre, double* errs) {
+    if (restart > 40) throw Err("amgx_dist_gmres: restart lengths above 40 are not supported (got " + std::to_string(restart) + ")");
+    const int m = std::max(1, restart);
+    const size_t R = M.size();
+    if (g_m < m || gV.size() != R) {
+      gV.clear(); gt.clear(); gV.resize(R); gt.resize(R);
+      for (size_t i = 0; i < R; ++i) { gV[i].alloc((size_t)(m + 1) * std::max<int64_t>(1, M[i]->n(0))); gt[i].alloc((size_t)std::max<int64_t>(1, M[i]->n(0))); }
+      gpartial.alloc((size_t)KR_BLOCKS * 64 * R);      // (its own buffer: slots a short rank never writes must stay 0, here and in dot())
+      HIPCHK(hipMemsetAsync(gpartial.p, 0, (size_t)KR_BLOCKS * 64 * R * sizeof(double), c.compute));
+      hdev.alloc(64);
+      g_m = m;
+    }
+    auto grid = [&](size_t i) { return Handle::grid_for(M[i]->n(0)); };
+    auto vj = [&](int j) { std::vector<double*> v(R); for (size_t i = 0; i < R; ++i) v[i] = gV[i].p + (size_t)j * M[i]->n(0); return v; };
+    std::vector<double*> wv(R), tv(R), xv(R);
+    for (size_t i = 0; i < R; ++i) { wv[i] = w[i].p; tv[i] = gt[i].p; xv[i] = x[i]; }
+    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), hcol(m + 1), hc2(m + 1), y(m);
+    int it = 0;
+    double err0 = -1.0;
+    while (it < maxit) {
+      // t = b - A x
+      for (size_t i = 0; i < R; ++i) M[i]->top->copy(sext[i].p, x[i], M[i]->n(0));
+      with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->residual(M[i]->top->lev[0].A, sext[i].p, b[i], tv[i], sp); });
+      precond_vec(tv, vj(0), use_pre);                       // v_0 = C t (not yet normalised)
+      { std::vector<const double*> a(R), bb(R); for (size_t i = 0; i < R; ++i) { a[i] = vj(0)[i]; bb[i] = a[i]; } dot(a, bb, 0); }
+      const double beta = std::sqrt(read(0));
+      if (err0 < 0.0) { err0 = beta; if (errs) errs[0] = err0; }
+      if (beta == 0.0 || beta <= tol * err0) break;
+      for (size_t i = 0; i < R; ++i) if (M[i]->n(0)) hipLaunchKernelGGL(kr_scale_kernel, dim3(grid(i)), dim3(BLOCK), 0, c.compute, M[i]->n(0), 1.0 / beta, vj(0)[i], vj(0)[i], 0);
+      std::fill(g.begin(), g.end(), 0.0);
+      g[0] = beta;
+      int j = 0;
+      bool done = false;
+      for (j = 0; j < m && it < maxit; ++j) {
+        ++it;
+        matvec(vj(j), tv);
+        precond_vec(tv, wv, use_pre);                        // w = C A v_j
+        std::fill(hcol.begin(), hcol.end(), 0.0);
+        for (int pass = 0; pass < 2; ++pass) {
+          multi_dot(j + 1, wv);
+          read_n(j + 1, hc2.data());
+          HIPCHK(hipMemcpyAsync(hdev.p, hc2.data(), (j + 1) * sizeof(double), hipMemcpyHostToDevice, c.compute));
+          for (size_t i = 0; i < R; ++i) if (M[i]->n(0)) hipLaunchKernelGGL(kr_multi_axpy_kernel, dim3(grid(i)), dim3(BLOCK), 0, c.compute, M[i]->n(0), j + 1, gV[i].p, M[i]->n(0), hdev.p, -1.0, wv[i]);
+          HIPCHK(hipStreamSynchronize(c.compute));           // hc2 is reused by the next pass
+          for (int i = 0; i <= j; ++i) hcol[i] += hc2[i];
+        }
+        { std::vector<const double*> a(R); for (size_t i = 0; i < R; ++i) a[i] = wv[i]; dot(a, a, 0); }
+        const double hn = std::sqrt(read(0));
+        hcol[j + 1] = hn;
+        if (hn > 0.0) for (size_t i = 0; i < R; ++i) if (M[i]->n(0)) hipLaunchKernelGGL(kr_scale_kernel, dim3(grid(i)), dim3(BLOCK), 0, c.compute, M[i]->n(0), 1.0 / hn, wv[i], vj(j + 1)[i], 0);
+        for (int i = 0; i < j; ++i) {                        // previous rotations
+          const double a = cs[i] * hcol[i] + sn[i] * hcol[i + 1];
+          hcol[i + 1] = -sn[i] * hcol[i] + cs[i] * hcol[i + 1];
+          hcol[i] = a;
+        }
+        const double den = std::hypot(hcol[j], hcol[j + 1]);
+        cs[j] = den > 0 ? hcol[j] / den : 1.0;
+        sn[j] = den > 0 ? hcol[j + 1] / den : 0.0;
+        hcol[j] = den;
+        g[j + 1] = -sn[j] * g[j];
+        g[j] = cs[j] * g[j];
+        for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
+        const double err = std::fabs(g[j + 1]);
+        if (errs) errs[it] = err;
+        if (err <= tol * err0 || hn == 0.0) { done = true; ++j; break; }
+      }
+      const int k = j;
+      for (int i = k - 1; i >= 0; --i) {
+        double sacc = g[i];
+        for (int q = i + 1; q < k; ++q) sacc -= H[(size_t)i * m + q] * y[q];
+        const double piv = H[(size_t)i * m + i];
+        y[i] = piv != 0.0 ? sacc / piv : 0.0;
+      }
+      if (k > 0) {
+        HIPCHK(hipMemcpyAsync(hdev.p, y.data(), k * sizeof(double), hipMemcpyHostToDevice, c.compute));
+        for (size_t i = 0; i < R; ++i) if (M[i]->n(0)) hipLaunchKernelGGL(kr_multi_axpy_kernel, dim3(grid(i)), dim3(BLOCK), 0, c.compute, M[i]->n(0), k, gV[i].p, M[i]->n(0), hdev.p, 1.0, xv[i]);
+        HIPCHK(hipStreamSynchronize(c.compute));
+      }
+      if (done) break;
+    }
+    HIPCHK(hipGetLastError());
     return it;
   }
 };
@@ -1078,8 +1328,35 @@ int amgx_dist_pcg(amgx_comm cc, const double* const* b, double* const* x, double
       if ((!b[i] || !x[i]) && d->n(0) > 0) throw amgx::Err("amgx_dist_pcg: null vector");
       if (b[i] == d->bext[0].p || x[i] == d->bext[0].p) throw amgx::Err("amgx_dist_pcg: b / x alias the cycle's right-hand-side buffer (it holds the residual)");
     }
-    amgx::DistKrylov K(c);
+    // the workspace lives with the communicator: the preconditioner's whole-cycle graph is keyed on the vector addresses, so a
+    // second solve replays the graph of the first instead of capturing a new one (and leaving a stale one behind)
+    if (!c.krylov_ws || c.krylov_members != c.members.size()) {
+      c.krylov_ws = std::shared_ptr<void>(new amgx::DistKrylov(c), [](void* p) { delete static_cast<amgx::DistKrylov*>(p); });
+      c.krylov_members = c.members.size();
+    }
+    amgx::DistKrylov& K = *static_cast<amgx::DistKrylov*>(c.krylov_ws.get());
     const int it = K.pcg(b, x, tol, maxit, use_precond != 0, errs);
+    if (iters) *iters = it;
+  });
+}
+
+int amgx_dist_gmres(amgx_comm cc, const double* const* b, double* const* x, double tol, int maxit, int restart, int use_precond, int flags,
+                    double* errs, int32_t* iters) {
+  return cguard(cc, [&](amgx::Comm& c) {
+    if (!b || !x || maxit < 0 || restart < 1) throw amgx::Err("amgx_dist_gmres: bad arguments");
+    if (!(flags & AMGX_DEVICE_PTR)) throw amgx::Err("amgx_dist_gmres: device vectors only (AMGX_DEVICE_PTR)");
+    if (c.members.empty() || (c.kind == AMGX_COMM_LOCAL && (int)c.members.size() != c.nranks)) throw amgx::Err("amgx_dist_gmres: not all ranks have a hierarchy");
+    for (size_t i = 0; i < c.members.size(); ++i) {
+      amgx::Dist* d = c.members[i];
+      if ((!b[i] || !x[i]) && d->n(0) > 0) throw amgx::Err("amgx_dist_gmres: null vector");
+      if (b[i] == d->bext[0].p || x[i] == d->bext[0].p) throw amgx::Err("amgx_dist_gmres: b / x alias the cycle's right-hand-side buffer");
+    }
+    if (!c.krylov_ws || c.krylov_members != c.members.size()) {
+      c.krylov_ws = std::shared_ptr<void>(new amgx::DistKrylov(c), [](void* p) { delete static_cast<amgx::DistKrylov*>(p); });
+      c.krylov_members = c.members.size();
+    }
+    amgx::DistKrylov& K = *static_cast<amgx::DistKrylov*>(c.krylov_ws.get());
+    const int it = K.gmres(b, x, tol, maxit, restart, use_precond != 0, errs);
     if (iters) *iters = it;
   });
 }

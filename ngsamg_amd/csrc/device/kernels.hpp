@@ -925,18 +925,28 @@ __global__ __launch_bounds__(BLOCK) void bgs_bsell_upper_residual_kernel(int n_s
 // nothing outside the block is read.
 // blk_ptr / blk_rows: the block rows of every sweep block (ascending inside a block).  Runs of consecutive rows, or compact
 // blocks grown over the matrix graph (amgh_compact_blocks): the local index of a row = its position in its block's list.
-template <int BS, bool FROM_ZERO>
-__global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_rows,
+// MODE 0: general sweep (xin -> xout).  MODE 1: from x = 0, nothing outside the block is read (phase 0 skipped).
+// MODE 2 (block-COLOURED sweeps from zero, see below): own rows start from 0, phase 0 streams OFF (= the couplings to the sweep
+//         blocks of LOWER block colours, already swept in this pass) with the values in xin; the in-block `other` image multiplies zeros.
+// Block-coloured form (blk_list != null, DevBGSB::bc): the sweep blocks carry a colouring of the BLOCK graph and a sweep is one
+// launch per block colour over blk_list[block0 ...): blocks of one colour are not coupled, so the launch works IN PLACE
+// (xin == xout) and a block reads the new values of every block swept before it -- Gauss-Seidel between the blocks as well as
+// inside them, i.e. exact Gauss-Seidel in the order (block colour, block, in-block colour), instead of the hybrid form's frozen
+// couplings.  PCG at 30^3 nodes: 15 iterations (sequential order 16, hybrid line blocks 19).
+template <int BS, int MODE>
+__global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, const int32_t* __restrict__ blk_list,
+                                                           const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ blk_rows,
                                                            BSellMat OFF, const int32_t* __restrict__ off_ptr,
                                                            BSellMat IN, BSellMat OTH, const int32_t* __restrict__ in_ptr, const int32_t* __restrict__ in_row,
                                                            int n_colors, int dir, const double* __restrict__ dinv, const double* __restrict__ b,
-                                                           const double* __restrict__ xin, double* __restrict__ xout) {
+                                                           const double* xin, double* xout) {
+  constexpr bool FROM_ZERO = MODE != 0;
   extern __shared__ double bgsb_sh[];
   constexpr int RB = WAVE / BS;
   double* xs = bgsb_sh;
   double* bsh = bgsb_sh + (size_t)BB * BS;
   int* rowsh = reinterpret_cast<int*>(bgsb_sh + (size_t)2 * BB * BS);      // global block row of every local row
-  const int blk = block0 + blockIdx.x;
+  const int blk = blk_list ? blk_list[block0 + blockIdx.x] : block0 + blockIdx.x;
   const int p0 = blk_ptr[blk];
   const int nb = blk_ptr[blk + 1] - p0;
   for (int e = threadIdx.x; e < nb; e += BLOCK) rowsh[e] = blk_rows[p0 + e];
@@ -951,7 +961,7 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
   const int rbl = lane / BS < RB ? lane / BS : RB - 1;
   const int r = lane % BS;
   const bool lane_on = lane < RB * BS;
-  if (!FROM_ZERO) {
+  if (MODE != 1) {
     const int s0 = off_ptr[blk], s1 = off_ptr[blk + 1];
     for (int s = s0 + wave; s < s1; s += WAVES_PER_BLOCK) {
       const int lrow = (s - s0) * RB + rbl;
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
     }
     __syncthreads();
     // the other in-block image: all colours at once, sweep-start values from LDS (a row sits in one slice of it)
-    const int t0 = in_ptr[blk * n_colors], t1 = in_ptr[(blk + 1) * n_colors];
+    const int t0 = in_ptr[blk * n_colors], t1 = MODE == 0 ? in_ptr[(blk + 1) * n_colors] : t0;
     for (int s = t0 + wave; s < t1; s += WAVES_PER_BLOCK) {
       const int lrow = in_row[(int64_t)s * RB + rbl];
       const bool active = lane_on && lrow >= 0;
@@ -1231,6 +1241,76 @@ __global__ __launch_bounds__(WB) void sell_win_cres_restrict_kernel(int64_t n_ro
   if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, x);
   __syncthreads();
   const double r = row < n_rows ? ci * xi - buf[threadIdx.x] : 0.0;
+  buf[threadIdx.x] = r;                      // (same thread, same entry: the residuals replace the row sums in place)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < MAXE / WB; ++q) {
+    const int e = threadIdx.x + q * WB;
+    if (e0 + e < e1) pr[e] = wq[q] * buf[fq[q]];
+  }
+  __syncthreads();
+  if (myslot < s1) {
+    const int pa = pa_raw - e0, pb = pb_raw - e0;
+    double acc = 0.0;
+    for (int k = pa; k < pb; ++k) acc += pr[k];
+    part[mydest] = acc;
+  }
+  for (int sl = myslot + WB; sl < s1; sl += WB) {
+    const int a = slot_ptr[sl] - e0, bnd = slot_ptr[sl + 1] - e0;
+    double acc = 0.0;
+    for (int k = a; k < bnd; ++k) acc += pr[k];
+    part[dest ? dest[sl] : sl] = acc;
+  }
+}
+
+// Jacobi pre-smoothing from zero + residual + chunk-local restriction (sell_pre_restrict_kernel, MODE 0) for the WINDOWED SELL form
+// of A': the coarser levels of a reference-shaped hierarchy have ragged rows (34 ... 63 entries at the 1.24 M-row level of cfg 2),
+// plain 64-row slices pad 20 %, length-sorted 512-row windows 3.6 %.  No diagonal-first trick here (the rows of a window are stored
+// by decreasing length): b and dinv of the own row are read in natural order, which on these levels is 1 % of the matrix stream.
+template <int WB, int EPT = 4>
+__global__ __launch_bounds__(WB) void sell_win_pre_restrict_kernel(int64_t n_rows, int win0, SellMat M, const uint16_t* __restrict__ rowloc,
+                                                                   const double* __restrict__ b, const double* __restrict__ dinv, double omega, int nt,
+                                                                   double* __restrict__ x,
+                                                                   const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ slot_ptr,
+                                                                   const double* __restrict__ w, const uint16_t* __restrict__ fi,
+                                                                   double* __restrict__ part, const int32_t* __restrict__ dest) {
+  constexpr int MAXE = EPT * WB;
+  __shared__ double buf[WB];
+  __shared__ double pr[MAXE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int c = win0 + sell_unit(M);
+  const int s = __builtin_amdgcn_readfirstlane(c * (WB / WAVE) + (threadIdx.x >> 6));
+  const int64_t slot = (int64_t)s * WAVE + lane;
+  const int64_t row = (int64_t)c * WB + threadIdx.x;
+  const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
+  const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
+  double wq[MAXE / WB];
+  int fq[MAXE / WB];
+#pragma unroll
+  for (int q = 0; q < MAXE / WB; ++q) {
+    const int e = e0 + threadIdx.x + q * WB;
+    wq[q] = e < e1 ? ld_nt(w + e) : 0.0;
+    fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
+  }
+  const int myslot = s0 + threadIdx.x;
+  int mydest = myslot, pa_raw = 0, pb_raw = 0;               // (consumed after the row product: see sell_pre_restrict_kernel)
+  if (myslot < s1) {
+    if (dest) mydest = dest[myslot];
+    pa_raw = slot_ptr[myslot];
+    pb_raw = slot_ptr[myslot + 1];
+  }
+  double bi = 0.0, di = 0.0;
+  if (row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+  if (slot < n_rows) buf[rowloc[slot]] = sell_row_dot(M, s, lane, 0, b);
+  __syncthreads();
+  double r = 0.0;
+  if (row < n_rows) {
+    r = bi - buf[threadIdx.x];
+    double xi = omega * (di * bi);
+    if (nt & EPF_FOLD) xi += omega * (di * r);
+    if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);
+    else x[row] = xi;
+  }
   buf[threadIdx.x] = r;                      // (same thread, same entry: the residuals replace the row sums in place)
   __syncthreads();
 #pragma unroll

@@ -108,6 +108,10 @@ int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* 
     o.spw = opts->spw; o.spw_rounds = opts->spw_rounds; o.spw_orphan_round = opts->spw_orphan_round;
     o.prol_type = opts->prol_type; o.sp_max_per_row_classic = opts->sp_max_per_row_classic;
     if (o.prol_type < -1 || o.prol_type > 3) throw amgh::Error("amgh_setup: prol_type must be -1 (default), 0, 1, 2 or 3");
+    // robust_soc belongs to the target-driven pairwise rounds (spw = 0): the SPW agglomerator carries maxTrOD through its rounds
+    // instead and neither reads nor forwards the vertex scales, so the option (and its "barely smaller" stop rule) would act on
+    // half of its data there
+    if (o.robust_soc && o.spw) throw amgh::Error("amgh_setup: robust_soc needs spw = 0 (with the SPW agglomerator the accumulated maxTrOD plays that role)");
     if (o.max_levels < 1) throw amgh::Error("amgh_setup: max_levels must be >= 1");
     if (o.dim != 2 && o.dim != 3) throw amgh::Error("amgh_setup: dim must be 2 or 3");
     amgh::BCSR A0 = to_bcsr(A);

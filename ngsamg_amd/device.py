@@ -65,6 +65,28 @@ def hybrid_gs_data(A, free, B, pinv=False):
     return color, int(nc.value), dinv
 
 
+def block_colored_gs_data(A, free, B, dinv_plain):
+    """square-block levels, block-COLOURED Gauss-Seidel (amgx_level_desc.gs_block_color): sweep blocks = runs of B consecutive block
+    rows; in-block colouring as for the hybrid form (amgh_coloring_blocked), a colouring of the BLOCK graph (amgh_bgs_coloring: coupled
+    blocks differ) and the plain (pseudo-)inverse of the diagonal blocks -- the sweep is exact Gauss-Seidel in the order (block colour,
+    block, in-block colour), so no l1 modification.  Returns (color, n_colors, block_color_of_row, n_block_colors, dinv)."""
+    lib = _lib.host()
+    d = A.desc()
+    fr = None if free is None else np.ascontiguousarray(free, dtype=np.uint8)
+    n = A.n_rows
+    color = np.full(n, -1, dtype=np.int32)
+    nc = C.c_int32()
+    _lib.hcheck(lib.amgh_coloring_blocked(C.byref(d), _lib.ptr(fr, C.c_uint8), int(B), _lib.ptr(color, C.c_int32), C.byref(nc)))
+    nb = (n + B - 1) // B
+    bptr = np.minimum(np.arange(nb + 1, dtype=np.int64) * B, n).astype(np.int32)
+    brows = np.arange(n, dtype=np.int32)
+    bcol = np.zeros(max(1, nb), dtype=np.int32)
+    nbc = C.c_int32()
+    _lib.hcheck(lib.amgh_bgs_coloring(C.byref(d), int(nb), _lib.ptr(bptr, C.c_int32), _lib.ptr(brows, C.c_int32), _lib.ptr(bcol, C.c_int32), C.byref(nbc)))
+    row_bcol = np.ascontiguousarray(np.repeat(bcol[:nb], B)[:n].astype(np.int32))
+    return color, int(nc.value), row_bcol, int(nbc.value), np.ascontiguousarray(dinv_plain, dtype=np.float64)
+
+
 def hybrid_gs_data_compact(A, free, B, pinv=False):
     """square-block levels: compact sweep blocks of at most B block rows grown over the matrix graph (amgh_compact_blocks)
     instead of runs of consecutive rows, with their colouring and l1-modified block diagonal.
@@ -147,8 +169,21 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
                 import os
                 pinv = bool(getattr(getattr(hierarchy, "options", None), "regularize_cmats", 0))
                 blk = None
+                bcolr, nbc = None, 0
+                # square-block levels big enough to be bandwidth-bound: block-COLOURED sweeps (exact Gauss-Seidel between the sweep
+                # blocks as well, one launch per block colour) -- PCG iterations of the sequential order (cfg 3: 16 -> 20 with the
+                # hybrid form's frozen couplings between grid lines); small levels keep the single launch of the hybrid form
+                bc_min = int(os.environ.get("AMGX_BGSB_BC_MIN_ROWS", "50000"))
                 if pre:
                     col, nc, dinv = pre["color"], pre["n_colors"], pre["dinv"]
+                elif lv.A.br > 1 and lv.A.n_rows >= bc_min and not os.environ.get("AMGX_BGSB_COMPACT") and not os.environ.get("AMGX_NO_BGSB_BC"):
+                    col, nc, bcolr, nbc, dinv = block_colored_gs_data(lv.A, lv.free, B, lv.dinv)
+                    # a launch per block colour must still fill the chip (256 CUs): an unstructured coarse level with 2 k sweep blocks
+                    # in 9 colours (cfg 3 level 1) would run 230 workgroups per launch -- such levels keep the hybrid form
+                    wg_min = int(os.environ.get("AMGX_BGSB_BC_MIN_WG", "1024")) if bc_min > 0 else 0
+                    if ((lv.A.n_rows + B - 1) // B) < wg_min * max(1, nbc):
+                        bcolr, nbc = None, 0
+                        col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B, pinv)
                 elif lv.A.br > 1 and os.environ.get("AMGX_BGSB_COMPACT"):
                     # block levels: compact sweep blocks (amgh_compact_blocks) freeze half as many couplings as runs of consecutive
                     # rows (= grid lines) and bring the PCG count to within one of the sequential sweep (cfg 3: 17 vs 16; line
@@ -157,11 +192,13 @@ def hierarchy_desc(hierarchy, sm_type="gs", omega=0.9, sm_steps=1, sm_symm=False
                     blk, col, nc, dinv = hybrid_gs_data_compact(lv.A, lv.free, B, pinv)
                 else:
                     col, nc, dinv = hybrid_gs_data(lv.A, lv.free, B, pinv)
-                info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv, block_of_row=blk)
+                info[i] = dict(B=B, color=col, n_colors=nc, dinv=dinv, block_of_row=blk, block_color=bcolr, n_block_colors=nbc)
                 keep.append(info[i])
                 d.color, d.n_colors, d.dinv, d.gs_block_rows = _lib.ptr(col, C.c_int32), nc, _lib.ptr(dinv, C.c_double), B
                 if blk is not None:
                     d.gs_block_ids = _lib.ptr(blk, C.c_int32)
+                if bcolr is not None:
+                    d.gs_block_color, d.gs_n_block_colors = _lib.ptr(bcolr, C.c_int32), nbc
         g = getattr(lv, "bgs", None)
         if types[i] == "bgs" and g is None and i + 1 < n:
             raise NgsAMGError("sm_type 'bgs' needs block data on every smoothed level (Hierarchy.build_bgs())")

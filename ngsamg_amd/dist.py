@@ -841,7 +841,7 @@ class DistributedAMG:
     """
 
     def __init__(self, comm, states0, dim=3, omega=0.9, dist_min_rows=50000, max_dist_levels=3, device=0,
-                 backend=None, sm_type="jacobi", fold=True, **opts):
+                 backend=None, sm_type="jacobi", fold=True, sm_steps=1, sm_symm=False, mg_cycle="V", **opts):
         if sm_type not in ("jacobi", "gs", "hgs", "bgs"):
             raise NgsAMGError("DistributedAMG: sm_type must be jacobi, gs (multicolour stages), hgs (block-hybrid Gauss-Seidel) or bgs")
         self.comm, self.dim, self.omega, self.sm_type = comm, dim, omega, sm_type
@@ -857,7 +857,16 @@ class DistributedAMG:
         # per stage); False = the literal stage sequence pre / restrict / prolong / post with two exchanges per level
         # (AMGX_NO_FOLD=1, the switch that makes the single-GPU handle run the literal kernel sequence, selects the literal
         # stages here too: the decision is taken from the environment on every rank alike, before anything is built)
-        self.fold = bool(fold) and sm_type == "jacobi" and not blocks and not os.environ.get("AMGX_NO_FOLD")
+        # ngs_amg_sm_steps / ngs_amg_sm_symm (ProxySmoother, base_smoother.hpp:169-229) and ngs_amg_mg_cycle = "W" on rank-partitioned
+        # levels: the native driver's step-by-step cycle (csrc/device/dist.hpp, DistCycle::generic_cycle); the folded V(1,1) form
+        # and the stage-by-stage Python test backend cover sm_steps = 1, sm_symm = False, V only
+        self.sm_steps, self.sm_symm, self.mg_cycle = int(sm_steps), bool(sm_symm), str(mg_cycle)
+        if self.mg_cycle not in ("V", "W"):
+            raise NgsAMGError("DistributedAMG: mg_cycle must be V or W")
+        self.generic = self.sm_steps > 1 or self.sm_symm or self.mg_cycle == "W"
+        if self.generic and backend is not None:
+            raise NgsAMGError("DistributedAMG: sm_steps / sm_symm / W-cycle run through the device driver only (backend=None)")
+        self.fold = bool(fold) and sm_type == "jacobi" and not blocks and not os.environ.get("AMGX_NO_FOLD") and not self.generic
         pinv = bool(opts.get("regularize_cmats", self.energy == 1 and all(_bs(s) == dim for s in states0)))
         for s in states0:
             interior_first(s)
@@ -962,6 +971,12 @@ class DistributedAMG:
         if self._dev is None:
             raise NgsAMGError("pcg: needs the device driver (no CPU path)")
         return self._dev.pcg(bs, xs, tol=tol, maxsteps=maxsteps, use_pre=use_pre)
+
+    def gmres(self, bs, xs, tol=1e-8, maxsteps=200, restart=30, use_pre=True):
+        """collective restarted GMRES(restart) with this cycle as left preconditioner (amgx_dist_gmres)"""
+        if self._dev is None:
+            raise NgsAMGError("gmres: needs the device driver (no CPU path)")
+        return self._dev.gmres(bs, xs, tol=tol, maxsteps=maxsteps, restart=restart, use_pre=use_pre)
 
     def level_k_map(self, i):
         """level k of local rank i in its [owned | ghost] layout -> index in the gathered (replicated) vector"""
@@ -1306,8 +1321,10 @@ class _DeviceDist:
             pass
         for i, top in enumerate(amg.tops):
             types = [sm] * (top.n_levels - 1) + ["jacobi"]
-            tdesc, tkeep, _ = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False)
-            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device)
+            stp, sym, cyc = getattr(amg, "sm_steps", 1), getattr(amg, "sm_symm", False), getattr(amg, "mg_cycle", "V")
+            tdesc, tkeep, _ = hierarchy_desc(top, sm_type=types, omega=amg.omega, clev="none", device=self.device, use_graph=False,
+                                             sm_steps=stp, sm_symm=sym, mg_cycle=cyc)
+            ldesc, lkeep, _ = hierarchy_desc(amg.tail_hier, sm_type=sm, omega=amg.omega, device=self.device, sm_steps=stp, sm_symm=sym, mg_cycle=cyc)
             halos = (_lib.amgx_halo_desc * k)()
             keep = [tkeep, lkeep, halos]
             for l in range(k):
@@ -1453,6 +1470,25 @@ class _DeviceDist:
         it = C.c_int32()
         self._ck(self._lib.amgx_dist_pcg(self._comm, pb, px, float(tol), int(maxsteps), int(bool(use_pre)), _lib.AMGX_DEVICE_PTR,
                                          _lib.ptr(errs, C.c_double), C.byref(it)))
+        return it.value, errs[:it.value + 1]
+
+    def gmres(self, bs, xs, tol=1e-8, maxsteps=200, restart=30, use_pre=True):
+        """amgx_dist_gmres: collective restarted GMRES with the rank-partitioned cycle as (left) preconditioner; xs hold the initial
+        guess and receive the solution.  Returns (iterations, err_0 .. err_iterations)."""
+        import torch
+        self._bind_stream()
+        n = len(self._dists)
+        for i, (b, x) in enumerate(zip(bs, xs)):
+            m = self.amg.dist_levels[0][i].n * _bs(self.amg.dist_levels[0][i])
+            for v, nm in ((b, "b"), (x, "x")):
+                if not (v.is_cuda and v.dtype == torch.float64 and v.is_contiguous() and v.numel() == m):
+                    raise NgsAMGError(f"{nm}[{i}]: need a contiguous float64 CUDA tensor with {m} entries")
+        pb = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        errs = np.zeros(int(maxsteps) + 1)
+        it = C.c_int32()
+        self._ck(self._lib.amgx_dist_gmres(self._comm, pb, px, float(tol), int(maxsteps), int(restart), int(bool(use_pre)), _lib.AMGX_DEVICE_PTR,
+                                           _lib.ptr(errs, C.c_double), C.byref(it)))
         return it.value, errs[:it.value + 1]
 
     def graph_info(self):

@@ -619,3 +619,91 @@ def test_strong_split_device_matches_serial_oracle(pg, gshape, dmin, sm):
     it, errs = amg.pcg(bs, xs, tol=1e-8, maxsteps=100)
     _, ito, erro = orc.pcg(np.concatenate(bh), tol=1e-8, maxit=100)
     assert it == ito and np.all(np.abs(errs - np.asarray(erro)[:it + 1]) <= 1e-6 * erro[0])
+
+
+# ---- ProxySmoother (sm_steps / sm_symm) and the W-cycle on rank-partitioned levels: the native driver's step-by-step cycle ----
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (4, (40, 40), 2, 100)])
+@pytest.mark.parametrize("steps,symm,cycle", [(2, False, "V"), (1, True, "V"), (2, True, "V"), (1, False, "W"), (2, False, "W")])
+def test_loopback_device_steps_symm_w_jacobi(R, box, dim, dmin, steps, symm, cycle):
+    """reference: ProxySmoother (base_smoother.hpp:169-229) around the level smoother, AMGMatrix::SmoothW (amg_matrix.cpp:37-107);
+    Jacobi steps of the parallel smoother with the plain diagonal are the global Jacobi steps, so the serial oracle with the same
+    sm_steps / sm_symm / cycle on the assembled global hierarchy is the reference"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, dim)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_steps=steps, sm_symm=symm, mg_cycle=cycle)
+    assert amg.k >= 1 and not amg.fold
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(3):          # direct launches, capture, replay
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    ref = Oracle(amg.global_levels(), sm_type="jacobi", sm_steps=steps, sm_symm=symm, cycle=cycle).apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (48, 48), 2, 300)])
+@pytest.mark.parametrize("steps,symm,cycle", [(2, False, "V"), (1, True, "V"), (1, False, "W")])
+def test_loopback_device_steps_symm_w_block_hybrid_gs(R, box, dim, dmin, steps, symm, cycle):
+    """the same for the block-hybrid Gauss-Seidel levels: every step is one hybrid sweep (exchange of x, then the sweep with the
+    off-block values frozen), against the oracle's serial hybrid sweep with the same blocks, colours and modified diagonal"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, dim)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=dim, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type="hgs", hgs_block_rows=256,
+                           sm_steps=steps, sm_symm=symm, mg_cycle=cycle)
+    rng = np.random.default_rng(1)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(2):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv), sm_steps=steps, sm_symm=symm, cycle=cycle).apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("R,box,dmin,sm,restart", [(2, (14, 12, 12), 100, "jacobi", 30), (4, (10, 10, 10), 50, "jacobi", 5), (2, (14, 12, 12), 100, "hgs", 12)])
+def test_distributed_gmres_history_equals_serial_oracle(R, box, dmin, sm, restart):
+    """amgx_dist_gmres (rank-local Arnoldi vectors, fused inner products + all-reduce) against the oracle's serial GMRES on the
+    assembled global hierarchy: same iteration count, same error history, same solution"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm,
+                           **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    rng = np.random.default_rng(3)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in states]
+    it, errs = amg.gmres(bs, xs, tol=1e-9, maxsteps=150, restart=restart)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type="jacobi") if sm == "jacobi" else Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
+    xo, ito, erro = orc.gmres(np.concatenate(bh), tol=1e-9, maxit=150, restart=restart)
+    assert it == ito
+    assert errs.shape == erro.shape and np.all(np.abs(errs - erro) <= 1e-6 * erro[0])
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - xo) <= 1e-7 * np.linalg.norm(xo)
+    # a second solve re-uses the workspace (and the preconditioner's captured graph)
+    for x in xs:
+        x.zero_()
+    it2, errs2 = amg.gmres(bs, xs, tol=1e-9, maxsteps=150, restart=restart)
+    assert it2 == it and np.array_equal(errs2, errs)

@@ -111,10 +111,21 @@ def test_cfg3_cfg5_elasticity_126_cubed(rot):
     from tests.hgs_oracle import hgs_levels
     dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
     assert dev.hgs[0] is not None and dev.hgs[0]["B"] in (120, 126)
+    assert dev.hgs[0]["block_color"] is not None, "the big block levels sweep in the block-coloured form"
     lv, types = hgs_levels(H.levels, dev.hgs)
     ref = Oracle(lv, sm_type=types, threads=_threads()).apply(b)
     x = _apply(dev, b)
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    # a GPU-parallel Gauss-Seidel order may cost at most 15 % more PCG iterations than the reference's sequential sweep
+    import torch
+    from ngsamg_amd.krylov import CGSolver
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        cg = CGSolver(dev, dev, tol=1e-8, maxsteps=200)
+        cg.Solve(torch.from_numpy(b).cuda())
+        st.synchronize()
+    it_seq = Oracle(H.levels, sm_type="gs", threads=_threads()).pcg(b, tol=1e-8, maxit=200)[1]
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)
 
 
 def test_cfg4_arrangement_8_virtual_ranks_production_formats():

@@ -167,6 +167,69 @@ def test_block_levels_hgs_cycles_match_hybrid_oracle(rot, shape, cycle, split, m
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("rot,shape", [(False, (14, 13, 12)), (True, (12, 11, 10)), (False, (40, 36))])
+@pytest.mark.parametrize("cycle,split", [("V", True), ("W", True), ("V", False)])
+def test_block_levels_block_coloured_gs_matches_ordered_oracle(rot, shape, cycle, split, monkeypatch):
+    """amgx_level_desc.gs_block_color (the default on square-block levels with >= 50 k block rows, forced onto these small ones):
+    the sweep blocks carry a colouring of the block graph, a sweep is one in-place launch per block colour = exact Gauss-Seidel in the
+    order (block colour, block, in-block colour); the oracle runs GSS3's loop (gssmoother.cpp:196-257) in exactly that order"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    monkeypatch.setenv("AMGX_BGSB_BC_MIN_ROWS", "0")
+    if not split:
+        monkeypatch.setenv("AMGX_BGSB_NO_SPLIT", "1")
+    p, H = elasticity_case(shape, rotations=rot, max_coarse_size=10)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", mg_cycle=cycle, device=0)
+    assert dev.hgs[0] is not None and dev.hgs[0]["block_color"] is not None and dev.hgs[0]["n_block_colors"] >= 2
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    assert lv[0].gs_block is None
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = Oracle(lv, sm_type=types, cycle=cycle).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_block_coloured_gs_flags_symmetry_and_iteration_tolerance(rot, monkeypatch):
+    """flag contract of the in-place block-coloured sweeps, symmetry of the cycle, and SURVEY 8d's tolerance for a GPU-parallel
+    Gauss-Seidel order: PCG iterations within +15 % of the reference's sequential order"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    monkeypatch.setenv("AMGX_BGSB_BC_MIN_ROWS", "0")
+    p, H = elasticity_case((16, 14, 12), rotations=rot, max_coarse_size=10)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    assert dev.hgs[0]["block_color"] is not None
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    orc = Oracle(lv, sm_type=types)
+    rng = np.random.default_rng(5)
+    n = p.n * p.bs
+    fr = np.repeat(p.free, p.bs).astype(np.float64)
+    A = H.levels[0].A.to_scipy()
+    for back in (False, True):
+        for ru, ur, xz in ((False, False, False), (False, True, False), (True, True, True), (False, False, True)):
+            b = rng.standard_normal(n) * fr
+            x = np.zeros(n) if xz else rng.standard_normal(n) * fr
+            res = (b - A @ x) if ru else rng.standard_normal(n)
+            xo, ro = orc.smooth(0, x.copy(), b, res.copy(), ru, ur, xz, back)
+            dev.Smooth(0, x, b, res, ru, ur, xz, back=back)
+            assert np.linalg.norm(x - xo) <= 1e-10 * max(np.linalg.norm(xo), 1.0)
+            if ur:
+                f = fr.astype(bool)
+                assert np.linalg.norm((res - ro)[f]) <= 1e-9 * max(np.linalg.norm(ro[f]), 1.0)
+    u, v = rng.standard_normal(n) * fr, rng.standard_normal(n) * fr
+    assert abs(np.dot(v, dev.apply(u)) - np.dot(u, dev.apply(v))) <= 1e-10 * abs(np.dot(v, dev.apply(u)))
+    b = rng.standard_normal(n) * fr
+    it_h = orc.pcg(b, tol=1e-8, maxit=200)[1]
+    it_seq = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=200)[1]
+    assert it_h <= int(np.ceil(1.15 * it_seq))
+
+
 @pytest.mark.parametrize("rot", [False, True])
 def test_block_levels_hgs_compact_sweep_blocks(rot, monkeypatch):
     """AMGX_BGSB_COMPACT=1: sweep blocks grown over the matrix graph (amgx_level_desc.gs_block_ids) instead of runs of

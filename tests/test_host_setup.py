@@ -212,6 +212,10 @@ def test_spw_agglomeration_is_robust_for_material_jumps():
     A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
     H = Hierarchy(A, p.free, p.coords, dim=2, energy=0, spw=0, robust_soc=1, max_coarse_size=5)
     assert Oracle(H.levels, sm_type="gs").pcg(p.load, tol=1e-6, maxit=200)[1] <= 20
+    # ... and is refused next to the SPW agglomerator, which would silently ignore the vertex scales
+    from ngsamg_amd._lib import NgsAMGError
+    with pytest.raises(NgsAMGError, match="robust_soc needs spw = 0"):
+        Hierarchy(A, p.free, p.coords, dim=2, energy=0, robust_soc=1, max_coarse_size=5)
 
 
 def test_spw_pairing_rule_properties():
