@@ -171,6 +171,8 @@ struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_
   int B = 0, G = 1, TH = 1024;          // rows per block, lanes per row, workgroup size (B * G == TH)
   int n_blocks = 0, n_colors = 0;
   int lowin_maxw = 0;                   // widest slice of `lowin` (entries per lane): <= 5 selects the narrow sweep-from-zero kernel
+  int full_maxw = 0;                    // widest slice of `full`: <= 11 selects the mid-width general sweep (fewer registers: two 1024-lane
+                                        //   workgroups per CU instead of one, so that one block's colour phases hide behind another's loads)
   DevMatrix::Sell full, lowin;          // block-local SELL-G copies (slots colour-sorted inside a block): all entries /
                                         //   only the in-block couplings to LOWER colours (forward sweep from x = 0)
   DevBuf<int32_t> rowid;
@@ -1260,7 +1262,9 @@ struct Handle {
     const bool fz = xin == nullptr;
     const bool narrow = fz && &copy == &g.lowin && g.lowin_maxw > 0 && g.lowin_maxw <= 5 && !std::getenv("AMGX_GSB_NO_NARROW");
 #define LAUNCH_GSB3(TT, GG, ZZ, WW) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ, WW>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
-#define LAUNCH_GSB2(TT, GG) { if (narrow) LAUNCH_GSB3(TT, GG, true, 2); else if (fz) LAUNCH_GSB3(TT, GG, true, GSB_WP); else LAUNCH_GSB3(TT, GG, false, GSB_WP); }
+    const bool mid = !fz && &copy == &g.full && g.G > 1 && g.full_maxw > 0 && g.full_maxw <= 11 && !std::getenv("AMGX_GSB_NO_MID");
+#define LAUNCH_GSB2(TT, GG) { if (narrow) LAUNCH_GSB3(TT, GG, true, 2); else if (fz) LAUNCH_GSB3(TT, GG, true, GSB_WP); \
+                              else if (mid && GG > 1) LAUNCH_GSB3(TT, (GG > 1 ? GG : 2), false, 5); else LAUNCH_GSB3(TT, GG, false, GSB_WP); }
 #define LAUNCH_GSB(TT) switch (g.G) { case 1: LAUNCH_GSB2(TT, 1); break; case 2: LAUNCH_GSB2(TT, 2); break; case 4: LAUNCH_GSB2(TT, 4); break; \
                                       case 8: LAUNCH_GSB2(TT, 8); break; default: LAUNCH_GSB2(TT, 16); break; }
     if (g.TH == 256) LAUNCH_GSB(256) else if (g.TH == 512) LAUNCH_GSB(512) else LAUNCH_GSB(1024)
@@ -2019,7 +2023,7 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
       DevBuf<int64_t> sp;
       const int64_t stored = dev_slice_offsets(*csr, g.rowid.p, slots, sp, G);
       dev_build_sell(*csr, g.rowid.p, slots, G, false, false, nullptr, 0.0, nullptr, sp, stored, g.full, nullptr);
-      max_width(g.full, "A");
+      g.full_maxw = max_width(g.full, "A");
     }
     DevBuf<int32_t> dcolor;
     dcolor.upload(d.color, (size_t)n);
@@ -2071,6 +2075,9 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
     HostSell S;
     build_sell(d.A, rows.data(), slots, false, G, S);
     check_width(S, "A");
+    g.full_maxw = 0;
+    for (size_t q = 0; q + 1 < S.slice_ptr.size(); ++q)
+      g.full_maxw = std::max(g.full_maxw, (int)(((S.slice_ptr[q + 1] & ~(int64_t)63) - (S.slice_ptr[q] & ~(int64_t)63)) / WAVE));
     upload_sell(S, g.full);
   }
   // split for the pre-smoothing from zero: lowin = in-block couplings to lower colours, rest = everything else but the
@@ -2816,7 +2823,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             H.n = L.n; H.ncols = L.ncols; H.bs = L.bs;
             build_gsb(s, H, &s.P, nullptr);
             const DevGSB &x = L.gsb, &y = H.gsb;
-            if (x.B != y.B || x.G != y.G || x.TH != y.TH || x.n_blocks != y.n_blocks || x.n_colors != y.n_colors || x.lowin_maxw != y.lowin_maxw ||
+            if (x.B != y.B || x.G != y.G || x.TH != y.TH || x.n_blocks != y.n_blocks || x.n_colors != y.n_colors || x.lowin_maxw != y.lowin_maxw || x.full_maxw != y.full_maxw ||
                 x.has_split != y.has_split) throw Err("AMGX_VERIFY_IMAGES: block-hybrid Gauss-Seidel: the descriptors differ");
             const size_t nsl = (size_t)((int64_t)x.n_blocks * x.B / (WAVE / x.G));
             verify_same_sell(x.full, y.full, nsl, 0, "block-hybrid Gauss-Seidel: A");
@@ -2856,9 +2863,11 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         // (device builder: A' = A diag(omega Dinv) from the CSR of A that is already there; the diagonal slot carries omega*Dinv_i
         //  under the same conditions as below)
         const bool dev_wdiag = s.omega != 0.0 && !std::getenv("AMGX_NO_WDIAG") && diagA.plain;
-        // levels >= 1 of a reference-shaped hierarchy have ragged long rows: A' takes the length-sorted windowed form there when
-        // plain slices would pad more than 10 % (level 0's FEM rows are uniform and keep the diagonal-first plain form)
-        const int apre_win = (l >= 1 && s.A.n_rows == s.A.n_cols && !std::getenv("AMGX_NO_APRE_WINDOW")) ? SELL_WIN : 0;
+        // levels >= 1 of a reference-shaped hierarchy have ragged long rows (plain slices pad 20 % at the 1.24 M-row level of cfg 2,
+        // length-sorted windows 3.6 %).  Measured NON-win (profiles/r04/l1_experiments.txt): the windowed image with its fused kernel
+        // (sell_win_pre_restrict_kernel) runs that level in 256 us against 215 us -- these levels are bound by the scattered gathers
+        // of x, and sorting the rows of a window by length puts unrelated rows into neighbouring lanes.  Opt-in: AMGX_APRE_WINDOW=1.
+        const int apre_win = (l >= 1 && s.A.n_rows == s.A.n_cols && std::getenv("AMGX_APRE_WINDOW")) ? SELL_WIN : 0;
         if (dev_images && !verify_images && dev_upload_matrix(csrA, L.Apre, true, 1.35, apre_win, &diagA, L.dinv.p, s.omega, dev_wdiag ? L.dinv.p : nullptr)) {
           fused_restrict();
           return;

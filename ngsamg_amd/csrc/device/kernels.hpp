@@ -662,7 +662,7 @@ struct GsbArgs {
 // WP = pair-steps a lane holds (2 * WP + 1 entries): GSB_WP in general; the sweep from zero reads the short `lowin` rows and
 // is instantiated with WP = 2 where they fit (fewer registers: more resident workgroups to hide each other's colour phases)
 template <int TH, int G, bool FROM_ZERO, int WP = GSB_WP>
-__global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : 1)) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
+__global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (TH == 1024 && WP <= 5 && !FROM_ZERO ? 2 : 1))) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
                                                         const double* __restrict__ xin, double* xout) {
   constexpr int B = TH / G;                  // rows per block
   constexpr int RPS = WAVE / G;              // rows per slice

@@ -25,7 +25,7 @@ def gs_block_rows(A):
     """rows per block of the block-hybrid Gauss-Seidel kernel for a scalar level matrix.  G lanes share a row, each holds
     at most 16 entries (+1 when G = 1) in registers; the workgroup has B * G lanes.  Measured at cfg 2:
     one-lane rows run fastest in 256-row blocks (more workgroups per CU hide the colour phases of their neighbours); rows
-    that need several lanes get 1024-lane workgroups, so the blocks stay as large as possible (fewer frozen couplings).
+    that need several lanes get 512-lane workgroups (1024 until round 3).
     0: the level keeps the multicolour form (rows too long, or a level small enough for the single-workgroup tail)."""
     import os
     if A.br == A.bc and A.br in (2, 3, 6) and A.n_rows == A.n_cols:
@@ -41,7 +41,10 @@ def gs_block_rows(A):
     mx = int(np.diff(A.rowptr).max()) if A.n_rows else 0
     for G in (1, 2, 4, 8, 16):
         if mx <= 16 * G + (1 if G == 1 else 0):
-            threads = int(os.environ.get("AMGX_GSB_THREADS", "256") if G == 1 else os.environ.get("AMGX_GSB_THREADS_MULTI", "1024"))
+            # (several lanes per row: 512-lane workgroups since round 4 -- on the long-row coarse levels of a reference-shaped hierarchy
+            #  one 1024-lane workgroup fills a CU's registers and nothing hides its colour phases: level 1 of cfg 2, backward sweep
+            #  299 -> 240 us; PCG iterations at 100^3 with 128 / 64 / 32-row blocks on those levels: 17 / 17 / 17, sequential order 15)
+            threads = int(os.environ.get("AMGX_GSB_THREADS", "256") if G == 1 else os.environ.get("AMGX_GSB_THREADS_MULTI", "512"))
             threads = threads if threads in (256, 512, 1024) else 1024
             return max(16, threads // G)
     return 0
