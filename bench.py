@@ -697,6 +697,15 @@ def main():
                     stream.synchronize()
                     pcg["native_solve_ms"] = round(1e3 * (time.perf_counter() - t_s), 3)
                     pcg["native_iterations"] = int(ncg.iterations)
+                    # the same solve in the single-reduction form of the recurrence (AMGX_PCG_SINGLE_REDUCTION)
+                    scg = NativeCGSolver(amg, amg, tol=1e-8, maxsteps=200, single_reduction=True)
+                    scg.Solve(b)
+                    stream.synchronize()
+                    t_s = time.perf_counter()
+                    scg.Solve(b)
+                    stream.synchronize()
+                    pcg["native_single_reduction_ms"] = round(1e3 * (time.perf_counter() - t_s), 3)
+                    pcg["native_single_reduction_iterations"] = int(scg.iterations)
                     # the same system by restarted GMRES(30) (amgx_gmres; criterion |C r_k| <= tol |C r_0|)
                     from ngsamg_amd.krylov import NativeGMResSolver
                     ngm = NativeGMResSolver(amg, amg, tol=1e-8, maxsteps=200, restart=30)

@@ -49,7 +49,11 @@ enum { AMGX_CLEV_NONE = 0, AMGX_CLEV_INV = 1 };                   /* ngs_amg_cle
 enum {
   AMGX_HOST_PTR = 0,          /* vectors are host arrays: copied H2D / D2H inside the call            */
   AMGX_DEVICE_PTR = 1,        /* vectors are device arrays on the handle's GPU (no copies)            */
-  AMGX_NO_GRAPH = 2           /* launch the kernels directly instead of replaying the captured graph  */
+  AMGX_NO_GRAPH = 2,          /* launch the kernels directly instead of replaying the captured graph  */
+  AMGX_PCG_SINGLE_REDUCTION = 16  /* amgx_pcg / amgx_dist_pcg with a preconditioner: the Chronopoulos / Gear form of the   */
+                              /* same recurrence -- ONE reduction point (one all-reduce of two scalars) per iteration and  */
+                              /* three launches beside the cycle and the level-0 product instead of five; histories agree   */
+                              /* with the classical form to ~1e-6                                                            */
 };
 
 typedef struct amgx_level_desc {
@@ -183,8 +187,9 @@ int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* 
  * Environment of amgx_create: AMGX_NO_DENSE_TAIL=1 disables, AMGX_DENSE_MAX=<n> caps dense_n (default 8192). */
 int amgx_cycle_info(amgx_handle h, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n);
 /* device-format report per level matrix: which = 0 A, 1 P, 2 PT, 3 A' = A*omega*Dinv (pre-smoothing image),
- * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation); fmt: -1 not built, 0 CSR-vector,
- * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows, 4 rigid-body transfer blocks (P_ik = w_ik Q(t_ik)
+ * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation), 5 the "local window" image of A' that the fused down
+ * kernel of a long-row level reads (chunk-local 16-bit columns, gathered vector staged in LDS); fmt: -1 not built, 0 CSR-vector,
+ * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows, 5 local-window sliced-ELL, 4 rigid-body transfer blocks (P_ik = w_ik Q(t_ik)
  * stored as (column, w, t): detected block by block at amgx_create, elasticity_energy.hpp:447-490); stored_entries counts padding
  * (for the traffic model in DESIGN.md) */
 int amgx_matrix_info(amgx_handle h, int level, int which, int32_t* fmt, int64_t* stored_entries, int32_t* lanes_per_row);

@@ -229,6 +229,7 @@ AMGX_UNIQUE_ID_BYTES = 128
 AMGX_CYCLE = {"V": 0, "W": 1, "BS": 2}
 AMGX_CLEV_NONE, AMGX_CLEV_INV = 0, 1
 AMGX_HOST_PTR, AMGX_DEVICE_PTR, AMGX_NO_GRAPH = 0, 1, 2
+AMGX_PCG_SINGLE_REDUCTION = 16
 
 AMGX_SYMBOLS = [
     "amgx_last_error", "amgx_create", "amgx_destroy", "amgx_set_stream", "amgx_synchronize", "amgx_apply",

@@ -252,6 +252,10 @@ struct DevLevel {
   int fused_block = 1024;               // workgroup size = rows per chunk of the fused kernel
   DevMatrix A, P, PT;
   DevMatrix Apre;                       // scalar Jacobi levels: A * diag(omega * dinv), see EP_PRE in kernels.hpp
+  // long-row levels: a second image of A' for the fused down kernel only, with chunk-local 16-bit columns into the sorted list of
+  // the distinct columns of every 256-row chunk (sell_lw_pre_restrict_kernel: the gathered vector is staged in LDS)
+  DevMatrix ApreLW;
+  DevBuf<int32_t> lw_cptr, lw_ccol;
   DevMatrix Q;                          // scalar Jacobi levels of the V-cycle: (I - omega*Dinv*A) P, see fold_prolongation()
   DevBuf<double> dinv;
   DevGS gs;
@@ -907,6 +911,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   int64_t mx_chunk = 0;
   for (int64_t v : fullest) mx_chunk = std::max(mx_chunk, v);
   R.ept = mx_chunk <= (int64_t)4 * threads ? 4 : 6;
+  if (CH == LW_ROWS && threads == 512 && max_entries == 4 * 512) R.ept = mx_chunk <= (int64_t)2 * threads ? 2 : 4;     // (local-window chunks: see lw_image)
   if (const char* e = std::getenv("AMGX_FUSED_EPT_MAX")) if (R.ept > std::atoi(e)) { R = DevRestrict(); return; }     // (A/B hook: keep the separate kernels instead)
   R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr);
   // Measured NON-win (profiles/r01/restrict_fused.txt): storing the partial sums row by row (scattered stores in the
@@ -919,6 +924,53 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   }
   R.w.upload(w); R.fi.upload(fi);
   R.part.alloc((size_t)std::max<int64_t>(1, ns));
+}
+
+// "local window" image of a long-row scalar matrix (sell_lw_pre_restrict_kernel): per chunk of LW_ROWS consecutive rows the sorted
+// list of its distinct columns; the SELL-2 image stores indices into that list.  vals: the (scaled) values in CSR order.
+// Returns false (nothing built) if a chunk touches more than LW_CAP distinct columns.
+static bool build_sell_lw(const amgx_matrix& A, const double* vals, DevMatrix& D, DevBuf<int32_t>& d_cptr, DevBuf<int32_t>& d_ccol) {
+  const int64_t n = A.n_rows, nnz = A.rowptr[n];
+  const int64_t nch = (n + LW_ROWS - 1) / LW_ROWS;
+  std::vector<int32_t> cnt((size_t)nch + 1, 0);
+  RawVec<int32_t> lcol;
+  lcol.resize((size_t)std::max<int64_t>(1, nnz));
+  std::vector<std::vector<int32_t>> lists((size_t)nch);
+  std::vector<char> over(setup_threads(), 0);
+  par_for(nch, [&](int64_t c0, int64_t c1, int t) {
+    std::vector<int32_t> u;
+    for (int64_t c = c0; c < c1; ++c) {
+      const int64_t r0 = c * LW_ROWS, r1 = std::min<int64_t>(n, r0 + LW_ROWS);
+      u.assign(A.col + A.rowptr[r0], A.col + A.rowptr[r1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      if ((int64_t)u.size() > LW_CAP) { over[t] = 1; return; }
+      for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) lcol[k] = (int32_t)(std::lower_bound(u.begin(), u.end(), A.col[k]) - u.begin());
+      cnt[c + 1] = (int32_t)u.size();
+      lists[c] = u;
+    }
+  }, 4);
+  for (char o : over) if (o) return false;
+  for (int64_t c = 0; c < nch; ++c) cnt[c + 1] += cnt[c];
+  std::vector<int32_t> ccol((size_t)std::max<int32_t>(1, cnt[nch]));
+  par_for(nch, [&](int64_t c0, int64_t c1, int) { for (int64_t c = c0; c < c1; ++c) std::copy(lists[c].begin(), lists[c].end(), ccol.begin() + cnt[c]); }, 64);
+  amgx_matrix L = A;
+  L.col = lcol.data();
+  L.val = vals;
+  L.n_cols = LW_CAP;
+  HostSell S;
+  build_sell(L, nullptr, n, false, 2, S, false);
+  const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
+  if (S.n_comp_slices != ns) return false;           // (every slice fits 16-bit deltas by construction; anything else is a builder bug)
+  D.n_rows = n; D.n_cols = A.n_cols; D.br = D.bc = 1; D.nnz = nnz;
+  D.fmt = FMT_SELL; D.lanes = 2;
+  D.n_slices = (int)ns;
+  D.stored = S.slice_ptr.back() & ~(int64_t)63;
+  D.stream_bytes = S.stream_bytes + 4 * (int64_t)ccol.size() + 4 * (nch + 1);
+  upload_sell(S, D.sell);
+  d_cptr.upload(cnt);
+  d_ccol.upload(ccol);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1531,6 +1583,29 @@ struct Handle {
     DevLevel& L = lev[l];
     if (fold && !folded(L)) throw Err("pre_smooth_restrict: level has no folded prolongation");
     const int epf = ep_nt | (fold ? EPF_FOLD : 0);
+    if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty() && !L.ApreLW.empty()) {
+      // long-row level: the local-window image (gathers from LDS), chunks of LW_ROWS rows
+      const DevRestrict& R = L.RF;
+      const int nch = (L.ApreLW.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
+      if (nch != R.n_chunks) throw Err("fused restriction (local-window image): chunk / slice mismatch");
+      int64_t ca, cb;
+      unit_range(sp, LW_ROWS, nch, ca, cb);
+      const int grid = (int)(cb - ca), c0 = (int)ca;
+      const bool probe = probe_level == l && probe_kind == 8 && probe_e0 && sp.part != PART_BND;
+      if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
+      if (grid > 0) {
+#define LAUNCH_LW(EPT_) hipLaunchKernelGGL((sell_lw_pre_restrict_kernel<EPT_>), dim3(grid), dim3(512), 0, stream, L.ApreLW.n_rows, c0, L.ApreLW.n_slices, \
+                           L.ApreLW.sell.view(), L.lw_cptr.p, L.lw_ccol.p, b, L.dinv.p, L.omega, epf, x, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+        if (R.ept == 2) LAUNCH_LW(2); else LAUNCH_LW(4);
+#undef LAUNCH_LW
+      }
+      if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
+      if (!skip_rsum && sp.part != PART_INT)
+        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                           R.oidx.p, R.part.p, b_coarse);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty()) {
       const DevRestrict& R = L.RF;
       const int FB = L.fused_block;
@@ -2840,7 +2915,24 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
       }, "smoother data");
       if (s.sm_type == AMGX_SM_JACOBI && s.A.br == 1 && s.sm_steps <= 1 && !s.sm_symm) {
         tasks.run([&] {
+        // long-row levels (>= 1) of a reference-shaped hierarchy: the "local window" image for the fused down kernel
+        auto lw_image = [&]() -> bool {
+          const int64_t nnzA = s.A.rowptr[s.A.n_rows];
+          const double avgA = s.A.n_rows ? (double)nnzA / (double)s.A.n_rows : 0.0;
+          int64_t lw_min_rows = 100000;
+          if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
+          if (l == 0 || s.A.n_rows != s.A.n_cols || avgA < 24.0 || s.A.n_rows < lw_min_rows || std::getenv("AMGX_NO_LW") ||
+              s.P.br != 1 || s.P.bc != 1 || s.P.rowptr[s.P.n_rows] >= (int64_t)2147483647 || std::getenv("AMGX_NO_FUSED_RESTRICT")) return false;
+          std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnzA)]);
+          par_for(nnzA, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
+          if (!build_sell_lw(s.A, sv.get(), L.ApreLW, L.lw_cptr, L.lw_ccol)) { L.ApreLW = DevMatrix(); return false; }
+          L.fused_block = 512;
+          build_restrict(s.P, L.RF, LW_ROWS, 4 * 512, 512);
+          if (L.RF.empty()) { L.ApreLW = DevMatrix(); L.lw_cptr.release(); L.lw_ccol.release(); return false; }
+          return true;
+        };
         auto fused_restrict = [&] {
+          if (lw_image()) return;
           // fused pre-smoothing + restriction when A' is in the one-thread-per-row SELL form (big levels).
           // Same-process A/B with 4 instances per variant (profiles/r01/restrict_fused.txt): 1-3 % faster cycle than the
           // separate pre-smoothing + P^T gather kernels, and r is never written to HBM.  AMGX_NO_FUSED_RESTRICT=1 disables it.
@@ -3468,10 +3560,10 @@ int amgx_cycle_info(amgx_handle hh, int32_t* tail_level, int32_t* dense_level, i
 int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t* stored, int32_t* lanes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matrix_info: level out of range");
-    if (which < 0 || which > 4) throw amgx::Err("matrix query: which must be 0..4");
+    if (which < 0 || which > 5) throw amgx::Err("matrix query: which must be 0..5");
     const amgx::DevLevel& LV = h.lev[level];
-    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : LV.Q;
-    if (fmt) *fmt = M.empty() ? -1 : ((M.fmt == amgx::FMT_SELL && M.sell.win) ? 3 : M.fmt);
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : LV.ApreLW;
+    if (fmt) *fmt = M.empty() ? -1 : (which == 5 ? 5 : ((M.fmt == amgx::FMT_SELL && M.sell.win) ? 3 : M.fmt));
     if (stored) *stored = M.stored;
     if (lanes) *lanes = M.lanes;
   });
@@ -3480,9 +3572,9 @@ int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t
 int amgx_matrix_stream_bytes(amgx_handle hh, int level, int which, int64_t* bytes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels() || !bytes) throw amgx::Err("amgx_matrix_stream_bytes: bad arguments");
-    if (which < 0 || which > 4) throw amgx::Err("matrix query: which must be 0..4");
+    if (which < 0 || which > 5) throw amgx::Err("matrix query: which must be 0..5");
     const amgx::DevLevel& LV = h.lev[level];
-    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : LV.Q;
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : LV.ApreLW;
     *bytes = M.stream_bytes;
   });
 }

@@ -1010,6 +1010,67 @@ struct DistKrylov {
     return it;
   }
 
+  // ---- single-reduction PCG over the ranks (Krylov::pcg_sr): u = C r, w = A u, ONE ncclAllReduce of (gamma, delta) per iteration
+  // instead of two all-reduces of one scalar; the residual lives in the cycle's right-hand-side buffer, u in the [owned | ghost]
+  // buffer the level-0 product reads
+  std::vector<DevBuf<double>> sr_p, sr_s;
+  DevBuf<double> sr_partial;
+  int pcg_sr(const double* const* b, double* const* x, double tol, int maxit, double* errs) {
+    const size_t R = M.size();
+    if (sr_p.size() != R) {
+      sr_p.clear(); sr_s.clear(); sr_p.resize(R); sr_s.resize(R);
+      for (size_t i = 0; i < R; ++i) { sr_p[i].alloc((size_t)std::max<int64_t>(1, M[i]->n(0))); sr_s[i].alloc((size_t)std::max<int64_t>(1, M[i]->n(0))); }
+      sr_partial.alloc((size_t)2 * KR_BLOCKS * R);
+      HIPCHK(hipMemsetAsync(sr_partial.p, 0, (size_t)2 * KR_BLOCKS * R * sizeof(double), c.compute));
+    }
+    for (size_t i = 0; i < R; ++i) { M[i]->top->zero(sr_p[i].p, M[i]->n(0)); M[i]->top->zero(sr_s[i].p, M[i]->n(0)); }
+    const double one = 1.0;
+    HIPCHK(hipMemcpyAsync(sc.p + SR_FIRST, &one, sizeof(double), hipMemcpyHostToDevice, c.compute));
+    auto precond_u = [&]() {                               // u = C r, written into the owned part of sext
+      std::vector<const double*> bp(R);
+      std::vector<double*> xp(R);
+      for (size_t i = 0; i < R; ++i) { bp[i] = d(i); xp[i] = sext[i].p; }
+      dist_apply(c, bp.data(), xp.data(), 1, AMGX_DEVICE_PTR);
+    };
+    auto av = [&]() { with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->mult(M[i]->top->lev[0].A, sext[i].p, w[i].p, sp); }); };   // w = A u
+    auto reduce = [&]() {
+      for (size_t i = 0; i < R; ++i) {
+        const int64_t n = M[i]->n(0);
+        if (n) hipLaunchKernelGGL(kr_dot2_partial_kernel, dim3(nb(n)), dim3(BLOCK), 0, c.compute, n, d(i), sext[i].p, w[i].p, sr_partial.p + (size_t)i * 2 * KR_BLOCKS);
+      }
+      hipLaunchKernelGGL(kr_sr_reduce_kernel, dim3(2), dim3(BLOCK), 0, c.compute, (int)R, sr_partial.p, sc.p);
+      HIPCHK(hipGetLastError());
+      if (c.kind == AMGX_COMM_RCCL && (c.nranks > 1 || M[0]->force_allgather))
+        NCCLCHK(Rccl::get().AllReduce(sc.p + SR_GNEW, sc.p + SR_GNEW, 2, ncclDouble, ncclSum, c.nccl, c.compute));
+      hipLaunchKernelGGL(kr_sr_scalars_kernel, dim3(1), dim3(1), 0, c.compute, sc.p);
+      HIPCHK(hipGetLastError());
+    };
+    // r = b - A x
+    for (size_t i = 0; i < R; ++i) M[i]->top->copy(sext[i].p, x[i], M[i]->n(0));
+    with_halo(sext, [&](size_t i, Handle::Span sp) { M[i]->top->residual(M[i]->top->lev[0].A, sext[i].p, b[i], d(i), sp); });
+    precond_u();
+    av();
+    reduce();
+    const double err0 = std::sqrt(std::fabs(read(SR_GOLD)));
+    if (errs) errs[0] = err0;
+    if (err0 == 0.0) return 0;
+    int it = 0;
+    for (it = 1; it <= maxit; ++it) {
+      for (size_t i = 0; i < R; ++i) {
+        const int64_t n = M[i]->n(0);
+        if (n) hipLaunchKernelGGL(kr_sr_update_kernel, dim3(Handle::grid_for(n)), dim3(BLOCK), 0, c.compute, n, sc.p, sext[i].p, w[i].p, sr_p[i].p, sr_s[i].p, x[i], d(i));
+      }
+      precond_u();
+      av();
+      reduce();
+      const double err = std::sqrt(std::fabs(read(SR_GOLD)));
+      if (errs) errs[it] = err;
+      if (err <= tol * err0) break;
+    }
+    if (it > maxit) it = maxit;
+    return it;
+  }
+
   // ---- restarted GMRES(m), left-preconditioned, over the ranks: Krylov::gmres with rank-local vectors.  The Arnoldi inner
   // products h = V^T w are ONE fused local pass + ONE ncclAllReduce of j + 1 scalars per Gram-Schmidt pass (the reference's
   // driver is ngsolve.krylovspace.GMRes on ParallelVectors: one MPI all-reduce per inner product); Givens rotations on the
@@ -1335,7 +1396,7 @@ int amgx_dist_pcg(amgx_comm cc, const double* const* b, double* const* x, double
       c.krylov_members = c.members.size();
     }
     amgx::DistKrylov& K = *static_cast<amgx::DistKrylov*>(c.krylov_ws.get());
-    const int it = K.pcg(b, x, tol, maxit, use_precond != 0, errs);
+    const int it = ((flags & AMGX_PCG_SINGLE_REDUCTION) && use_precond) ? K.pcg_sr(b, x, tol, maxit, errs) : K.pcg(b, x, tol, maxit, use_precond != 0, errs);
     if (iters) *iters = it;
   });
 }

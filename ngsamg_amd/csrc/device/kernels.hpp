@@ -662,7 +662,9 @@ struct GsbArgs {
 // WP = pair-steps a lane holds (2 * WP + 1 entries): GSB_WP in general; the sweep from zero reads the short `lowin` rows and
 // is instantiated with WP = 2 where they fit (fewer registers: more resident workgroups to hide each other's colour phases)
 template <int TH, int G, bool FROM_ZERO, int WP = GSB_WP>
-__global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (TH == 1024 && WP <= 5 && !FROM_ZERO ? 2 : 1))) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
+// (second launch-bounds argument = waves per SIMD the register budget must allow: the mid-width general sweep asks for two 1024-lane
+//  or three 512-lane workgroups per CU)
+__global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (WP <= 5 && !FROM_ZERO ? (TH == 1024 ? 8 : 6) : 1))) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
                                                         const double* __restrict__ xin, double* xout) {
   constexpr int B = TH / G;                  // rows per block
   constexpr int RPS = WAVE / G;              // rows per slice
@@ -1330,6 +1332,105 @@ __global__ __launch_bounds__(WB) void sell_win_pre_restrict_kernel(int64_t n_row
     double acc = 0.0;
     for (int k = a; k < bnd; ++k) acc += pr[k];
     part[dest ? dest[sl] : sl] = acc;
+  }
+}
+
+// Fused Jacobi pre-smoothing + residual + chunk-local restriction (sell_pre_restrict_kernel, MODE 0) for the LONG-ROW levels of a
+// reference-shaped hierarchy, with the gathered vector staged in LDS ("local window" image).  On those levels (cfg 2, level 1:
+// 1.24 M rows x 52 entries) 30 % of the plain kernel's time are scattered gathers: a wave step reads entry k of 64 different rows,
+// up to 64 cache lines, and every gathered double drags a line from L2 to the CU (tools/gather_probe.py: 186 us with the real
+// columns, 130 us with perfectly coalesced ones).  Here a 512-lane workgroup owns LW_ROWS = 256 consecutive rows (two lanes per
+// row); the image stores, per chunk, the sorted list of the DISTINCT columns its rows touch (~3 900 of 13 300 entries) and 16-bit
+// indices into that list.  The workgroup loads b at those columns once -- sorted, hence in runs, a quarter of the gathers -- into
+// LDS and the row products gather from LDS (ds_read_b64) instead of L2.  Everything else as in sell_pre_restrict_kernel.
+constexpr int LW_ROWS = 256;                 // rows per chunk
+constexpr int LW_CAP = 4608;                 // distinct columns per chunk the LDS window holds (36 KB); more: the level keeps the plain image
+template <int EPT = 4>
+__global__ __launch_bounds__(512, 6) void sell_lw_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
+                                                                   const int32_t* __restrict__ lw_cptr, const int32_t* __restrict__ lw_ccol,
+                                                                   const double* __restrict__ b, const double* __restrict__ dinv,
+                                                                   double omega, int nt, double* __restrict__ x,
+                                                                   const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ slot_ptr,
+                                                                   const double* __restrict__ w, const uint16_t* __restrict__ fi,
+                                                                   double* __restrict__ part, const int32_t* __restrict__ dest) {
+  constexpr int FB = 512, G = 2;
+  constexpr int MAXE = EPT * FB;
+  __shared__ double xw[LW_CAP];
+  __shared__ double rl[LW_ROWS];
+  __shared__ double pr[MAXE];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int c = chunk0 + sell_unit(M);
+  const int s = __builtin_amdgcn_readfirstlane(c * (FB / WAVE) + (threadIdx.x >> 6));
+  const int row = s * (WAVE / G) + lane / G;
+  const int lrow = (threadIdx.x >> 6) * (WAVE / G) + lane / G;
+  const bool writer = (lane % G) == 0;
+  // stage the window: xw[k] = b[ccol[k]]  (all loads of the prologue are requested before anything is consumed)
+  const int k0 = lw_cptr[c], k1 = lw_cptr[c + 1];
+  double xv[LW_CAP / FB];
+#pragma unroll
+  for (int q = 0; q < LW_CAP / FB; ++q) {
+    const int k = k0 + threadIdx.x + q * FB;
+    xv[q] = k < k1 ? b[lw_ccol[k]] : 0.0;
+  }
+  const bool has_slice = s < n_slices;
+  const int64_t sp0 = has_slice ? M.slice_ptr[s] : 0, sp1 = has_slice ? M.slice_ptr[s + 1] : 0;
+  const int s0 = chunk_slot[c], s1 = chunk_slot[c + 1];
+  const int e0 = slot_ptr[s0], e1 = slot_ptr[s1];
+  double wq[EPT];
+  int fq[EPT];
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = e0 + threadIdx.x + q * FB;
+    wq[q] = e < e1 ? ld_nt(w + e) : 0.0;
+    fq[q] = e < e1 ? (int)ld_nt(fi + e) : 0;
+  }
+  const int myslot = s0 + threadIdx.x;
+  int mydest = myslot, pa_raw = 0, pb_raw = 0;
+  if (myslot < s1) {
+    if (dest) mydest = dest[myslot];
+    pa_raw = slot_ptr[myslot];
+    pb_raw = slot_ptr[myslot + 1];
+  }
+  double bi = 0.0, di = 0.0;
+  if (writer && has_slice && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+#pragma unroll
+  for (int q = 0; q < LW_CAP / FB; ++q) {
+    const int k = threadIdx.x + q * FB;
+    if (k0 + k < k1) xw[k] = xv[q];
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (has_slice) {
+    double xd[2] = {0.0, 0.0};
+    double acc = sell_row_dot_sp(M, sp0, sp1, lane, 0, xw, xd);          // columns = indices into the window
+    acc += __shfl_xor(acc, 1, G);
+    if (writer && row < n_rows) {
+      r = bi - acc;
+      double xi = omega * (di * bi);
+      if (nt & EPF_FOLD) xi += omega * (di * r);
+      if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);
+      else x[row] = xi;
+    }
+  }
+  if (writer) rl[lrow] = r;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < EPT; ++q) {
+    const int e = threadIdx.x + q * FB;
+    if (e0 + e < e1) pr[e] = wq[q] * rl[fq[q]];
+  }
+  __syncthreads();
+  if (myslot < s1) {
+    const int pa = pa_raw - e0, pb = pb_raw - e0;
+    double acc = 0.0;
+    for (int k = pa; k < pb; ++k) acc += pr[k];
+    part[mydest] = acc;
+  }
+  for (int slot = myslot + FB; slot < s1; slot += FB) {
+    const int a = slot_ptr[slot] - e0, bnd = slot_ptr[slot + 1] - e0;
+    double acc = 0.0;
+    for (int k = a; k < bnd; ++k) acc += pr[k];
+    part[dest ? dest[slot] : slot] = acc;
   }
 }
 

@@ -113,6 +113,62 @@ __global__ __launch_bounds__(BLOCK) void kr_scale_kernel(int64_t n, double a, co
   if (i < n) y[i] = (add ? y[i] : 0.0) + a * x[i];
 }
 
+// ---- single-reduction PCG (Chronopoulos / Gear form of the same recurrence): ONE reduction point per iteration -------------
+// gamma = <r, u>, delta = <w, u> with u = C r, w = A u in one pass; partial[blk] / partial[KR_BLOCKS + blk]
+__global__ __launch_bounds__(BLOCK) void kr_dot2_partial_kernel(int64_t n, const double* __restrict__ r, const double* __restrict__ u,
+                                                                const double* __restrict__ w, double* __restrict__ partial) {
+  __shared__ double red[2][BLOCK / WAVE];
+  double a = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) { const double ui = u[i]; a += r[i] * ui; c += w[i] * ui; }
+#pragma unroll
+  for (int o = WAVE >> 1; o > 0; o >>= 1) { a += __shfl_xor(a, o, WAVE); c += __shfl_xor(c, o, WAVE); }
+  if ((threadIdx.x & (WAVE - 1)) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = 0; q < BLOCK / WAVE; ++q) { s0 += red[0][q]; s1 += red[1][q]; }
+    partial[blockIdx.x] = s0;
+    partial[KR_BLOCKS + blockIdx.x] = s1;
+  }
+}
+// scalar slots of the single-reduction recurrence
+enum { SR_GOLD = 0, SR_GNEW = 1, SR_DELTA = 2, SR_ALPHA = 3, SR_BETA = 4, SR_FIRST = 5 };
+// sc[SR_GNEW], sc[SR_DELTA] = sums of the n_local x KR_BLOCKS partials of the two products (fixed order); two workgroups
+__global__ __launch_bounds__(BLOCK) void kr_sr_reduce_kernel(int n_local, const double* __restrict__ partial, double* __restrict__ sc) {
+  __shared__ double red[BLOCK];
+  const int j = blockIdx.x;                    // 0: gamma, 1: delta
+  double acc = 0.0;
+  for (int i = 0; i < n_local; ++i) {
+    const double* p = partial + ((size_t)i * 2 + j) * KR_BLOCKS;
+    for (int q = threadIdx.x; q < KR_BLOCKS; q += BLOCK) acc += p[q];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = BLOCK >> 1; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) sc[SR_GNEW + j] = red[0];
+}
+// beta = gamma_new / gamma_old (0 on the first pass), alpha = gamma_new / (delta - beta * gamma_new / alpha_old); gamma_old <- gamma_new
+__global__ void kr_sr_scalars_kernel(double* __restrict__ sc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double g = sc[SR_GNEW], d = sc[SR_DELTA];
+  const bool first = sc[SR_FIRST] != 0.0;
+  const double beta = first ? 0.0 : g / sc[SR_GOLD];
+  const double alpha = first ? g / d : g / (d - beta * g / sc[SR_ALPHA]);
+  sc[SR_BETA] = beta; sc[SR_ALPHA] = alpha; sc[SR_GOLD] = g; sc[SR_FIRST] = 0.0;
+}
+// p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s      (one pass: 6 reads, 4 writes)
+__global__ __launch_bounds__(BLOCK) void kr_sr_update_kernel(int64_t n, const double* __restrict__ sc, const double* __restrict__ u,
+                                                             const double* __restrict__ w, double* __restrict__ p, double* __restrict__ s,
+                                                             double* __restrict__ x, double* __restrict__ r) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double alpha = sc[SR_ALPHA], beta = sc[SR_BETA];
+  const double pi = u[i] + beta * p[i], si = w[i] + beta * s[i];
+  p[i] = pi; s[i] = si;
+  x[i] += alpha * pi;
+  r[i] -= alpha * si;
+}
+
 struct Krylov {
   Handle& h;
   int64_t n;
@@ -181,6 +237,45 @@ struct Krylov {
       hipLaunchKernelGGL(kr_xpby_kernel, dim3(grid()), dim3(BLOCK), 0, h.stream, n, sc.p, cur, old, w.p, s.p);               // beta = <w,d>_new / <w,d>_old
       HIPCHK(hipGetLastError());
       const double err = std::sqrt(std::fabs(read(cur)));
+      if (errs) errs[it] = err;
+      if (err <= tol * err0) break;
+    }
+    if (it > maxit) it = maxit;
+    return it;
+  }
+
+  // The same preconditioned CG with ONE reduction point per iteration (Chronopoulos / Gear): u = C r, w = A u, gamma = <r, u> and
+  // delta = <w, u> in one fused pass, alpha and beta from (gamma, delta) on the device, then p, s, x, r in one fused pass -- three
+  // launches per iteration beside the cycle and the level-0 product instead of five, and one device -> host scalar.  Mathematically
+  // the recurrence of pcg() (alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}) equals <C r, r> / <p, A p>); the rounding
+  // differs, histories agree to ~1e-6 (tests/test_gpu_krylov.py).  err_k = sqrt(|<C r_k, r_k>|) as in pcg().
+  int pcg_sr(const double* b, double* x, double tol, int maxit, double* errs) {
+    DevBuf<double> r, u, w, p, s;
+    r.alloc(n); u.alloc(n); w.alloc(n); p.alloc(n); s.alloc(n);
+    h.zero(p.p, n); h.zero(s.p, n);
+    const double one = 1.0;
+    HIPCHK(hipMemcpyAsync(sc.p + SR_FIRST, &one, sizeof(double), hipMemcpyHostToDevice, h.stream));
+    auto reduce = [&]() {
+      hipLaunchKernelGGL(kr_dot2_partial_kernel, dim3(nb()), dim3(BLOCK), 0, h.stream, n, r.p, u.p, w.p, partial.p);
+      hipLaunchKernelGGL(kr_sr_reduce_kernel, dim3(2), dim3(BLOCK), 0, h.stream, 1, partial.p, sc.p);
+      hipLaunchKernelGGL(kr_sr_scalars_kernel, dim3(1), dim3(1), 0, h.stream, sc.p);
+      HIPCHK(hipGetLastError());
+    };
+    h.residual(h.lev[0].A, x, b, r.p);                       // r = b - A x
+    precond(r.p, u.p, true);
+    h.mult(h.lev[0].A, u.p, w.p);
+    HIPCHK(hipMemsetAsync(partial.p, 0, (size_t)2 * KR_BLOCKS * sizeof(double), h.stream));   // (slots a short vector never writes)
+    reduce();
+    const double err0 = std::sqrt(std::fabs(read(SR_GOLD)));
+    if (errs) errs[0] = err0;
+    if (err0 == 0.0) return 0;
+    int it = 0;
+    for (it = 1; it <= maxit; ++it) {
+      hipLaunchKernelGGL(kr_sr_update_kernel, dim3(grid()), dim3(BLOCK), 0, h.stream, n, sc.p, u.p, w.p, p.p, s.p, x, r.p);
+      precond(r.p, u.p, true);
+      h.mult(h.lev[0].A, u.p, w.p);
+      reduce();
+      const double err = std::sqrt(std::fabs(read(SR_GOLD)));
       if (errs) errs[it] = err;
       if (err <= tol * err0) break;
     }
@@ -280,7 +375,7 @@ int amgx_pcg(amgx_handle hh, const double* b, double* x, double tol, int maxit, 
     double* dx = st.inout(1, x, n, true, 0);
     if (use_precond && (db == h.lev[0].x.p || dx == h.lev[0].x.p)) throw amgx::Err("amgx_pcg: vectors alias the handle's work vectors");
     amgx::Krylov K(h);
-    const int it = K.pcg(db, dx, tol, maxit, use_precond != 0, errs);
+    const int it = ((flags & AMGX_PCG_SINGLE_REDUCTION) && use_precond) ? K.pcg_sr(db, dx, tol, maxit, errs) : K.pcg(db, dx, tol, maxit, use_precond != 0, errs);
     if (iters) *iters = it;
     st.out(1, x, n, 0);
     st.finish();

@@ -964,13 +964,13 @@ class DistributedAMG:
         self.ops = [backend(top, self.tail_hier, i) for i, top in enumerate(self.tops)]
         self._alloc()
 
-    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True):
+    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True, single_reduction=False):
         """collective preconditioned CG on the rank-partitioned level-0 operator with this cycle as preconditioner
         (amgx_dist_pcg; the reference's driver is NGSolve's CGSolver on ParallelVectors, tests/h1/amg_utils.py:337-363).
         bs[i], xs[i]: owned level-0 CUDA tensors of local rank i; xs hold the initial guess.  Returns (iterations, errs)."""
         if self._dev is None:
             raise NgsAMGError("pcg: needs the device driver (no CPU path)")
-        return self._dev.pcg(bs, xs, tol=tol, maxsteps=maxsteps, use_pre=use_pre)
+        return self._dev.pcg(bs, xs, tol=tol, maxsteps=maxsteps, use_pre=use_pre, single_reduction=single_reduction)
 
     def gmres(self, bs, xs, tol=1e-8, maxsteps=200, restart=30, use_pre=True):
         """collective restarted GMRES(restart) with this cycle as left preconditioner (amgx_dist_gmres)"""
@@ -1453,9 +1453,10 @@ class _DeviceDist:
         self._ck(self._lib.amgx_comm_info(self._comm, None, None, None, C.byref(ne)))
         return ne.value
 
-    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True):
+    def pcg(self, bs, xs, tol=1e-8, maxsteps=200, use_pre=True, single_reduction=False):
         """amgx_dist_pcg: collective PCG with the rank-partitioned cycle as preconditioner; xs hold the initial guess and
-        receive the solution.  Returns (iterations, err_0 .. err_iterations)."""
+        receive the solution.  Returns (iterations, err_0 .. err_iterations).  single_reduction: one all-reduce of two scalars per
+        iteration (AMGX_PCG_SINGLE_REDUCTION) instead of two of one."""
         import torch
         self._bind_stream()
         n = len(self._dists)
@@ -1468,7 +1469,8 @@ class _DeviceDist:
         px = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
         errs = np.zeros(int(maxsteps) + 1)
         it = C.c_int32()
-        self._ck(self._lib.amgx_dist_pcg(self._comm, pb, px, float(tol), int(maxsteps), int(bool(use_pre)), _lib.AMGX_DEVICE_PTR,
+        self._ck(self._lib.amgx_dist_pcg(self._comm, pb, px, float(tol), int(maxsteps), int(bool(use_pre)),
+                                         _lib.AMGX_DEVICE_PTR | (_lib.AMGX_PCG_SINGLE_REDUCTION if single_reduction else 0),
                                          _lib.ptr(errs, C.c_double), C.byref(it)))
         return it.value, errs[:it.value + 1]
 

@@ -101,7 +101,7 @@ class _NativeSolver:
         vb, vx = _Vec(rhs, n, "rhs"), _Vec(sol, n, "sol", True)
         errs = np.zeros(self.maxsteps + 1)
         it = C.c_int32()
-        flags = self.mat._flags(vb, vx)
+        flags = self.mat._flags(vb, vx) | int(getattr(self, "_extra_flags", 0))
         self.mat._ck(fn(self.mat._h, vb.addr, vx.addr, float(self.tol), int(self.maxsteps), *extra, int(self.use_pre), flags,
                         errs.ctypes.data_as(C.POINTER(C.c_double)), C.byref(it)))
         self.iterations = int(it.value)
@@ -110,7 +110,14 @@ class _NativeSolver:
 
 
 class NativeCGSolver(_NativeSolver):
-    """NGSolve CGSolver stand-in running inside libngsamg_hip (amgx_pcg): err_k = sqrt(|<C r_k, r_k>|), stop at err_k <= tol err_0"""
+    """NGSolve CGSolver stand-in running inside libngsamg_hip (amgx_pcg): err_k = sqrt(|<C r_k, r_k>|), stop at err_k <= tol err_0.
+    single_reduction: the Chronopoulos / Gear form of the recurrence (AMGX_PCG_SINGLE_REDUCTION: one reduction point and three
+    launches per iteration beside the cycle and the level-0 product instead of five)"""
+
+    def __init__(self, mat, pre=None, tol=1e-12, maxsteps=100, single_reduction=False):
+        super().__init__(mat, pre, tol, maxsteps)
+        from . import _lib
+        self._extra_flags = _lib.AMGX_PCG_SINGLE_REDUCTION if single_reduction else 0
 
     def Solve(self, rhs, sol=None):
         return self._run(self.mat._lib.amgx_pcg, rhs, sol, ())

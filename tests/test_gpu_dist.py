@@ -707,3 +707,32 @@ def test_distributed_gmres_history_equals_serial_oracle(R, box, dmin, sm, restar
         x.zero_()
     it2, errs2 = amg.gmres(bs, xs, tol=1e-9, maxsteps=150, restart=restart)
     assert it2 == it and np.array_equal(errs2, errs)
+
+
+@pytest.mark.parametrize("R,box,dmin,sm", [(2, (14, 12, 12), 100, "jacobi"), (4, (10, 10, 10), 50, "hgs")])
+def test_distributed_single_reduction_pcg_equals_serial_oracle(R, box, dmin, sm):
+    """amgx_dist_pcg with AMGX_PCG_SINGLE_REDUCTION: one all-reduce of (gamma, delta) per iteration; history of the serial oracle's
+    classical PCG on the assembled global hierarchy to 1e-6"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    from tests.dist_oracle import oracle_bgs, oracle_sm_types
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10, sm_type=sm,
+                           **({"hgs_block_rows": 256} if sm == "hgs" else {}))
+    rng = np.random.default_rng(5)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.zeros(s.n, dtype=torch.float64, device="cuda") for s in states]
+    it, errs = amg.pcg(bs, xs, tol=1e-9, maxsteps=100, single_reduction=True)
+    torch.cuda.synchronize()
+    glv = amg.global_levels()
+    orc = Oracle(glv, sm_type="jacobi") if sm == "jacobi" else Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv))
+    xo, ito, erro = orc.pcg(np.concatenate(bh), tol=1e-9, maxit=100)
+    assert abs(it - ito) <= 1
+    k = min(it, ito)
+    assert np.allclose(errs[:k], erro[:k], rtol=1e-6)
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - xo) <= 1e-7 * np.linalg.norm(xo)

@@ -91,3 +91,22 @@ def test_native_gmres_history_equals_oracle_gmres(restart, sm):
     assert errs.shape == erro.shape and np.all(np.abs(errs - erro) <= 1e-6 * erro[0])
     assert np.allclose(errs[:4], erro[:4], rtol=1e-9)
     assert np.linalg.norm(x - xo) <= 1e-7 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("sm,osm", [("jacobi", "jacobi"), ("gs", "gs_mc")])
+def test_single_reduction_pcg_history_equals_classical(sm, osm):
+    """AMGX_PCG_SINGLE_REDUCTION (Chronopoulos / Gear form: one reduction point, three launches per iteration) against the oracle's
+    classical PCG: same iteration count (+-1), histories equal to 1e-6, same solution"""
+    import torch
+    from ngsamg_amd.krylov import NativeCGSolver
+    from oracle.pyoracle import Oracle
+    p, H, dev = _case((25, 25, 25), sm)
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal(p.n) * p.free
+    cg = NativeCGSolver(dev, dev, tol=1e-10, maxsteps=100, single_reduction=True)
+    x = cg.Solve(torch.from_numpy(b).cuda()).cpu().numpy()
+    xo, it, errs = Oracle(H.levels, sm_type=osm).pcg(b, tol=1e-10, maxit=100)
+    assert abs(cg.iterations - it) <= 1
+    k = min(cg.iterations, it)
+    assert np.allclose(cg.errors[:k], errs[:k], rtol=1e-6)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)

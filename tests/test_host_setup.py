@@ -353,3 +353,40 @@ def test_prolongation_types_of_the_reference():
     assert n_classic > 100                      # (3D: most vertices see more than 5 aggregates and take the aux branch)
     with pytest.raises(NgsAMGError):
         Hierarchy(A, p.free, p.coords, dim=3, prol_type="smoothest")
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_block_coloured_gauss_seidel_order_is_inside_the_iteration_tolerance(rot):
+    """host data of the block-coloured Gauss-Seidel form (ngsamg_amd.device.block_colored_gs_data: in-block colours, a colouring
+    of the block graph, plain diagonal) on an elasticity level with grid-LINE sweep blocks: the oracle's Gauss-Seidel in the order
+    (block colour, block, in-block colour) needs at most 15 % more PCG iterations than the reference's sequential order,
+    where the hybrid form with the same blocks (couplings between blocks frozen) needs more"""
+    from copy import copy
+    from ngsamg_amd.device import block_colored_gs_data, hybrid_gs_data
+    from oracle.pyoracle import Oracle
+    from tests.hgs_oracle import hgs_levels
+    nv = 18
+    p = fem.elasticity_fast((nv, nv, nv), dirichlet="left", mu=1.0, lam=0.5, rotations=rot)
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    from ngsamg_amd.hierarchy import Hierarchy
+    H = Hierarchy(A, p.free, p.coords, dim=3, energy=1, max_coarse_size=20, regularize_cmats=0 if rot else 1)
+    lv0 = H.levels[0]
+    B = nv                                            # one sweep block = one grid line
+    col, nc, bcol, nbc, dinv = block_colored_gs_data(lv0.A, lv0.free, B, lv0.dinv)
+    blk = np.arange(lv0.n) // B
+    assert nbc >= 2 and np.all(bcol[blk * B] == bcol)                     # constant inside a block
+    S = sp.csr_matrix((np.ones(len(lv0.A.col)), np.asarray(lv0.A.col), np.asarray(lv0.A.rowptr)), shape=(lv0.n, lv0.n)).tocoo()
+    cross = blk[S.row] != blk[S.col]
+    assert np.all(bcol[S.row[cross]] != bcol[S.col[cross]])               # coupled blocks differ: the in-place launches cannot race
+    info = [dict(B=B, color=col, n_colors=nc, dinv=dinv, block_of_row=None, block_color=bcol, n_block_colors=nbc)] + [None] * (H.n_levels - 1)
+    lv, types = hgs_levels(H.levels, info)
+    hcol, hnc, hdinv = hybrid_gs_data(lv0.A, lv0.free, B, pinv=not rot)
+    hinfo = [dict(B=B, color=hcol, n_colors=hnc, dinv=hdinv, block_of_row=None)] + [None] * (H.n_levels - 1)
+    hlv, htypes = hgs_levels(H.levels, hinfo)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    it_seq = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=200)[1]
+    it_bc = Oracle(lv, sm_type=types).pcg(b, tol=1e-8, maxit=200)[1]
+    it_hy = Oracle(hlv, sm_type=htypes).pcg(b, tol=1e-8, maxit=200)[1]
+    assert it_bc <= int(np.ceil(1.15 * it_seq)), (it_bc, it_seq)
+    assert it_bc <= it_hy, (it_bc, it_hy)
