@@ -228,6 +228,9 @@ struct DevRestrict {                    // column-blocked P^T (see restrict_chun
   DevBuf<double> w, part;
   DevBuf<uint16_t> fi;
   int ept = 4;                          // entries of P per thread of the fused kernels (4 or 6: the fullest chunk decides)
+  // compact chunks (cluster_slices): chunk c works on the 64-row slices slice_list[c * spc .. (c + 1) * spc) instead of spc
+  // consecutive ones (-1: no slice); empty = consecutive slices
+  DevBuf<int32_t> slice_list;
   bool empty() const { return n_chunks == 0; }
 };
 
@@ -433,7 +436,9 @@ static int64_t sell_stored(const amgx_matrix& A, int G) {
   return stored;
 }
 
-static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, int G, HostSell& S, bool want_diag_first = false) {
+// no16 (optional, per row of A): slices holding such a row keep the 32-bit column encoding
+static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, bool rowrel, int G, HostSell& S, bool want_diag_first = false,
+                       const std::vector<char>* no16 = nullptr) {
   const int R = WAVE / G;
   const int64_t ns = (m + R - 1) / R;
   S.rowrel = rowrel ? 1 : 0;
@@ -488,6 +493,8 @@ static void build_sell(const amgx_matrix& A, const int32_t* rows, int64_t m, boo
     // (lane l, column j) -> entry index within the lane's row
     auto entry = [&](int l, int j) { return (G == 1) ? j : 2 * ((j >> 1) * G + (l % G)) + (j & 1); };
     bool comp = true;
+    if (no16)
+      for (int r = 0; r < R; ++r) { const int64_t rr = row_of(s * R + r); if (rr >= 0 && (*no16)[rr]) comp = false; }
     for (int j = 0; j < w; ++j) {
       // pass 1: real entries -> 32-bit columns, column base for the 16-bit form
       int64_t cb = INT64_MAX;
@@ -852,11 +859,84 @@ static void build_bgs(const amgx_level_desc& d, DevLevel& L) {
   g.val.upload(d.A.val, (size_t)nnz * bs * bs);
 }
 
+// Compact chunks for the fused pre-smoothing + restriction kernels.  A chunk of 512 CONSECUTIVE rows of a lexicographically numbered
+// grid is 2.4 grid lines of one plane, while the fine support of a coarse basis function spans 4 lines x 4 planes: 13 chunks hold a
+// piece of every coarse row (cfg 2, reference hierarchy: 16 M partial sums for 1.24 M coarse rows, restrict_sum_kernel 53 us).  The
+// matrix image keeps its natural 64-row slices (coalesced streaming, diagonal-first rows, row-relative 16-bit columns); only the
+// ASSIGNMENT of slices to workgroups changes: slices that share coarse columns are clustered greedily over the slice graph (shared
+// columns of P as weights), spc slices per chunk.  On the grid above a chunk becomes ~64 (x) x 3 x 3: 4-5 partial sums per coarse row.
+// Returns the slice list (n_chunks * spc entries, -1 = no slice).  Independent ranges per setup thread (chunks do not cross them).
+static std::vector<int32_t> cluster_slices(const amgx_matrix& P, int spc) {
+  const int64_t nf = P.n_rows, nc = P.n_cols;
+  const int64_t ns = (nf + WAVE - 1) / WAVE;
+  // coarse columns of every slice (sorted, unique) and the slices of every coarse column
+  std::vector<int64_t> sptr((size_t)ns + 1, 0);
+  std::vector<std::vector<int32_t>> scols((size_t)ns);
+  par_for(ns, [&](int64_t s0, int64_t s1, int) {
+    for (int64_t sl = s0; sl < s1; ++sl) {
+      std::vector<int32_t>& u = scols[sl];
+      const int64_t r0 = sl * WAVE, r1 = std::min<int64_t>(nf, r0 + WAVE);
+      u.assign(P.col + P.rowptr[r0], P.col + P.rowptr[r1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+    }
+  }, 64);
+  std::vector<int32_t> cptr((size_t)nc + 1, 0);
+  for (int64_t sl = 0; sl < ns; ++sl) for (int32_t J : scols[sl]) cptr[J + 1]++;
+  for (int64_t J = 0; J < nc; ++J) cptr[J + 1] += cptr[J];
+  std::vector<int32_t> cs((size_t)cptr[nc]);
+  { std::vector<int32_t> pos(cptr.begin(), cptr.end() - 1); for (int64_t sl = 0; sl < ns; ++sl) for (int32_t J : scols[sl]) cs[pos[J]++] = (int32_t)sl; }
+  const int T = std::max(1, std::min<int>(setup_threads(), (int)(ns / (64 * spc) + 1)));
+  std::vector<std::vector<int32_t>> lists((size_t)T);
+  std::vector<std::thread> th;
+  auto work = [&](int t) {
+    const int64_t a = ns * t / T, b = ns * (t + 1) / T;
+    std::vector<char> done((size_t)(b - a), 0);
+    std::vector<int32_t> wgt((size_t)(b - a), 0), touched;
+    std::vector<int32_t>& out = lists[t];
+    for (int64_t seed = a; seed < b; ++seed) {
+      if (done[seed - a]) continue;
+      touched.clear();
+      int64_t cur = seed;
+      for (int q = 0; q < spc; ++q) {
+        out.push_back((int32_t)cur);
+        done[cur - a] = 1;
+        if (q + 1 == spc) break;
+        for (int32_t J : scols[cur])
+          for (int32_t k = cptr[J]; k < cptr[J + 1]; ++k) {
+            const int64_t o = cs[k];
+            if (o < a || o >= b || done[o - a]) continue;
+            if (wgt[o - a]++ == 0) touched.push_back((int32_t)o);
+          }
+        int64_t best = -1;
+        int32_t bw = 0;
+        for (int32_t o : touched) if (!done[o - a] && (wgt[o - a] > bw || (wgt[o - a] == bw && bw > 0 && o < best))) { bw = wgt[o - a]; best = o; }
+        if (best < 0) {                                        // nothing adjacent is left: take the next free slice in order
+          for (int64_t o = seed + 1; o < b; ++o) if (!done[o - a]) { best = o; break; }
+          if (best < 0) { for (int r = q + 1; r < spc; ++r) out.push_back(-1); break; }
+        }
+        cur = best;
+      }
+      for (int32_t o : touched) wgt[o - a] = 0;
+    }
+  };
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  std::vector<int32_t> list;
+  for (int t = 0; t < T; ++t) list.insert(list.end(), lists[t].begin(), lists[t].end());
+  return list;
+}
+
 // CH = fine rows per chunk; threads = workgroup size of the kernel that consumes the chunk (= CH unless several lanes share a row)
-static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES, int threads = 0) {
+// slice_list (optional, one thread per row only): chunk c = the 64-row slices slice_list[c * CH / 64 ...) (cluster_slices)
+static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRICT_CHUNK, int max_entries = RESTRICT_MAX_ENTRIES, int threads = 0,
+                           const std::vector<int32_t>* slice_list = nullptr) {
   if (threads <= 0) threads = CH;
   const int64_t nf = P.n_rows, nc = P.n_cols;
-  const int64_t nch = (nf + CH - 1) / CH;
+  const int spc = CH / WAVE;
+  if (slice_list && (CH % WAVE != 0 || slice_list->size() % spc != 0)) throw Err("build_restrict: slice list does not match the chunk size");
+  const int64_t nch = slice_list ? (int64_t)slice_list->size() / spc : (nf + CH - 1) / CH;
   // pass 1 (parallel over chunks): slots (= distinct coarse columns) per chunk; a chunk's entries are the P entries of its rows
   std::vector<int32_t> chunk_slot(nch + 1, 0);
   std::vector<char> too_long(setup_threads(), 0);
@@ -864,11 +944,22 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   struct Trip { int32_t J; uint16_t i; double w; };
   auto chunk_trips = [&](int64_t c, std::vector<Trip>& t) {
     t.clear();
-    const int64_t r0 = c * CH, r1 = std::min<int64_t>(nf, r0 + CH);
-    for (int64_t i = r0; i < r1; ++i)
-      for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) t.push_back({P.col[k], (uint16_t)(i - r0), P.val[k]});
+    if (slice_list) {
+      for (int q = 0; q < spc; ++q) {
+        const int64_t sl = (*slice_list)[c * spc + q];
+        if (sl < 0) continue;
+        const int64_t r0 = sl * WAVE, r1 = std::min<int64_t>(nf, r0 + WAVE);
+        for (int64_t i = r0; i < r1; ++i)
+          for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) t.push_back({P.col[k], (uint16_t)(q * WAVE + (i - r0)), P.val[k]});
+      }
+    } else {
+      const int64_t r0 = c * CH, r1 = std::min<int64_t>(nf, r0 + CH);
+      for (int64_t i = r0; i < r1; ++i)
+        for (int64_t k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) t.push_back({P.col[k], (uint16_t)(i - r0), P.val[k]});
+    }
     std::stable_sort(t.begin(), t.end(), [](const Trip& a, const Trip& b) { return a.J < b.J; });
   };
+  std::vector<int64_t> chunk_ent(nch + 1, 0);            // first entry of every chunk
   par_for(nch, [&](int64_t c0, int64_t c1, int tid) {
     std::vector<Trip> t;
     for (int64_t c = c0; c < c1; ++c) {
@@ -878,20 +969,21 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
       int32_t nsl = 0;
       for (size_t q = 0; q < t.size(); ++q) if (q == 0 || t[q].J != t[q - 1].J) nsl++;
       chunk_slot[c + 1] = nsl;
+      chunk_ent[c + 1] = (int64_t)t.size();
     }
   }, 8);
   for (char c : too_long) if (c) return;             // rows too long for the LDS product buffer: keep the P^T form
-  for (int64_t c = 0; c < nch; ++c) chunk_slot[c + 1] += chunk_slot[c];
+  for (int64_t c = 0; c < nch; ++c) { chunk_slot[c + 1] += chunk_slot[c]; chunk_ent[c + 1] += chunk_ent[c]; }
   const int64_t n_slots = chunk_slot[nch], n_ent = P.rowptr[nf];
   std::vector<int32_t> slot_ptr((size_t)n_slots + 1, 0), slot_col((size_t)n_slots);
   std::vector<double> w((size_t)n_ent);
   std::vector<uint16_t> fi((size_t)n_ent);
-  // pass 2: fill (entries of chunk c start at rowptr[c * CH]: the chunk's rows are consecutive)
+  // pass 2: fill (entries of chunk c start at chunk_ent[c])
   par_for(nch, [&](int64_t c0, int64_t c1, int) {
     std::vector<Trip> t;
     for (int64_t c = c0; c < c1; ++c) {
       chunk_trips(c, t);
-      int64_t e = P.rowptr[c * CH];
+      int64_t e = chunk_ent[c];
       int64_t sl = chunk_slot[c];
       for (size_t q = 0; q < t.size(); ++q) {
         if (q == 0 || t[q].J != t[q - 1].J) { slot_ptr[sl] = (int32_t)e; slot_col[sl] = t[q].J; sl++; }
@@ -924,6 +1016,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   }
   R.w.upload(w); R.fi.upload(fi);
   R.part.alloc((size_t)std::max<int64_t>(1, ns));
+  if (slice_list) R.slice_list.upload(*slice_list);
 }
 
 // "local window" image of a long-row scalar matrix (sell_lw_pre_restrict_kernel): per chunk of LW_ROWS consecutive rows the sorted
@@ -936,7 +1029,11 @@ static bool build_sell_lw(const amgx_matrix& A, const double* vals, DevMatrix& D
   RawVec<int32_t> lcol;
   lcol.resize((size_t)std::max<int64_t>(1, nnz));
   std::vector<std::vector<int32_t>> lists((size_t)nch);
-  std::vector<char> over(setup_threads(), 0);
+  std::vector<char> no16((size_t)n, 0);                 // rows of chunks whose window would not fit: global 32-bit columns, no window
+  int64_t cap = LW_CAP;
+  const char* tcap = std::getenv("AMGX_LW_TEST_CAP");    // (tests: a smaller capacity sends some chunks through the no-window path)
+  if (tcap) cap = std::min<int64_t>(cap, std::atoll(tcap));
+  std::vector<int64_t> n_over(setup_threads(), 0);
   par_for(nch, [&](int64_t c0, int64_t c1, int t) {
     std::vector<int32_t> u;
     for (int64_t c = c0; c < c1; ++c) {
@@ -944,24 +1041,33 @@ static bool build_sell_lw(const amgx_matrix& A, const double* vals, DevMatrix& D
       u.assign(A.col + A.rowptr[r0], A.col + A.rowptr[r1]);
       std::sort(u.begin(), u.end());
       u.erase(std::unique(u.begin(), u.end()), u.end());
-      if ((int64_t)u.size() > LW_CAP) { over[t] = 1; return; }
+      if ((int64_t)u.size() > cap) {
+        for (int64_t i = r0; i < r1; ++i) no16[i] = 1;
+        for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) lcol[k] = A.col[k];
+        n_over[t]++;
+        continue;
+      }
       for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) lcol[k] = (int32_t)(std::lower_bound(u.begin(), u.end(), A.col[k]) - u.begin());
       cnt[c + 1] = (int32_t)u.size();
       lists[c] = u;
     }
   }, 4);
-  for (char o : over) if (o) return false;
+  int64_t overs = 0;
+  for (int64_t v : n_over) overs += v;
+  if (overs * 20 > nch && !tcap) return false;          // (more than 5 % of the chunks without a window: the plain image is the better choice)
   for (int64_t c = 0; c < nch; ++c) cnt[c + 1] += cnt[c];
   std::vector<int32_t> ccol((size_t)std::max<int32_t>(1, cnt[nch]));
   par_for(nch, [&](int64_t c0, int64_t c1, int) { for (int64_t c = c0; c < c1; ++c) std::copy(lists[c].begin(), lists[c].end(), ccol.begin() + cnt[c]); }, 64);
   amgx_matrix L = A;
   L.col = lcol.data();
   L.val = vals;
-  L.n_cols = LW_CAP;
   HostSell S;
-  build_sell(L, nullptr, n, false, 2, S, false);
+  build_sell(L, nullptr, n, false, 2, S, false, &no16);
   const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
-  if (S.n_comp_slices != ns) return false;           // (every slice fits 16-bit deltas by construction; anything else is a builder bug)
+  // (every slice of a chunk with a window fits 16-bit deltas by construction: indices < LW_CAP; anything else would be a builder bug)
+  int64_t want16 = 0;
+  for (int64_t sl = 0; sl < ns; ++sl) if (!no16[std::min<int64_t>(n - 1, sl * (WAVE / 2))]) ++want16;
+  if (S.n_comp_slices != want16) return false;
   D.n_rows = n; D.n_cols = A.n_cols; D.br = D.bc = 1; D.nnz = nnz;
   D.fmt = FMT_SELL; D.lanes = 2;
   D.n_slices = (int)ns;
@@ -1610,8 +1716,9 @@ struct Handle {
       const DevRestrict& R = L.RF;
       const int FB = L.fused_block;
       const int G = L.Apre.lanes;
-      const int nch = (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
+      const int nch = R.slice_list.n ? R.n_chunks : (L.Apre.n_slices + (FB / WAVE) - 1) / (FB / WAVE);
       if (nch != R.n_chunks) throw Err("fused restriction: chunk / slice mismatch");
+      if (R.slice_list.n && sp.part != PART_ALL) throw Err("fused restriction: compact chunks are not split into interior / boundary parts");
       int64_t ca, cb;
       unit_range(sp, FB / G, nch, ca, cb);
       const int grid = (int)(cb - ca), c0 = (int)ca;
@@ -1620,7 +1727,8 @@ struct Handle {
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       if (grid > 0) {
 #define LAUNCH_PRF(FB_, EPT_) hipLaunchKernelGGL((sell_pre_restrict_kernel<FB_, 0, EPT_>), dim3(grid), dim3(FB_), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
-                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+                             L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p, \
+                             (const int32_t*)R.slice_list.p)
 #define LAUNCH_PRG(G_) hipLaunchKernelGGL((sell_pre_restrict_kernel<512, 0, 4, G_>), dim3(grid), dim3(512), 0, stream, L.Apre.n_rows, c0, L.Apre.n_slices, \
                              L.Apre.sell.view(), b, L.dinv.p, L.omega, epf, x, (double*)nullptr, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
         if (L.Apre.sell.win) {
@@ -2949,6 +3057,13 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             L.fused_block = 512;       // same-process A/B: 512 < 1024 (epilogues of more, smaller workgroups overlap better)
             if (const char* e = std::getenv("AMGX_FUSED_BLOCK")) { const int v = std::atoi(e); L.fused_block = (v == 256 || v == 1024) ? v : 512; }
             if (G > 1) L.fused_block = 512;        // (several lanes per row: the chunk holds 512 / G rows)
+            // big square one-thread-per-row levels: compact chunks (cluster_slices) -- fewer partial sums per coarse row
+            int64_t cc_min = 200000;
+            if (const char* e = std::getenv("AMGX_COMPACT_CHUNKS_MIN_ROWS")) cc_min = std::atoll(e);
+            if (G == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows >= cc_min && !std::getenv("AMGX_NO_COMPACT_CHUNKS")) {
+              const std::vector<int32_t> sl = cluster_slices(s.P, L.fused_block / WAVE);
+              build_restrict(s.P, L.RF, L.fused_block, 6 * L.fused_block, L.fused_block, &sl);
+            } else
             build_restrict(s.P, L.RF, L.fused_block / G, 6 * L.fused_block, L.fused_block);
           }
         };

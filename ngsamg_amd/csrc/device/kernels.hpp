@@ -255,8 +255,11 @@ __device__ __forceinline__ void sell_pairs(int np, const double* __restrict__ vb
 // (xd is always a real local of the caller: a conditionally-null pointer kept the pair in scratch memory)
 // K = pair-steps per batch of the software pipeline (see SELL_BATCH)
 // (sp0, sp1 = slice_ptr[s], slice_ptr[s + 1]: callers with a long prologue load them first, see sell_pre_restrict_kernel)
+// x32 (optional): the vector slices in the 32-bit encoding gather from (local-window images: 16-bit slices index the LDS window,
+// 32-bit slices -- chunks whose window would not fit -- carry global columns)
 template <int K = SELL_BATCH>
-__device__ __forceinline__ double sell_row_dot_sp(const SellMat& M, int64_t sp0, int64_t sp1, int lane, int row, const double* x, double* xd) {
+__device__ __forceinline__ double sell_row_dot_sp(const SellMat& M, int64_t sp0, int64_t sp1, int lane, int row, const double* x, double* xd,
+                                                  const double* x32 = nullptr) {
   const int64_t base = sp0 & ~(int64_t)63;
   const int w = (int)(((sp1 & ~(int64_t)63) - base) >> 6);
   const int np = w >> 1;
@@ -273,10 +276,11 @@ __device__ __forceinline__ double sell_row_dot_sp(const SellMat& M, int64_t sp0,
     vs = ld_nt(vb + o);
     cs = c16 ? (int)ld_nt(M.col16 + base + o) : ld_nt(M.col32 + base + o);
   }
+  const double* __restrict__ xw32 = x32 ? x32 : x;
   if (c16) sell_pairs<true, K>(np, vb, M.col16 + base, cb, r0, lane, x, acc0, acc1, xd);
-  else sell_pairs<false, K>(np, vb, M.col32 + base, nullptr, 0, lane, x, acc0, acc1, xd);
+  else sell_pairs<false, K>(np, vb, M.col32 + base, nullptr, 0, lane, xw32, acc0, acc1, xd);
   if (w & 1) {
-    const double x0 = x[c16 ? r0 + cb[w - 1] + cs : cs];
+    const double x0 = c16 ? x[r0 + cb[w - 1] + cs] : xw32[cs];
     if (np == 0) { xd[0] = x0; xd[1] = vs; }
     acc0 += vs * x0;
   }
@@ -1110,14 +1114,18 @@ __global__ __launch_bounds__(FUSED_BLOCK) void sell_pre_restrict_kernel(int64_t 
                                                                         const int32_t* __restrict__ slot_ptr,
                                                                         const double* __restrict__ w, const uint16_t* __restrict__ fi,
                                                                         double* __restrict__ part,
-                                                                        const int32_t* __restrict__ dest) {
+                                                                        const int32_t* __restrict__ dest,
+                                                                        const int32_t* __restrict__ slice_list = nullptr) {
   constexpr int FUSED_MAX_ENTRIES = EPT * FUSED_BLOCK;
   constexpr int RPC = FUSED_BLOCK / G;         // rows per chunk
   __shared__ double rl[RPC];
   __shared__ double pr[FUSED_MAX_ENTRIES];
   const int lane = threadIdx.x & (WAVE - 1);
   const int c = chunk0 + sell_unit(M);         // chunk0: first chunk of the launch (interior / boundary chunks of a rank-partitioned level)
-  const int s = __builtin_amdgcn_readfirstlane(c * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6));
+  // compact chunks (G == 1, cluster_slices): the chunk's slices come from a list (-1: none) instead of being consecutive
+  const int sq = c * (FUSED_BLOCK / WAVE) + (threadIdx.x >> 6);
+  const int s_raw = slice_list ? slice_list[sq] : sq;
+  const int s = __builtin_amdgcn_readfirstlane(s_raw < 0 ? n_slices : s_raw);
   const int row = s * (WAVE / G) + lane / G;
   const int lrow = (threadIdx.x >> 6) * (WAVE / G) + lane / G;     // row inside the chunk
   const bool writer = (lane % G) == 0;
@@ -1346,7 +1354,7 @@ __global__ __launch_bounds__(WB) void sell_win_pre_restrict_kernel(int64_t n_row
 constexpr int LW_ROWS = 256;                 // rows per chunk
 constexpr int LW_CAP = 4608;                 // distinct columns per chunk the LDS window holds (36 KB); more: the level keeps the plain image
 template <int EPT = 4>
-__global__ __launch_bounds__(512, 6) void sell_lw_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
+__global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                    const int32_t* __restrict__ lw_cptr, const int32_t* __restrict__ lw_ccol,
                                                                    const double* __restrict__ b, const double* __restrict__ dinv,
                                                                    double omega, int nt, double* __restrict__ x,
@@ -1402,7 +1410,7 @@ __global__ __launch_bounds__(512, 6) void sell_lw_pre_restrict_kernel(int64_t n_
   double r = 0.0;
   if (has_slice) {
     double xd[2] = {0.0, 0.0};
-    double acc = sell_row_dot_sp(M, sp0, sp1, lane, 0, xw, xd);          // columns = indices into the window
+    double acc = sell_row_dot_sp(M, sp0, sp1, lane, 0, xw, xd, b);       // 16-bit slices: indices into the window; 32-bit: global columns
     acc += __shfl_xor(acc, 1, G);
     if (writer && row < n_rows) {
       r = bi - acc;

