@@ -188,7 +188,8 @@ int amgx_level_info(amgx_handle h, int level, int64_t* n, int32_t* bs, int64_t* 
 int amgx_cycle_info(amgx_handle h, int32_t* tail_level, int32_t* dense_level, int64_t* dense_n);
 /* device-format report per level matrix: which = 0 A, 1 P, 2 PT, 3 A' = A*omega*Dinv (pre-smoothing image),
  * 4 Q = (I - omega*Dinv*A) P (post-smoothing folded into the prolongation), 5 the "local window" image of A' that the fused down
- * kernel of a long-row level reads (chunk-local 16-bit columns, gathered vector staged in LDS); fmt: -1 not built, 0 CSR-vector,
+ * kernel of a long-row level reads (chunk-local 16-bit columns, gathered vector staged in LDS), 6 the local-window image of Q
+ * (window-local columns, the coarse values of a 512-row window staged in LDS); fmt: -1 not built, 0 CSR-vector,
  * 1 sliced-ELL, 2 block sliced-ELL, 3 sliced-ELL with length-sorted row windows, 5 local-window sliced-ELL, 4 rigid-body transfer blocks (P_ik = w_ik Q(t_ik)
  * stored as (column, w, t): detected block by block at amgx_create, elasticity_energy.hpp:447-490); stored_entries counts padding
  * (for the traffic model in DESIGN.md) */

@@ -171,6 +171,9 @@ struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_
   int B = 0, G = 1, TH = 1024;          // rows per block, lanes per row, workgroup size (B * G == TH)
   int n_blocks = 0, n_colors = 0;
   int lowin_maxw = 0;                   // widest slice of `lowin` (entries per lane): <= 5 selects the narrow sweep-from-zero kernel
+  // long-row levels: local-window image of `rest` (sell_lw_pre_restrict_kernel, MODE 1) for the fused residual + restriction
+  DevMatrix restLW;
+  DevBuf<int32_t> lw_cptr, lw_ccol;
   int full_maxw = 0;                    // widest slice of `full`: <= 11 selects the mid-width general sweep (fewer registers: two 1024-lane
                                         //   workgroups per CU instead of one, so that one block's colour phases hide behind another's loads)
   DevMatrix::Sell full, lowin;          // block-local SELL-G copies (slots colour-sorted inside a block): all entries /
@@ -259,6 +262,9 @@ struct DevLevel {
   // the distinct columns of every 256-row chunk (sell_lw_pre_restrict_kernel: the gathered vector is staged in LDS)
   DevMatrix ApreLW;
   DevBuf<int32_t> lw_cptr, lw_ccol;
+  // the same for the folded prolongation Q (sell_lw_win_spmv_kernel): windowed SELL with window-local 16-bit columns
+  DevMatrix QLW;
+  DevBuf<int32_t> qlw_cptr, qlw_ccol;
   DevMatrix Q;                          // scalar Jacobi levels of the V-cycle: (I - omega*Dinv*A) P, see fold_prolongation()
   DevBuf<double> dinv;
   DevGS gs;
@@ -1003,7 +1009,7 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
   int64_t mx_chunk = 0;
   for (int64_t v : fullest) mx_chunk = std::max(mx_chunk, v);
   R.ept = mx_chunk <= (int64_t)4 * threads ? 4 : 6;
-  if (CH == LW_ROWS && threads == 512 && max_entries == 4 * 512) R.ept = mx_chunk <= (int64_t)2 * threads ? 2 : 4;     // (local-window chunks: see lw_image)
+  if ((CH == 256 || CH == 128) && threads == 512 && max_entries == 4 * 512) R.ept = mx_chunk <= (int64_t)2 * threads ? 2 : 4;     // (local-window chunks: see lw_image)
   if (const char* e = std::getenv("AMGX_FUSED_EPT_MAX")) if (R.ept > std::atoi(e)) { R = DevRestrict(); return; }     // (A/B hook: keep the separate kernels instead)
   R.chunk_slot.upload(chunk_slot); R.slot_ptr.upload(slot_ptr); R.optr.upload(optr);
   // Measured NON-win (profiles/r01/restrict_fused.txt): storing the partial sums row by row (scattered stores in the
@@ -1022,8 +1028,9 @@ static void build_restrict(const amgx_matrix& P, DevRestrict& R, int CH = RESTRI
 // "local window" image of a long-row scalar matrix (sell_lw_pre_restrict_kernel): per chunk of LW_ROWS consecutive rows the sorted
 // list of its distinct columns; the SELL-2 image stores indices into that list.  vals: the (scaled) values in CSR order.
 // Returns false (nothing built) if a chunk touches more than LW_CAP distinct columns.
-static bool build_sell_lw(const amgx_matrix& A, const double* vals, DevMatrix& D, DevBuf<int32_t>& d_cptr, DevBuf<int32_t>& d_ccol) {
+static bool build_sell_lw(const amgx_matrix& A, const double* vals, int G, DevMatrix& D, DevBuf<int32_t>& d_cptr, DevBuf<int32_t>& d_ccol) {
   const int64_t n = A.n_rows, nnz = A.rowptr[n];
+  const int LW_ROWS = 512 / G;
   const int64_t nch = (n + LW_ROWS - 1) / LW_ROWS;
   std::vector<int32_t> cnt((size_t)nch + 1, 0);
   RawVec<int32_t> lcol;
@@ -1062,18 +1069,82 @@ static bool build_sell_lw(const amgx_matrix& A, const double* vals, DevMatrix& D
   L.col = lcol.data();
   L.val = vals;
   HostSell S;
-  build_sell(L, nullptr, n, false, 2, S, false, &no16);
+  build_sell(L, nullptr, n, false, G, S, false, &no16);
   const int64_t ns = (int64_t)S.slice_ptr.size() - 1;
   // (every slice of a chunk with a window fits 16-bit deltas by construction: indices < LW_CAP; anything else would be a builder bug)
   int64_t want16 = 0;
-  for (int64_t sl = 0; sl < ns; ++sl) if (!no16[std::min<int64_t>(n - 1, sl * (WAVE / 2))]) ++want16;
+  for (int64_t sl = 0; sl < ns; ++sl) if (!no16[std::min<int64_t>(n - 1, sl * (WAVE / G))]) ++want16;
   if (S.n_comp_slices != want16) return false;
   D.n_rows = n; D.n_cols = A.n_cols; D.br = D.bc = 1; D.nnz = nnz;
-  D.fmt = FMT_SELL; D.lanes = 2;
+  D.fmt = FMT_SELL; D.lanes = G;
   D.n_slices = (int)ns;
   D.stored = S.slice_ptr.back() & ~(int64_t)63;
   D.stream_bytes = S.stream_bytes + 4 * (int64_t)ccol.size() + 4 * (nch + 1);
   upload_sell(S, D.sell);
+  d_cptr.upload(cnt);
+  d_ccol.upload(ccol);
+  return true;
+}
+
+// local-window form of a WINDOWED SELL image (sell_lw_win_spmv_kernel): windows of SELL_WIN consecutive rows stored by decreasing
+// length as in upload_matrix, columns = indices into the window's sorted list of distinct columns (at most QW_CAP; windows beyond
+// that keep 32-bit global columns).  rowptr / col / val: host CSR.  Returns false if too many windows miss the capacity.
+static bool build_sell_lw_windowed(int64_t n, int64_t n_cols, const int64_t* rowptr, const int32_t* col, const double* val, DevMatrix& D,
+                                   DevBuf<int32_t>& d_cptr, DevBuf<int32_t>& d_ccol) {
+  const int win = SELL_WIN;
+  const int64_t nnz = rowptr[n];
+  const int64_t nw = (n + win - 1) / win;
+  std::vector<int32_t> cnt((size_t)nw + 1, 0);
+  RawVec<int32_t> lcol;
+  lcol.resize((size_t)std::max<int64_t>(1, nnz));
+  std::vector<std::vector<int32_t>> lists((size_t)nw);
+  std::vector<char> no16((size_t)n, 0);
+  std::vector<int32_t> rows((size_t)n);
+  std::vector<uint16_t> rowloc((size_t)n);
+  std::vector<int64_t> n_over(setup_threads(), 0);
+  int64_t cap = QW_CAP;
+  const char* tcap = std::getenv("AMGX_LW_TEST_CAP");
+  if (tcap) cap = std::min<int64_t>(cap, std::max<int64_t>(8, std::atoll(tcap) / 4));
+  par_for(nw, [&](int64_t q0, int64_t q1, int t) {
+    std::vector<int32_t> u;
+    for (int64_t q = q0; q < q1; ++q) {
+      const int64_t w0 = q * win, w1 = std::min<int64_t>(n, w0 + win);
+      for (int64_t i = w0; i < w1; ++i) rows[i] = (int32_t)i;
+      std::stable_sort(rows.begin() + w0, rows.begin() + w1, [&](int32_t a, int32_t b) { return rowptr[a + 1] - rowptr[a] > rowptr[b + 1] - rowptr[b]; });
+      for (int64_t i = w0; i < w1; ++i) rowloc[i] = (uint16_t)(rows[i] - w0);
+      u.assign(col + rowptr[w0], col + rowptr[w1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      if ((int64_t)u.size() > cap) {
+        for (int64_t i = w0; i < w1; ++i) no16[i] = 1;
+        for (int64_t k = rowptr[w0]; k < rowptr[w1]; ++k) lcol[k] = col[k];
+        n_over[t]++;
+        continue;
+      }
+      for (int64_t k = rowptr[w0]; k < rowptr[w1]; ++k) lcol[k] = (int32_t)(std::lower_bound(u.begin(), u.end(), col[k]) - u.begin());
+      cnt[q + 1] = (int32_t)u.size();
+      lists[q] = u;
+    }
+  }, 4);
+  int64_t overs = 0;
+  for (int64_t v : n_over) overs += v;
+  if (overs * 20 > nw && !tcap) return false;
+  for (int64_t q = 0; q < nw; ++q) cnt[q + 1] += cnt[q];
+  std::vector<int32_t> ccol((size_t)std::max<int32_t>(1, cnt[nw]));
+  par_for(nw, [&](int64_t q0, int64_t q1, int) { for (int64_t q = q0; q < q1; ++q) std::copy(lists[q].begin(), lists[q].end(), ccol.begin() + cnt[q]); }, 64);
+  amgx_matrix L{};
+  L.n_rows = n; L.n_cols = n_cols; L.br = L.bc = 1;
+  L.rowptr = rowptr; L.col = lcol.data(); L.val = val;
+  HostSell S;
+  build_sell(L, rows.data(), n, false, 1, S, false, &no16);
+  D.n_rows = n; D.n_cols = n_cols; D.br = D.bc = 1; D.nnz = nnz;
+  D.fmt = FMT_SELL; D.lanes = 1;
+  D.n_slices = (int)(S.slice_ptr.size() - 1);
+  D.stored = S.slice_ptr.back() & ~(int64_t)63;
+  D.stream_bytes = S.stream_bytes + 2 * n + 4 * (int64_t)ccol.size() + 4 * (nw + 1);
+  upload_sell(S, D.sell);
+  D.sell.win = win;
+  D.sell.rowloc.upload(rowloc);
   d_cptr.upload(cnt);
   d_ccol.upload(ccol);
   return true;
@@ -1690,19 +1761,21 @@ struct Handle {
     if (fold && !folded(L)) throw Err("pre_smooth_restrict: level has no folded prolongation");
     const int epf = ep_nt | (fold ? EPF_FOLD : 0);
     if (plain(L) && L.sm_type == AMGX_SM_JACOBI && !L.RF.empty() && !L.ApreLW.empty()) {
-      // long-row level: the local-window image (gathers from LDS), chunks of LW_ROWS rows
+      // long-row level: the local-window image (gathers from LDS), chunks of 512 / lanes rows
       const DevRestrict& R = L.RF;
       const int nch = (L.ApreLW.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
       if (nch != R.n_chunks) throw Err("fused restriction (local-window image): chunk / slice mismatch");
       int64_t ca, cb;
-      unit_range(sp, LW_ROWS, nch, ca, cb);
+      const int LG = L.ApreLW.lanes;
+      unit_range(sp, 512 / LG, nch, ca, cb);
       const int grid = (int)(cb - ca), c0 = (int)ca;
       const bool probe = probe_level == l && probe_kind == 8 && probe_e0 && sp.part != PART_BND;
       if (probe) HIPCHK(hipEventRecord(probe_e0, stream));
       if (grid > 0) {
-#define LAUNCH_LW(EPT_) hipLaunchKernelGGL((sell_lw_pre_restrict_kernel<EPT_>), dim3(grid), dim3(512), 0, stream, L.ApreLW.n_rows, c0, L.ApreLW.n_slices, \
+#define LAUNCH_LW(EPT_, G_) hipLaunchKernelGGL((sell_lw_pre_restrict_kernel<EPT_, G_, 0>), dim3(grid), dim3(512), 0, stream, L.ApreLW.n_rows, c0, L.ApreLW.n_slices, \
                            L.ApreLW.sell.view(), L.lw_cptr.p, L.lw_ccol.p, b, L.dinv.p, L.omega, epf, x, R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
-        if (R.ept == 2) LAUNCH_LW(2); else LAUNCH_LW(4);
+        if (LG == 2) { if (R.ept == 2) LAUNCH_LW(2, 2); else LAUNCH_LW(4, 2); }
+        else { if (R.ept == 2) LAUNCH_LW(2, 4); else LAUNCH_LW(4, 4); }
 #undef LAUNCH_LW
       }
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
@@ -1769,6 +1842,23 @@ struct Handle {
   void gsb_residual_restrict(int l, const double* x, double* r, double* b_coarse) {
     DevLevel& L = lev[l];
     if (!L.gsb.has_split) throw Err("gsb_residual_restrict: the level has no lower / rest split");
+    if (!L.gsb.restLW.empty() && !L.RG.empty()) {
+      // long-row level: local-window image of the rest part (the swept x is staged in LDS per chunk)
+      const DevRestrict& R = L.RG;
+      const DevMatrix& M = L.gsb.restLW;
+      const int nch = (M.n_slices + (512 / WAVE) - 1) / (512 / WAVE);
+      if (nch != R.n_chunks) throw Err("fused Gauss-Seidel residual (local-window image): chunk / slice mismatch");
+#define LAUNCH_LWC(EPT_, G_) hipLaunchKernelGGL((sell_lw_pre_restrict_kernel<EPT_, G_, 1>), dim3(nch), dim3(512), 0, stream, M.n_rows, 0, M.n_slices, M.sell.view(), \
+                             L.gsb.lw_cptr.p, L.gsb.lw_ccol.p, (const double*)x, (const double*)L.gsb.cvec.p, 0.0, 0, (double*)nullptr, \
+                             R.chunk_slot.p, R.slot_ptr.p, R.w.p, R.fi.p, R.part.p, R.dest.p)
+      if (M.lanes == 2) { if (R.ept == 2) LAUNCH_LWC(2, 2); else LAUNCH_LWC(4, 2); }
+      else { if (R.ept == 2) LAUNCH_LWC(2, 4); else LAUNCH_LWC(4, 4); }
+#undef LAUNCH_LWC
+      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+                         R.oidx.p, R.part.p, b_coarse);
+      HIPCHK(hipGetLastError());
+      return;
+    }
     if (L.RG.empty()) {
       spmv_ep<EP_CRES>(L.gsb.rest, x, r, EpArgs{x, nullptr, L.gsb.cvec.p, 0.0, nullptr, ep_nt & EPF_HOIST});
       transfer_f2c(l, r, b_coarse);
@@ -1797,7 +1887,13 @@ struct Handle {
   // fold: x holds z of the folded pre-smoothing pass; x' = z + Q x_c (see fold_prolongation)
   void post_smooth(int l, double* x, const double* b, double* r, const double* xc, bool fold = false, const Span sp = Span()) {
     DevLevel& L = lev[l];
-    if (fold) {
+    if (fold && !L.QLW.empty() && sp.part == PART_ALL) {
+      // local-window form of Q: the coarse values a window needs are staged in LDS (sell_lw_win_spmv_kernel)
+      const int64_t nw = (L.QLW.n_rows + SELL_WIN - 1) / SELL_WIN;
+      hipLaunchKernelGGL((sell_lw_win_spmv_kernel<SELL_WIN, EP_AXPY>), dim3((int)nw), dim3(SELL_WIN), 0, stream, L.QLW.n_rows, 0, L.QLW.sell.view(), L.QLW.sell.rowloc.p,
+                         L.qlw_cptr.p, L.qlw_ccol.p, xc, x, EpArgs{nullptr, x, nullptr, 1.0, nullptr, ep_nt & EPF_HOIST});
+      HIPCHK(hipGetLastError());
+    } else if (fold) {
       mult_add(L.Q, 1.0, xc, x, x, sp);
     } else if (sp.part == PART_INT) {
       return;                                  // literal forms are driven stage by stage (Dist), not through this function
@@ -2249,6 +2345,27 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
       upload_matrix(F, g.rest, "A (block-hybrid Gauss-Seidel: rest)", true, false, false, 1.6, SELL_WIN);
     }
     g.has_split = true;
+    {
+      // long-row levels: local-window image of the rest part (host builder from the downloaded part)
+      const double avgA = n ? (double)csr->nnz / (double)n : 0.0;
+      int64_t lw_min_rows = 100000;
+      if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
+      if (P && avgA >= 24.0 && n >= lw_min_rows && d.A.n_cols == n && P->br == 1 && P->bc == 1 && P->rowptr[P->n_rows] < (int64_t)2147483647 &&
+          !std::getenv("AMGX_NO_LW") && !std::getenv("AMGX_NO_FUSED_RESTRICT")) {
+        std::vector<int64_t> rp = db_download(part[1].rowptr, (size_t)n + 1);
+        std::vector<int32_t> cc = db_download(part[1].col, (size_t)std::max<int64_t>(1, part[1].nnz));
+        std::vector<double> vv = db_download(part[1].val, (size_t)std::max<int64_t>(1, part[1].nnz));
+        amgx_matrix F = d.A;
+        F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+        int G = 0;
+        for (int gg : {2, 4}) if (build_sell_lw(F, F.val, gg, g.restLW, g.lw_cptr, g.lw_ccol)) { G = gg; break; } else g.restLW = DevMatrix();
+        if (G) {
+          build_restrict(*P, L.RG, 512 / G, 4 * 512, 512);
+          if (!L.RG.empty()) return;
+          g.restLW = DevMatrix(); g.lw_cptr.release(); g.lw_ccol.release();
+        }
+      }
+    }
     if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
         P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
       build_restrict(*P, L.RG, 512, 6 * 512);
@@ -2327,6 +2444,21 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
     upload_matrix(F, g.rest, "A (block-hybrid Gauss-Seidel: rest)", true, false, false, 1.6, SELL_WIN);
     g.cvec.upload(cv);
     g.has_split = true;
+    {
+      const double avgA = n ? (double)d.A.rowptr[n] / (double)n : 0.0;
+      int64_t lw_min_rows = 100000;
+      if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
+      if (P && avgA >= 24.0 && n >= lw_min_rows && d.A.n_cols == n && P->br == 1 && P->bc == 1 && P->rowptr[P->n_rows] < (int64_t)2147483647 &&
+          !std::getenv("AMGX_NO_LW") && !std::getenv("AMGX_NO_FUSED_RESTRICT")) {
+        int G = 0;
+        for (int gg : {2, 4}) if (build_sell_lw(F, F.val, gg, g.restLW, g.lw_cptr, g.lw_ccol)) { G = gg; break; } else g.restLW = DevMatrix();
+        if (G) {
+          build_restrict(*P, L.RG, 512 / G, 4 * 512, 512);
+          if (!L.RG.empty()) return;
+          g.restLW = DevMatrix(); g.lw_cptr.release(); g.lw_ccol.release();
+        }
+      }
+    }
     if (P && g.rest.fmt == FMT_SELL && g.rest.lanes == 1 && P->br == 1 && P->bc == 1 &&
         P->rowptr[P->n_rows] < (int64_t)2147483647 && !std::getenv("AMGX_NO_FUSED_RESTRICT"))
       build_restrict(*P, L.RG, 512, 6 * 512);
@@ -3033,9 +3165,12 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
               s.P.br != 1 || s.P.bc != 1 || s.P.rowptr[s.P.n_rows] >= (int64_t)2147483647 || std::getenv("AMGX_NO_FUSED_RESTRICT")) return false;
           std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnzA)]);
           par_for(nnzA, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
-          if (!build_sell_lw(s.A, sv.get(), L.ApreLW, L.lw_cptr, L.lw_ccol)) { L.ApreLW = DevMatrix(); return false; }
+          // two lanes per row (256-row chunks); levels whose 256-row chunks touch too many columns: four lanes (128-row chunks)
+          int G = 0;
+          for (int g : {2, 4}) if (build_sell_lw(s.A, sv.get(), g, L.ApreLW, L.lw_cptr, L.lw_ccol)) { G = g; break; } else L.ApreLW = DevMatrix();
+          if (!G) return false;
           L.fused_block = 512;
-          build_restrict(s.P, L.RF, LW_ROWS, 4 * 512, 512);
+          build_restrict(s.P, L.RF, 512 / G, 4 * 512, 512);
           if (L.RF.empty()) { L.ApreLW = DevMatrix(); L.lw_cptr.release(); L.lw_ccol.release(); return false; }
           return true;
         };
@@ -3120,6 +3255,11 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
         // post-smoothing folded into the prolongation (V-cycle).  Square levels: Q is built here.  Rank-partitioned
         // levels: Q needs the P rows of the ghost vertices, so the caller supplies it (amgx_level_desc.Q) and drives
         // the level through amgx_cycle_down / amgx_cycle_up.
+        auto qlw_wanted = [](int64_t rows) {
+          int64_t mn = 100000;
+          if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) mn = std::atoll(e);
+          return rows >= mn && !std::getenv("AMGX_NO_LW") && !std::getenv("AMGX_NO_QLW");
+        };
         if (d->cycle == AMGX_CYCLE_V && s.P.br == 1 && s.P.bc == 1 && !std::getenv("AMGX_NO_FOLD")) {
           double qpad = 1.6;
           if (const char* e = std::getenv("AMGX_Q_MAX_PAD")) qpad = std::atof(e);
@@ -3136,6 +3276,12 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
                 DevCsrSrc csrP, csrQ;
                 csrP.upload(s.P);
                 if (dev_fold_prolongation(csrA, csrP, L.dinv.p, s.omega, csrQ) && dev_upload_matrix(csrQ, L.Q, false, qpad, SELL_WIN, nullptr)) {
+                  if (qlw_wanted(s.A.n_rows)) {
+                    std::vector<int64_t> rp = db_download(csrQ.rowptr, (size_t)s.A.n_rows + 1);
+                    std::vector<int32_t> cc = db_download(csrQ.col, (size_t)std::max<int64_t>(1, csrQ.nnz));
+                    std::vector<double> vv = db_download(csrQ.val, (size_t)std::max<int64_t>(1, csrQ.nnz));
+                    if (!build_sell_lw_windowed(s.A.n_rows, csrQ.n_cols, rp.data(), cc.data(), vv.data(), L.QLW, L.qlw_cptr, L.qlw_ccol)) L.QLW = DevMatrix();
+                  }
                   if (verify_images) {
                     HostCsr q;
                     fold_prolongation(s.A, s.P, s.dinv, s.omega, q);
@@ -3157,6 +3303,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
                 amgx_matrix Qm = s.P;
                 Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
                 upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+                if (qlw_wanted(s.A.n_rows) && L.Q.fmt == FMT_SELL && L.Q.sell.win &&
+                    !build_sell_lw_windowed(s.A.n_rows, s.P.n_cols, q.rowptr.data(), q.col.data(), q.val.data(), L.QLW, L.qlw_cptr, L.qlw_ccol)) L.QLW = DevMatrix();
               }
             }, "Q = (I - w Dinv A) P");
           }
@@ -3675,10 +3823,10 @@ int amgx_cycle_info(amgx_handle hh, int32_t* tail_level, int32_t* dense_level, i
 int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t* stored, int32_t* lanes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels()) throw amgx::Err("amgx_matrix_info: level out of range");
-    if (which < 0 || which > 5) throw amgx::Err("matrix query: which must be 0..5");
+    if (which < 0 || which > 6) throw amgx::Err("matrix query: which must be 0..6");
     const amgx::DevLevel& LV = h.lev[level];
-    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : LV.ApreLW;
-    if (fmt) *fmt = M.empty() ? -1 : (which == 5 ? 5 : ((M.fmt == amgx::FMT_SELL && M.sell.win) ? 3 : M.fmt));
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : which == 5 ? LV.ApreLW : LV.QLW;
+    if (fmt) *fmt = M.empty() ? -1 : (which >= 5 ? 5 : ((M.fmt == amgx::FMT_SELL && M.sell.win) ? 3 : M.fmt));
     if (stored) *stored = M.stored;
     if (lanes) *lanes = M.lanes;
   });
@@ -3687,9 +3835,9 @@ int amgx_matrix_info(amgx_handle hh, int level, int which, int32_t* fmt, int64_t
 int amgx_matrix_stream_bytes(amgx_handle hh, int level, int which, int64_t* bytes) {
   return guard(hh, [&](amgx::Handle& h) {
     if (level < 0 || level >= h.n_levels() || !bytes) throw amgx::Err("amgx_matrix_stream_bytes: bad arguments");
-    if (which < 0 || which > 5) throw amgx::Err("matrix query: which must be 0..5");
+    if (which < 0 || which > 6) throw amgx::Err("matrix query: which must be 0..6");
     const amgx::DevLevel& LV = h.lev[level];
-    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : LV.ApreLW;
+    const amgx::DevMatrix& M = which == 0 ? LV.A : which == 1 ? LV.P : which == 2 ? LV.PT : which == 3 ? LV.Apre : which == 4 ? LV.Q : which == 5 ? LV.ApreLW : LV.QLW;
     *bytes = M.stream_bytes;
   });
 }

@@ -1351,9 +1351,15 @@ __global__ __launch_bounds__(WB) void sell_win_pre_restrict_kernel(int64_t n_row
 // row); the image stores, per chunk, the sorted list of the DISTINCT columns its rows touch (~3 900 of 13 300 entries) and 16-bit
 // indices into that list.  The workgroup loads b at those columns once -- sorted, hence in runs, a quarter of the gathers -- into
 // LDS and the row products gather from LDS (ds_read_b64) instead of L2.  Everything else as in sell_pre_restrict_kernel.
-constexpr int LW_ROWS = 256;                 // rows per chunk
-constexpr int LW_CAP = 4608;                 // distinct columns per chunk the LDS window holds (36 KB); more: the level keeps the plain image
-template <int EPT = 4>
+// Counters (profiles/r04/pmc_l1_*.csv): the plain kernel spends 40 % of its wave cycles stalled on instruction ISSUE (SQ_WAIT_INST_ANY;
+// level 0: 24 %) -- the address path takes one cycle per distinct line of a gather -- while its fabric traffic equals the algorithmic
+// bytes (no over-fetch) and the vector L1 hits 84 %.  Measured at cfg 2: level-1 down kernel 209 -> 157 us.
+constexpr int LW_CAP = 4608;                 // distinct columns per chunk the LDS window holds (36 KB); chunks beyond it: 32-bit global columns
+// G = lanes per row (2: 256-row chunks; 4: 128-row chunks for levels with ~80+ entries per row, whose 256-row chunks would not fit).
+// MODE 0: Jacobi pre-smoothing from zero as described above (b = right-hand side, dinv, x receives omega*Dinv*b [+ fold]).
+// MODE 1: residual after a block-hybrid Gauss-Seidel sweep from zero, r = c .* x - A_rest x (b = the swept x, dinv = c; nothing is
+//         written to x) -- sell_win_cres_restrict_kernel's job on a local-window image of A_rest.
+template <int EPT = 4, int G = 2, int MODE = 0>
 __global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_kernel(int64_t n_rows, int chunk0, int n_slices, SellMat M,
                                                                    const int32_t* __restrict__ lw_cptr, const int32_t* __restrict__ lw_ccol,
                                                                    const double* __restrict__ b, const double* __restrict__ dinv,
@@ -1361,10 +1367,11 @@ __global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_
                                                                    const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ slot_ptr,
                                                                    const double* __restrict__ w, const uint16_t* __restrict__ fi,
                                                                    double* __restrict__ part, const int32_t* __restrict__ dest) {
-  constexpr int FB = 512, G = 2;
+  constexpr int FB = 512;
+  constexpr int ROWS = FB / G;
   constexpr int MAXE = EPT * FB;
   __shared__ double xw[LW_CAP];
-  __shared__ double rl[LW_ROWS];
+  __shared__ double rl[ROWS];
   __shared__ double pr[MAXE];
   const int lane = threadIdx.x & (WAVE - 1);
   const int c = chunk0 + sell_unit(M);
@@ -1400,7 +1407,7 @@ __global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_
     pb_raw = slot_ptr[myslot + 1];
   }
   double bi = 0.0, di = 0.0;
-  if (writer && has_slice && row < n_rows) { bi = b[row]; di = (nt & EPF_NT) ? ld_nt(dinv + row) : dinv[row]; }
+  if (writer && has_slice && row < n_rows) { bi = b[row]; di = (MODE == 0 && (nt & EPF_NT)) ? ld_nt(dinv + row) : dinv[row]; }
 #pragma unroll
   for (int q = 0; q < LW_CAP / FB; ++q) {
     const int k = threadIdx.x + q * FB;
@@ -1411,13 +1418,17 @@ __global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_
   if (has_slice) {
     double xd[2] = {0.0, 0.0};
     double acc = sell_row_dot_sp(M, sp0, sp1, lane, 0, xw, xd, b);       // 16-bit slices: indices into the window; 32-bit: global columns
-    acc += __shfl_xor(acc, 1, G);
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
     if (writer && row < n_rows) {
-      r = bi - acc;
-      double xi = omega * (di * bi);
-      if (nt & EPF_FOLD) xi += omega * (di * r);
-      if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);
-      else x[row] = xi;
+      if (MODE == 1) r = di * bi - acc;
+      else {
+        r = bi - acc;
+        double xi = omega * (di * bi);
+        if (nt & EPF_FOLD) xi += omega * (di * r);
+        if (nt & EPF_NT) __builtin_nontemporal_store(xi, x + row);
+        else x[row] = xi;
+      }
     }
   }
   if (writer) rl[lrow] = r;
@@ -1439,6 +1450,50 @@ __global__ __launch_bounds__(512, (EPT <= 2 ? 6 : 4)) void sell_lw_pre_restrict_
     double acc = 0.0;
     for (int k = a; k < bnd; ++k) acc += pr[k];
     part[dest ? dest[slot] : slot] = acc;
+  }
+}
+
+// x = z + Q x_c (windowed SELL, EP_AXPY and friends) with the gathered COARSE vector staged in LDS: the local-window form of
+// sell_win_spmv_kernel.  Counters of the plain kernel on Q (profiles/r04/pmc_*): 40 % (level 0) / 58 % (level 1) of the wave cycles
+// stalled on instruction issue -- 14 / 30 gathers per row whose 64 lanes hit 8 ... 30 different lines, one address-path cycle each.
+// The 512 fine rows of a window interpolate from only ~400 coarse columns: their values are loaded once (sorted list, ~3 KB) and
+// the row products gather from LDS.  Windows whose list would not fit keep 32-bit global columns.
+constexpr int QW_CAP = 2048;                 // distinct coarse columns per window the LDS stage holds (16 KB)
+template <int WB, int EP>
+__global__ __launch_bounds__(WB) void sell_lw_win_spmv_kernel(int64_t n_rows, int win0, SellMat M, const uint16_t* __restrict__ rowloc,
+                                                              const int32_t* __restrict__ lw_cptr, const int32_t* __restrict__ lw_ccol,
+                                                              const double* __restrict__ x, double* y, EpArgs ep) {
+  __shared__ double buf[WB];
+  __shared__ double xw[QW_CAP];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wb = win0 + sell_unit(M);
+  const int s = __builtin_amdgcn_readfirstlane(wb * (WB / WAVE) + (threadIdx.x >> 6));
+  const int64_t slot = (int64_t)s * WAVE + lane;
+  const int64_t row = (int64_t)wb * WB + threadIdx.x;
+  const int k0 = lw_cptr[wb], k1 = lw_cptr[wb + 1];
+  double xv[QW_CAP / WB];
+#pragma unroll
+  for (int q = 0; q < QW_CAP / WB; ++q) {
+    const int k = k0 + threadIdx.x + q * WB;
+    xv[q] = k < k1 ? x[lw_ccol[k]] : 0.0;
+  }
+  const bool hoist = (ep.nt & EPF_HOIST) && EP != EP_MULT;
+  EpOps ops{0.0, 0.0, 0.0};
+  if (hoist && row < n_rows) ops = ep_operands<EP>(row, ep, false);
+#pragma unroll
+  for (int q = 0; q < QW_CAP / WB; ++q) {
+    const int k = threadIdx.x + q * WB;
+    if (k0 + k < k1) xw[k] = xv[q];
+  }
+  __syncthreads();
+  if (slot < n_rows) {
+    double xd[2];
+    buf[rowloc[slot]] = sell_row_dot_sp(M, M.slice_ptr[s], M.slice_ptr[s + 1], lane, 0, xw, xd, x);
+  }
+  __syncthreads();
+  if (row < n_rows) {
+    if (!hoist) ops = ep_operands<EP>(row, ep, false);
+    store_scalar_ops<EP>(row, buf[threadIdx.x], y, ep, ops, false, 0.0);
   }
 }
 

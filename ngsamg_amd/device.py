@@ -418,10 +418,10 @@ class DeviceAMGMatrix:
 
     def matrix_info(self, level, which):
         fmt, stored, lanes = C.c_int32(), C.c_int64(), C.c_int32()
-        self._ck(self._lib.amgx_matrix_info(self._h, level, {"A": 0, "P": 1, "PT": 2, "Apre": 3, "Q": 4, "ApreLW": 5}[which], C.byref(fmt),
+        self._ck(self._lib.amgx_matrix_info(self._h, level, {"A": 0, "P": 1, "PT": 2, "Apre": 3, "Q": 4, "ApreLW": 5, "QLW": 6}[which], C.byref(fmt),
                                             C.byref(stored), C.byref(lanes)))
         nb = C.c_int64()
-        self._ck(self._lib.amgx_matrix_stream_bytes(self._h, level, {"A": 0, "P": 1, "PT": 2, "Apre": 3, "Q": 4, "ApreLW": 5}[which], C.byref(nb)))
+        self._ck(self._lib.amgx_matrix_stream_bytes(self._h, level, {"A": 0, "P": 1, "PT": 2, "Apre": 3, "Q": 4, "ApreLW": 5, "QLW": 6}[which], C.byref(nb)))
         return {"fmt": {-1: None, 0: "csrvec", 1: "sell", 2: "bsell", 3: "sellwin", 4: "rigid-body", 5: "sell-lw"}.get(fmt.value, "?"), "stored": stored.value, "lanes": lanes.value,
                 "stream_bytes": nb.value}
 

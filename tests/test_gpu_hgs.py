@@ -31,6 +31,32 @@ def test_hgs_cycles_match_hybrid_oracle(shape, cycle):
     assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("shape,cap", [((40, 38, 30), None), ((40, 38, 30), 1500)])
+def test_hgs_local_window_residual_on_long_row_levels(shape, cap, monkeypatch):
+    """the residual after the sweep from zero + chunk-local restriction through the local-window image of the rest part
+    (sell_lw_pre_restrict_kernel, MODE 1: the swept x staged in LDS), forced onto the small coarse levels of this case;
+    cap: some chunks without a window (32-bit global columns)"""
+    from ngsamg_amd.device import DeviceAMGMatrix
+    from oracle.pyoracle import Oracle
+    from tests.hgs_oracle import hgs_levels
+    monkeypatch.setenv("AMGX_LW_MIN_ROWS", "300")
+    monkeypatch.setenv("AMGX_NO_DENSE_TAIL", "1")
+    if cap:
+        monkeypatch.setenv("AMGX_LW_TEST_CAP", str(cap))
+    p, H = _case(shape)
+    dev = DeviceAMGMatrix(H, sm_type="hgs", device=0)
+    lv, types = hgs_levels(H.levels, dev.hgs)
+    rng = np.random.default_rng(2)
+    b = rng.standard_normal(p.n) * p.free
+    for rep in range(2):
+        x = dev.apply(b)
+    ref = Oracle(lv, sm_type=types).apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    monkeypatch.setenv("AMGX_NO_LW", "1")
+    xp = DeviceAMGMatrix(H, sm_type="hgs", device=0).apply(b)
+    assert np.linalg.norm(x - xp) <= 1e-12 * np.linalg.norm(xp) and not np.array_equal(x, xp)
+
+
 @pytest.mark.parametrize("threads", ["512", "1024"])
 @pytest.mark.parametrize("split", [True, False])
 def test_hgs_variants(threads, split, monkeypatch):

@@ -626,6 +626,7 @@ def test_local_window_image_of_long_row_levels(shape, cap, monkeypatch):
     dev = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
     used = [l for l in range(1, H.n_levels - 1) if dev.matrix_info(l, "ApreLW")["fmt"] == "sell-lw"]
     assert used, "no level took the local-window image"
+    assert dev.matrix_info(0, "QLW")["fmt"] == "sell-lw", "level 0 did not take the local-window image of Q"
     rng = np.random.default_rng(0)
     b = rng.standard_normal(p.n) * p.free
     for rep in range(2):
@@ -634,7 +635,7 @@ def test_local_window_image_of_long_row_levels(shape, cap, monkeypatch):
     assert np.linalg.norm(x - ref) <= 1e-12 * np.linalg.norm(ref)
     monkeypatch.setenv("AMGX_NO_LW", "1")
     plain = DeviceAMGMatrix(H, sm_type="jacobi", device=0)
-    assert all(plain.matrix_info(l, "ApreLW")["fmt"] is None for l in range(H.n_levels))
+    assert all(plain.matrix_info(l, "ApreLW")["fmt"] is None and plain.matrix_info(l, "QLW")["fmt"] is None for l in range(H.n_levels))
     xp = plain.apply(b)
     assert np.linalg.norm(x - xp) <= 1e-13 * np.linalg.norm(xp)
 
