@@ -1598,7 +1598,7 @@ struct Handle {
     if (R.empty()) { mult(lev[l].PT, xf, xc); return; }
     hipLaunchKernelGGL(restrict_chunk_kernel, dim3(R.n_chunks), dim3(BLOCK), 0, stream, lev[l].n, R.chunk_slot.p, R.slot_ptr.p,
                        R.w.p, R.fi.p, xf, R.part.p, R.dest.p);
-    hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+    hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for((lev[l + 1].n + RSUM_R - 1) / RSUM_R * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                        R.oidx.p, R.part.p, xc);
     HIPCHK(hipGetLastError());
   }
@@ -1780,7 +1780,7 @@ struct Handle {
       }
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
       if (!skip_rsum && sp.part != PART_INT)
-        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for((lev[l + 1].n + RSUM_R - 1) / RSUM_R * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                            R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
       return;
@@ -1823,7 +1823,7 @@ struct Handle {
       }
       if (probe) HIPCHK(hipEventRecord(probe_e1, stream));
       if (!skip_rsum && sp.part != PART_INT)
-        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+        hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for((lev[l + 1].n + RSUM_R - 1) / RSUM_R * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                            R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
       return;
@@ -1854,7 +1854,7 @@ struct Handle {
       if (M.lanes == 2) { if (R.ept == 2) LAUNCH_LWC(2, 2); else LAUNCH_LWC(4, 2); }
       else { if (R.ept == 2) LAUNCH_LWC(2, 4); else LAUNCH_LWC(4, 4); }
 #undef LAUNCH_LWC
-      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for((lev[l + 1].n + RSUM_R - 1) / RSUM_R * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
       return;
@@ -1877,7 +1877,7 @@ struct Handle {
       else { if (R.ept == 4) LAUNCH_PCR(4); else LAUNCH_PCR(6); }
 #undef LAUNCH_WCR
 #undef LAUNCH_PCR
-      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for(lev[l + 1].n * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
+      hipLaunchKernelGGL(restrict_sum_kernel, dim3(grid_for((lev[l + 1].n + RSUM_R - 1) / RSUM_R * RSUM_G)), dim3(BLOCK), 0, stream, lev[l + 1].n, R.optr.p,
                          R.oidx.p, R.part.p, b_coarse);
       HIPCHK(hipGetLastError());
     }
@@ -3303,7 +3303,7 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
                 amgx_matrix Qm = s.P;
                 Qm.rowptr = q.rowptr.data(); Qm.col = q.col.data(); Qm.val = q.val.data();
                 upload_matrix(Qm, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
-                if (qlw_wanted(s.A.n_rows) && L.Q.fmt == FMT_SELL && L.Q.sell.win &&
+                if (qlw_wanted(s.A.n_rows) &&
                     !build_sell_lw_windowed(s.A.n_rows, s.P.n_cols, q.rowptr.data(), q.col.data(), q.val.data(), L.QLW, L.qlw_cptr, L.qlw_ccol)) L.QLW = DevMatrix();
               }
             }, "Q = (I - w Dinv A) P");

@@ -1500,29 +1500,52 @@ __global__ __launch_bounds__(WB) void sell_lw_win_spmv_kernel(int64_t n_rows, in
 // adds the partial sums of every coarse row: RSUM_G lanes per row (the partials of a row sit in different chunks,
 // i.e. in unrelated cache lines: lanes in parallel instead of one thread walking them)
 constexpr int RSUM_G = 8;
+// RSUM_R consecutive coarse rows per lane group: the kernel is pure latency (counters: 86 % of the wave cycles parked on memory, three
+// dependent round trips per wave -- row pointers, slot indices, partial sums -- and 4 TB/s of fabric traffic), so every lane carries the
+// loads of RSUM_R rows through each round trip instead of one
+constexpr int RSUM_R = 4;
 __global__ __launch_bounds__(BLOCK) void restrict_sum_kernel(int64_t n_coarse, const int32_t* __restrict__ optr,
                                                              const int32_t* __restrict__ oidx,
                                                              const double* __restrict__ part, double* __restrict__ bc) {
   const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t J = t / RSUM_G;
+  const int64_t J0 = (t / RSUM_G) * RSUM_R;
   const int sub = (int)(t % RSUM_G);
-  double acc = 0.0;
-  if (J < n_coarse) {
-    const int e = optr[J + 1];
-    int k = optr[J] + sub;
-    if (oidx) {
-      // a row has ~10 partials over RSUM_G lanes: the first two per lane are requested together (index, then value), so
-      // the common case is two dependent round trips instead of four
-      const int i0 = k < e ? oidx[k] : -1, i1 = k + RSUM_G < e ? oidx[k + RSUM_G] : -1;
-      const double p0 = i0 >= 0 ? part[i0] : 0.0, p1 = i1 >= 0 ? part[i1] : 0.0;
-      acc = p0 + p1;
-      for (k += 2 * RSUM_G; k < e; k += RSUM_G) acc += part[oidx[k]];
-    } else { for (; k < e; k += RSUM_G) acc += part[k]; }      // partials stored row by row (dest)
+  int kb[RSUM_R], ke[RSUM_R];
+#pragma unroll
+  for (int r = 0; r < RSUM_R; ++r) {
+    const int64_t J = J0 + r;
+    kb[r] = J < n_coarse ? optr[J] + sub : 0;
+    ke[r] = J < n_coarse ? optr[J + 1] : 0;
+  }
+  double acc[RSUM_R];
+  if (oidx) {
+    // a row has ~10 partials over RSUM_G lanes: the first two per lane are requested together (index, then value), so
+    // the common case is two dependent round trips instead of four
+    int i0[RSUM_R], i1[RSUM_R];
+#pragma unroll
+    for (int r = 0; r < RSUM_R; ++r) {
+      i0[r] = kb[r] < ke[r] ? oidx[kb[r]] : -1;
+      i1[r] = kb[r] + RSUM_G < ke[r] ? oidx[kb[r] + RSUM_G] : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RSUM_R; ++r) {
+      const double p0 = i0[r] >= 0 ? part[i0[r]] : 0.0, p1 = i1[r] >= 0 ? part[i1[r]] : 0.0;
+      acc[r] = p0 + p1;
+    }
+#pragma unroll
+    for (int r = 0; r < RSUM_R; ++r)
+      for (int k = kb[r] + 2 * RSUM_G; k < ke[r]; k += RSUM_G) acc[r] += part[oidx[k]];
+  } else {
+#pragma unroll
+    for (int r = 0; r < RSUM_R; ++r) { acc[r] = 0.0; for (int k = kb[r]; k < ke[r]; k += RSUM_G) acc[r] += part[k]; }      // partials stored row by row (dest)
   }
   // fixed combination order: deterministic
 #pragma unroll
-  for (int o = RSUM_G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, RSUM_G);
-  if (J < n_coarse && sub == 0) bc[J] = acc;
+  for (int r = 0; r < RSUM_R; ++r) {
+#pragma unroll
+    for (int o = RSUM_G >> 1; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, RSUM_G);
+    if (J0 + r < n_coarse && sub == 0) bc[J0 + r] = acc[r];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
