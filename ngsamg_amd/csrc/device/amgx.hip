@@ -174,6 +174,10 @@ struct DevGSB {                         // block-hybrid Gauss-Seidel (gsb_sweep_
   // long-row levels: local-window image of `rest` (sell_lw_pre_restrict_kernel, MODE 1) for the fused residual + restriction
   DevMatrix restLW;
   DevBuf<int32_t> lw_cptr, lw_ccol;
+  // ... and of `full` for the general sweep (gsb_sweep_kernel<..., LW>): codes instead of columns, see GsbArgs
+  DevMatrix::Sell fullLW;
+  DevBuf<int32_t> flw_cptr, flw_ccol;
+  bool has_fullLW = false;
   int full_maxw = 0;                    // widest slice of `full`: <= 11 selects the mid-width general sweep (fewer registers: two 1024-lane
                                         //   workgroups per CU instead of one, so that one block's colour phases hide behind another's loads)
   DevMatrix::Sell full, lowin;          // block-local SELL-G copies (slots colour-sorted inside a block): all entries /
@@ -1486,19 +1490,23 @@ struct Handle {
     if (blk1 < 0 || blk1 > g.n_blocks) blk1 = g.n_blocks;
     if (blk1 <= blk0) return;
     if (xin == xout) throw Err("block-hybrid Gauss-Seidel sweeps are out of place");
-    GsbArgs a{g.rowid.p, g.slotcolor.p, L.dinv.p, b, g.n_colors, dir};
-    const SellMat M = copy.view();
     const bool fz = xin == nullptr;
+    const bool lw = !fz && &copy == &g.full && g.has_fullLW && g.G > 1;
+    GsbArgs a{g.rowid.p, g.slotcolor.p, L.dinv.p, b, g.n_colors, dir, lw ? g.flw_cptr.p : nullptr, lw ? g.flw_ccol.p : nullptr};
+    const SellMat M = lw ? g.fullLW.view() : copy.view();
     const bool narrow = fz && &copy == &g.lowin && g.lowin_maxw > 0 && g.lowin_maxw <= 5 && !std::getenv("AMGX_GSB_NO_NARROW");
 #define LAUNCH_GSB3(TT, GG, ZZ, WW) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, ZZ, WW>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
     const bool mid = !fz && &copy == &g.full && g.G > 1 && g.full_maxw > 0 && g.full_maxw <= 11 && !std::getenv("AMGX_GSB_NO_MID");
+#define LAUNCH_GSBL(TT, GG, WW) hipLaunchKernelGGL((gsb_sweep_kernel<TT, GG, false, WW, true>), dim3(blk1 - blk0), dim3(TT), 0, stream, L.n, blk0, M, a, xin, xout)
 #define LAUNCH_GSB2(TT, GG) { if (narrow) LAUNCH_GSB3(TT, GG, true, 2); else if (fz) LAUNCH_GSB3(TT, GG, true, GSB_WP); \
+                              else if (lw && mid && GG > 1) LAUNCH_GSBL(TT, (GG > 1 ? GG : 2), 5); else if (lw && GG > 1) LAUNCH_GSBL(TT, (GG > 1 ? GG : 2), GSB_WP); \
                               else if (mid && GG > 1) LAUNCH_GSB3(TT, (GG > 1 ? GG : 2), false, 5); else LAUNCH_GSB3(TT, GG, false, GSB_WP); }
 #define LAUNCH_GSB(TT) switch (g.G) { case 1: LAUNCH_GSB2(TT, 1); break; case 2: LAUNCH_GSB2(TT, 2); break; case 4: LAUNCH_GSB2(TT, 4); break; \
                                       case 8: LAUNCH_GSB2(TT, 8); break; default: LAUNCH_GSB2(TT, 16); break; }
     if (g.TH == 256) LAUNCH_GSB(256) else if (g.TH == 512) LAUNCH_GSB(512) else LAUNCH_GSB(1024)
 #undef LAUNCH_GSB
 #undef LAUNCH_GSB2
+#undef LAUNCH_GSBL
 #undef LAUNCH_GSB3
     HIPCHK(hipGetLastError());
   }
@@ -2224,6 +2232,61 @@ namespace amgx {
 // Block-hybrid Gauss-Seidel data (gsb_sweep_kernel).  Validated like the colourings above: two coupled rows of one block
 // sharing a colour would be a data race.
 // csr: the level matrix on the device (big levels): the three images and the split are then formed there (devbuild.hpp)
+// local-window image of the colour-sorted block image `full` (gsb_sweep_kernel<..., LW>): per block of B rows the sorted list of its
+// distinct off-block columns; entries carry codes (in-block: row - r0 < B; off-block: B + position in the list).  Blocks whose list
+// exceeds GSB_LW_CAP keep global 32-bit columns.  rows: the slot -> row list of the block image (-1 = padding), slots = n_blocks * B.
+static bool build_gsb_full_lw(const amgx_matrix& A, const std::vector<int32_t>& rows, int64_t slots, int B, int G, DevGSB& g) {
+  const int64_t n = A.n_rows, nnz = A.rowptr[n];
+  const int64_t nb = (n + B - 1) / B;
+  std::vector<int32_t> cnt((size_t)nb + 1, 0);
+  RawVec<int32_t> code;
+  code.resize((size_t)std::max<int64_t>(1, nnz));
+  std::vector<std::vector<int32_t>> lists((size_t)nb);
+  std::vector<char> no16((size_t)n, 0);
+  std::vector<int64_t> n_over(setup_threads(), 0);
+  int64_t cap = GSB_LW_CAP;
+  const char* tcap = std::getenv("AMGX_LW_TEST_CAP");
+  if (tcap) cap = std::min<int64_t>(cap, std::max<int64_t>(8, std::atoll(tcap) / 4));
+  par_for(nb, [&](int64_t b0, int64_t b1, int t) {
+    std::vector<int32_t> u;
+    for (int64_t kb = b0; kb < b1; ++kb) {
+      const int64_t r0 = kb * B, r1 = std::min<int64_t>(n, r0 + B);
+      u.clear();
+      for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) if (A.col[k] < r0 || A.col[k] >= r1) u.push_back(A.col[k]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      if ((int64_t)u.size() > cap) {
+        for (int64_t i = r0; i < r1; ++i) no16[i] = 1;
+        for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) code[k] = A.col[k];
+        n_over[t]++;
+        continue;
+      }
+      for (int64_t k = A.rowptr[r0]; k < A.rowptr[r1]; ++k) {
+        const int32_t j = A.col[k];
+        code[k] = (j >= r0 && j < r1) ? (int32_t)(j - r0) : (int32_t)(B + (std::lower_bound(u.begin(), u.end(), j) - u.begin()));
+      }
+      cnt[kb + 1] = (int32_t)u.size();
+      lists[kb] = u;
+    }
+  }, 16);
+  int64_t overs = 0;
+  for (int64_t v : n_over) overs += v;
+  if (overs * 20 > nb && !tcap) return false;
+  for (int64_t kb = 0; kb < nb; ++kb) cnt[kb + 1] += cnt[kb];
+  std::vector<int32_t> ccol((size_t)std::max<int32_t>(1, cnt[nb]));
+  par_for(nb, [&](int64_t b0, int64_t b1, int) { for (int64_t kb = b0; kb < b1; ++kb) std::copy(lists[kb].begin(), lists[kb].end(), ccol.begin() + cnt[kb]); }, 64);
+  amgx_matrix Lm = A;
+  Lm.col = code.data();
+  HostSell S;
+  build_sell(Lm, rows.data(), slots, false, G, S, false, &no16);
+  // every slice must fit the kernel's register budget exactly like `full` (same widths: same rows, same lengths)
+  upload_sell(S, g.fullLW);
+  g.flw_cptr.upload(cnt);
+  g.flw_ccol.upload(ccol);
+  g.has_fullLW = true;
+  return true;
+}
+
 static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* P, const DevCsrSrc* csr = nullptr) {
   const int64_t n = d.A.n_rows;
   DevGSB& g = L.gsb;
@@ -2288,6 +2351,17 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
   };
   g.rowid.upload(rows);
   g.slotcolor.upload(sc);
+  {
+    // long-row square levels: local-window image of `full` for the general sweep
+    const double avgA = n ? (double)d.A.rowptr[n] / (double)n : 0.0;
+    int64_t lw_min_rows = 100000;
+    if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
+    // Measured NON-win at cfg 2 (profiles/r04/gs_experiments.txt): level-1 backward sweep 231 us with the window against 196 us without
+    // (the extra barrier and the window's registers cost more than the gathers of the off-block values, which this kernel issues
+    // back to back in one burst).  Built and tested, off unless AMGX_GSB_LW=1.
+    if (avgA >= 24.0 && n >= lw_min_rows && d.A.n_cols == n && G > 1 && !std::getenv("AMGX_NO_LW") && std::getenv("AMGX_GSB_LW"))
+      build_gsb_full_lw(d.A, rows, slots, B, G, g);
+  }
   if (csr) {
     // device builders: the colour-sorted image of A, the split by kernels, the images of its two parts
     auto max_width = [&](const DevMatrix::Sell& S, const char* what) {
@@ -3161,7 +3235,8 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           const double avgA = s.A.n_rows ? (double)nnzA / (double)s.A.n_rows : 0.0;
           int64_t lw_min_rows = 100000;
           if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
-          if (l == 0 || s.A.n_rows != s.A.n_cols || avgA < 24.0 || s.A.n_rows < lw_min_rows || std::getenv("AMGX_NO_LW") ||
+          // (rank-partitioned levels too: the window of an interior chunk holds owned columns only, ghost columns are just columns)
+          if (l == 0 || avgA < 24.0 || s.A.n_rows < lw_min_rows || std::getenv("AMGX_NO_LW") ||
               s.P.br != 1 || s.P.bc != 1 || s.P.rowptr[s.P.n_rows] >= (int64_t)2147483647 || std::getenv("AMGX_NO_FUSED_RESTRICT")) return false;
           std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnzA)]);
           par_for(nnzA, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);

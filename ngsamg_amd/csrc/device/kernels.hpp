@@ -661,11 +661,17 @@ struct GsbArgs {
   const double* b;
   int n_colors;
   int backward;
+  // local-window form (LW): per block the sorted list of the distinct OFF-block columns its rows touch; slices in the 16-bit encoding
+  // then carry codes -- code < B: in-block row, code >= B: entry code - B of the list -- and the sweep-start values of the list are
+  // staged in LDS; slices in the 32-bit encoding (blocks whose list would not fit) carry global columns as in the plain form
+  const int32_t* lw_cptr;
+  const int32_t* lw_ccol;
 };
+constexpr int GSB_LW_CAP = 3072;             // off-block columns per block the LDS stage holds (24 KB)
 
 // WP = pair-steps a lane holds (2 * WP + 1 entries): GSB_WP in general; the sweep from zero reads the short `lowin` rows and
 // is instantiated with WP = 2 where they fit (fewer registers: more resident workgroups to hide each other's colour phases)
-template <int TH, int G, bool FROM_ZERO, int WP = GSB_WP>
+template <int TH, int G, bool FROM_ZERO, int WP = GSB_WP, bool LW = false>
 // (second launch-bounds argument = waves per SIMD the register budget must allow: the mid-width general sweep asks for two 1024-lane
 //  or three 512-lane workgroups per CU)
 __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (WP <= 5 && !FROM_ZERO ? (TH == 1024 ? 8 : 6) : 1))) void gsb_sweep_kernel(int64_t n_rows, int block0, SellMat M, GsbArgs a,
@@ -673,10 +679,21 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (WP <= 5 && !FROM_ZERO 
   constexpr int B = TH / G;                  // rows per block
   constexpr int RPS = WAVE / G;              // rows per slice
   __shared__ double xs[B], bs[B], ds[B];     // x of the block; b and the (modified) inverse diagonal in natural row order
+  __shared__ double xw[LW ? GSB_LW_CAP : 1]; // local-window form: sweep-start values of the block's off-block columns
   const int blk = block0 + blockIdx.x;
   const int64_t r0 = (int64_t)blk * B;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int s = __builtin_amdgcn_readfirstlane(blk * (TH / WAVE) + (tid >> 6));
+  double xwv[LW ? (GSB_LW_CAP + TH - 1) / TH : 1];
+  int wk0 = 0, wk1 = 0;
+  if (LW) {
+    wk0 = a.lw_cptr[blk]; wk1 = a.lw_cptr[blk + 1];
+#pragma unroll
+    for (int q = 0; q < (GSB_LW_CAP + TH - 1) / TH; ++q) {
+      const int k = wk0 + tid + q * TH;
+      xwv[q] = k < wk1 ? xin[a.lw_ccol[k]] : 0.0;
+    }
+  }
   // ---- phase 1: every load that depends on nothing goes out before anything is consumed (a wait inside this phase
   // would serialise ~30 round trips per wave: measured 456 us -> see profiles/r02/gs_block_ab.txt)
   double x_own = 0.0, b_nat = 0.0, d_nat = 0.0;
@@ -743,6 +760,27 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (WP <= 5 && !FROM_ZERO 
   cl[2 * WP] = (w & 1) ? (c16 ? cbt + (int)rt : (int)rt) : (int)r0;
   // ---- phase 3: off-block part (frozen values): all gathers requested, then summed; in-block part keeps (value, LDS slot)
   double xg[2 * WP + 1];
+  if (LW) {
+    // the window goes to LDS first (its loads were requested at the very top); EVERY thread of the block stages its share, whatever
+    // the encoding of its own slice (an empty slice is never flagged 16-bit)
+#pragma unroll
+    for (int q = 0; q < (GSB_LW_CAP + TH - 1) / TH; ++q) {
+      const int k = tid + q * TH;
+      if (wk0 + k < wk1) xw[k] = xwv[q];
+    }
+    __syncthreads();
+  }
+  if (LW && c16) {
+    // local-window slice: codes
+#pragma unroll
+    for (int j = 0; j < 2 * WP + 1; ++j) {
+      // (slots beyond the slice's width carry the r0 dummy of the decode above with value 0: in-block slot 0)
+      const int code = (j < 2 * np || (j == 2 * WP && (w & 1))) ? cl[j] : 0;
+      const bool inb = code < B;
+      xg[j] = inb ? 0.0 : xw[code - B];
+      cl[j] = inb ? code : -1;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < 2 * WP + 1; ++j) {
     const int loc = cl[j] - (int)r0;
@@ -750,6 +788,7 @@ __global__ __launch_bounds__(TH, (TH == 256 ? GSB_MINW : (WP <= 5 && !FROM_ZERO 
     xg[j] = 0.0;
     if (!FROM_ZERO) { if (!inb) xg[j] = xin[cl[j]]; }
     cl[j] = inb ? loc : -1;
+  }
   }
   double acc_off = 0.0;
 #pragma unroll

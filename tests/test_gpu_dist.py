@@ -736,3 +736,30 @@ def test_distributed_single_reduction_pcg_equals_serial_oracle(R, box, dmin, sm)
     assert np.allclose(errs[:k], erro[:k], rtol=1e-6)
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - xo) <= 1e-7 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("R,box,dmin", [(2, (20, 18, 16), 150), (4, (14, 14, 12), 40)])
+def test_loopback_device_local_window_image_on_rank_partitioned_levels(R, box, dmin, monkeypatch):
+    """the local-window image of A' (gathered vector staged in LDS, sell_lw_pre_restrict_kernel) on rank-partitioned coarse levels:
+    interior chunks run beside the exchange (their windows hold owned columns only), boundary chunks after it (ghost columns are
+    ordinary columns of the [owned | ghost] vector) -- forced onto the small level 1 of this case"""
+    import torch
+    from ngsamg_amd import dist as D
+    from oracle.pyoracle import Oracle
+    monkeypatch.setenv("AMGX_LW_MIN_ROWS", "50")
+    comm = D.LoopbackComm(R)
+    pg = D.proc_grid(R, 3)
+    states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
+    amg = D.DistributedAMG(comm, states, dim=3, dist_min_rows=dmin, device=0, max_coarse_size=10)
+    assert amg.k >= 2, "the case needs a rank-partitioned level 1"
+    assert any(op.top.matrix_info(1, "ApreLW")["fmt"] == "sell-lw" for op in amg.ops), "no rank took the local-window image on level 1"
+    rng = np.random.default_rng(0)
+    bh = [rng.standard_normal(s.n) * s.free for s in states]
+    bs = [torch.from_numpy(b).cuda() for b in bh]
+    xs = [torch.full((s.n,), float("nan"), dtype=torch.float64, device="cuda") for s in states]
+    for rep in range(3):
+        amg.Mult(bs, xs)
+    torch.cuda.synchronize()
+    ref = Oracle(amg.global_levels(), sm_type="jacobi").apply(np.concatenate(bh))
+    got = np.concatenate([x.cpu().numpy() for x in xs])
+    assert np.linalg.norm(got - ref) <= 1e-12 * np.linalg.norm(ref)

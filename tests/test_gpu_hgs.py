@@ -41,6 +41,7 @@ def test_hgs_local_window_residual_on_long_row_levels(shape, cap, monkeypatch):
     from tests.hgs_oracle import hgs_levels
     monkeypatch.setenv("AMGX_LW_MIN_ROWS", "300")
     monkeypatch.setenv("AMGX_NO_DENSE_TAIL", "1")
+    monkeypatch.setenv("AMGX_GSB_LW", "1")              # (the local-window form of the general sweep too: opt-in, a measured non-win)
     if cap:
         monkeypatch.setenv("AMGX_LW_TEST_CAP", str(cap))
     p, H = _case(shape)
