@@ -582,7 +582,11 @@ def main():
         sb = 0
         for l in range(H.n_levels - 1):
             Vl, Vc = 8 * H.levels[l].n * H.levels[l].bs, 8 * H.levels[l + 1].n * H.levels[l + 1].bs
-            sb += sum(amg.matrix_info(l, w)["stream_bytes"] for w in ("Apre", "PT", "Q")) + 5 * Vl + 2 * Vc
+            # (the images the cycle actually reads: the local-window forms of A' and Q where a level has them)
+            def _sb(plain, lw):
+                i = amg.matrix_info(l, lw)
+                return i["stream_bytes"] if i["fmt"] is not None else amg.matrix_info(l, plain)["stream_bytes"]
+            sb += _sb("Apre", "ApreLW") + amg.matrix_info(l, "PT")["stream_bytes"] + _sb("Q", "QLW") + 5 * Vl + 2 * Vc
     elif args.config != "cfg2":
         # block levels: folded where Q exists (A once + PT + Q), literal otherwise (A twice + P + PT), device encodings
         sb = 0
