@@ -40,6 +40,12 @@ def main():
             continue
         f, nf = fg[rank]
         w, nw = wg[rank] if len(wg) > rank else (0.0, 0)
+        if "bgsb_sweep" in needle:
+            # block-coloured sweep: one launch per block colour, each with its own grid; a sweep = the sum of the level-0 colour launches
+            # (the groups whose mean is at least half of the largest one)
+            f = sum(m for m, _ in fg if m >= 0.5 * fg[0][0])
+            w = sum(m for m, _ in wg if wg and m >= 0.5 * wg[0][0])
+            label = label.replace("ONE block colour of the", "all block colours of the").replace("; a sweep = the launches of all colours", "")
         js = {"kernel": label, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "launches_averaged": [nf, nw],
               "correction": "gfx950: FETCH_SIZE counts 1/2 of the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section; "
                             "calibrated in round 1: profiles/r01/pmc_lab_calibration.csv); WRITE_SIZE exact",
