@@ -1895,11 +1895,15 @@ struct Handle {
   // fold: x holds z of the folded pre-smoothing pass; x' = z + Q x_c (see fold_prolongation)
   void post_smooth(int l, double* x, const double* b, double* r, const double* xc, bool fold = false, const Span sp = Span()) {
     DevLevel& L = lev[l];
-    if (fold && !L.QLW.empty() && sp.part == PART_ALL) {
-      // local-window form of Q: the coarse values a window needs are staged in LDS (sell_lw_win_spmv_kernel)
+    if (fold && !L.QLW.empty()) {
+      // local-window form of Q: the coarse values a window needs are staged in LDS (sell_lw_win_spmv_kernel); interior / boundary
+      // window ranges on rank-partitioned levels (the list of an interior window holds owned coarse columns only)
       const int64_t nw = (L.QLW.n_rows + SELL_WIN - 1) / SELL_WIN;
-      hipLaunchKernelGGL((sell_lw_win_spmv_kernel<SELL_WIN, EP_AXPY>), dim3((int)nw), dim3(SELL_WIN), 0, stream, L.QLW.n_rows, 0, L.QLW.sell.view(), L.QLW.sell.rowloc.p,
-                         L.qlw_cptr.p, L.qlw_ccol.p, xc, x, EpArgs{nullptr, x, nullptr, 1.0, nullptr, ep_nt & EPF_HOIST});
+      int64_t wa, wb;
+      unit_range(sp, SELL_WIN, nw, wa, wb);
+      if (wb > wa)
+        hipLaunchKernelGGL((sell_lw_win_spmv_kernel<SELL_WIN, EP_AXPY>), dim3((int)(wb - wa)), dim3(SELL_WIN), 0, stream, L.QLW.n_rows, (int)wa, L.QLW.sell.view(),
+                           L.QLW.sell.rowloc.p, L.qlw_cptr.p, L.qlw_ccol.p, xc, x, EpArgs{nullptr, x, nullptr, 1.0, nullptr, ep_nt & EPF_HOIST});
       HIPCHK(hipGetLastError());
     } else if (fold) {
       mult_add(L.Q, 1.0, xc, x, x, sp);
@@ -3270,7 +3274,9 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             // big square one-thread-per-row levels: compact chunks (cluster_slices) -- fewer partial sums per coarse row
             int64_t cc_min = 200000;
             if (const char* e = std::getenv("AMGX_COMPACT_CHUNKS_MIN_ROWS")) cc_min = std::atoll(e);
-            if (G == 1 && s.A.n_rows == s.A.n_cols && s.A.n_rows >= cc_min && !std::getenv("AMGX_NO_COMPACT_CHUNKS")) {
+            // (not on a handle that a rank-partitioned driver runs stage by stage -- dense_first < 0 --: its launches cover interior and
+            //  boundary chunk RANGES, which only consecutive chunks have; a rank without ghost columns, e.g. world size 1, has a square level)
+            if (G == 1 && dense_first >= 0 && s.A.n_rows == s.A.n_cols && s.A.n_rows >= cc_min && !std::getenv("AMGX_NO_COMPACT_CHUNKS")) {
               const std::vector<int32_t> sl = cluster_slices(s.P, L.fused_block / WAVE);
               build_restrict(s.P, L.RF, L.fused_block, 6 * L.fused_block, L.fused_block, &sl);
             } else
@@ -3342,7 +3348,12 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
             if (s.Q.n_rows != s.A.n_rows || s.Q.br != 1 || s.Q.bc != 1 || s.Q.n_cols < c.A.n_rows || s.Q.n_cols > c.A.n_cols)
               throw Err("Q does not match the level matrices");
             if (s.Q.rowptr[s.Q.n_rows] >= (int64_t)2147483647) throw Err("Q: too many entries");
-            tasks.run([&, qpad] { upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN); });
+            tasks.run([&, qpad] {
+              upload_matrix(s.Q, L.Q, "Q (folded post-smoothing prolongation)", true, false, false, qpad, SELL_WIN);
+              // (rank-partitioned level: the caller's Q, columns [owned | ghost] of the coarse level)
+              if (qlw_wanted(s.A.n_rows) &&
+                  !build_sell_lw_windowed(s.Q.n_rows, s.Q.n_cols, s.Q.rowptr, s.Q.col, s.Q.val, L.QLW, L.qlw_cptr, L.qlw_ccol)) L.QLW = DevMatrix();
+            });
           } else if (s.A.n_rows == s.A.n_cols && s.P.n_cols == c.A.n_rows) {
             tasks.run([&, qpad] {
               // (device: the sparse product and the windowed image of its result, devbuild.hpp)

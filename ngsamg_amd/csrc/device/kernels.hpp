@@ -461,6 +461,33 @@ struct BSellMat {
 #ifndef BSELL_UNROLL
 #define BSELL_UNROLL 2
 #endif
+// one block step of a BSELL row product: acc += (row r of the BS x BS block at vk) . x_block.
+// V2 (even block sizes, x 16-byte aligned: c * BS * 8 is then a multiple of 16): the x block is read with 16-byte loads.  Counters at
+// cfg 3 (profiles/r04/pmc_cfg3_gs_sq.csv): the 6x6 kernels spend 46 ... 78 % of their wave cycles stalled on instruction ISSUE -- per
+// block step six 8-byte gathers (ten distinct lines each: one per block row of the wave) next to three streaming loads; 16-byte loads
+// halve the gather instructions.
+template <int BS, bool V2>
+__device__ __forceinline__ void bsell_block_step(const double* __restrict__ vk, const double* __restrict__ xv, int lane, double& acc) {
+  if (V2 && (BS % 2) == 0) {
+    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(xv);
+    double2 xx[BS / 2];
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) xx[cp] = x2[cp];
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) {
+      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+      acc += v0 * xx[cp].x + v1 * xx[cp].y;
+    }
+  } else {
+#pragma unroll
+    for (int cp = 0; cp < BS / 2; ++cp) {
+      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+      acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
+    }
+    if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+  }
+}
+
 template <int BS, int EP>
 __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int slice0, int n_slices, BSellMat M,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
@@ -492,17 +519,19 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int s
     }
   }
   double acc = 0.0;
+  const bool x16 = (BS % 2) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;      // (wave-uniform)
+  if (x16) {
+#pragma unroll BSELL_UNROLL
+    for (int k = 0; k < w; ++k) {
+      const int c = cb[k * RB + rbl];
+      bsell_block_step<BS, true>(vb + (int64_t)k * (BS * WAVE), x + (int64_t)c * BS, lane, acc);
+    }
+  } else {
 #pragma unroll BSELL_UNROLL
   for (int k = 0; k < w; ++k) {
     const int c = cb[k * RB + rbl];        // cached load: the RB*4-byte column chunks of consecutive steps share cache lines
-    const double* __restrict__ xv = x + (int64_t)c * BS;
-    const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
-#pragma unroll
-    for (int cp = 0; cp < BS / 2; ++cp) {
-      const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
-      acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
-    }
-    if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+    bsell_block_step<BS, false>(vb + (int64_t)k * (BS * WAVE), x + (int64_t)c * BS, lane, acc);
+  }
   }
   double out = 0.0;
   if (EP == EP_JAC) {
@@ -1016,17 +1045,18 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
       const double* __restrict__ vb = OFF.val + k0 * (BS * WAVE);
       const int32_t* __restrict__ cb = OFF.col + k0 * RB;
       double acc = 0.0;
+      if ((BS % 2) == 0 && (reinterpret_cast<uintptr_t>(xin) & 15) == 0) {
+#pragma unroll 2
+        for (int k = 0; k < w; ++k) {
+          const int c = cb[k * RB + rbl];
+          bsell_block_step<BS, true>(vb + (int64_t)k * (BS * WAVE), xin + (int64_t)c * BS, lane, acc);
+        }
+      } else {
 #pragma unroll 2
       for (int k = 0; k < w; ++k) {
         const int c = cb[k * RB + rbl];
-        const double* __restrict__ xv = xin + (int64_t)c * BS;
-        const double* __restrict__ vk = vb + (int64_t)k * (BS * WAVE);
-#pragma unroll
-        for (int cp = 0; cp < BS / 2; ++cp) {
-          const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
-          acc += v0 * xv[2 * cp] + v1 * xv[2 * cp + 1];
-        }
-        if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
+        bsell_block_step<BS, false>(vb + (int64_t)k * (BS * WAVE), xin + (int64_t)c * BS, lane, acc);
+      }
       }
       if (active) bsh[lrow * BS + r] -= acc;
     }
@@ -2107,6 +2137,19 @@ __global__ __launch_bounds__(BLOCK) void dense_op_gemv_kernel(int n, int ld, con
   const int np = n >> 1;                        // full pairs per row; an odd last entry is added by lane 0 (x has exactly n entries)
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int c = lane;
+  // (a wave walks its row in dependent round trips: eight 16-byte loads of M in flight per lane halve their number -- n = 2 824 at cfg 2:
+  //  3 instead of 6)
+  for (; c + 7 * WAVE < np; c += 8 * WAVE) {
+    double2 m[8], v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = m2[c + q * WAVE];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = x2[c + q * WAVE];
+    a0 += (m[0].x * v[0].x + m[0].y * v[0].y) + (m[4].x * v[4].x + m[4].y * v[4].y);
+    a1 += (m[1].x * v[1].x + m[1].y * v[1].y) + (m[5].x * v[5].x + m[5].y * v[5].y);
+    a2 += (m[2].x * v[2].x + m[2].y * v[2].y) + (m[6].x * v[6].x + m[6].y * v[6].y);
+    a3 += (m[3].x * v[3].x + m[3].y * v[3].y) + (m[7].x * v[7].x + m[7].y * v[7].y);
+  }
   for (; c + 3 * WAVE < np; c += 4 * WAVE) {    // four independent 16-byte loads in flight per lane
     const double2 m0 = m2[c], m1 = m2[c + WAVE], mm2 = m2[c + 2 * WAVE], m3 = m2[c + 3 * WAVE];
     const double2 v0 = x2[c], v1 = x2[c + WAVE], v2 = x2[c + 2 * WAVE], v3 = x2[c + 3 * WAVE];

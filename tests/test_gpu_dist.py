@@ -260,7 +260,7 @@ def test_overlap_split_equals_unsplit(monkeypatch):
     assert np.linalg.norm(res[0] - res[1]) <= 1e-14 * np.linalg.norm(res[1])
 
 
-@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (3, (20, 9, 9), 3, 100)])
+@pytest.mark.parametrize("R,box,dim,dmin", [(2, (16, 16, 16), 3, 200), (4, (12, 12, 12), 3, 100), (3, (20, 9, 9), 3, 100), (1, (20, 18, 16), 3, 200)])
 def test_loopback_device_fused_kernels_on_rank_partitioned_levels(R, box, dim, dmin, monkeypatch):
     """the production shape of the multi-GPU run: level 0 in the one-thread-per-row form, i.e. the FUSED down kernel
     (pre-smoothing + chunk-local restriction, omega*Dinv in the diagonal slot) and the windowed Q kernel on matrices WITH
@@ -269,6 +269,9 @@ def test_loopback_device_fused_kernels_on_rank_partitioned_levels(R, box, dim, d
     from ngsamg_amd import dist as D
     from oracle.pyoracle import Oracle
     monkeypatch.setenv("AMGX_SELL_MAX_LANES", "1")
+    # (R = 1: a rank without ghost columns has SQUARE levels -- the compact-chunk form of the fused kernel must stay off on a handle
+    #  that is driven in interior / boundary chunk ranges; the size threshold is lowered so that it would otherwise apply)
+    monkeypatch.setenv("AMGX_COMPACT_CHUNKS_MIN_ROWS", "100")
     comm = D.LoopbackComm(R)
     pg = (R, 1, 1) if R == 3 else D.proc_grid(R, dim)
     states = [D.assemble_poisson_owned(r, pg, box) for r in range(R)]
