@@ -137,6 +137,15 @@ int amgh_transpose_fill(const amgh_matrix* A, const int64_t* rowptr_T, int32_t* 
 /* C = A*B in two calls: first with col_out == NULL to obtain rowptr (size n_rows+1), then fill */
 int amgh_matmul(const amgh_matrix* A, const amgh_matrix* B, int64_t* rowptr_out, int32_t* col_out, double* val_out);
 
+/* Galerkin product on an accelerator: when a pair is installed, amgh_setup hands the scalar products (P^T A) P of levels
+ * with at least `min_rows` fine rows to `run` (which returns 0 = done with *n_rows / *nnz set, 2 = "not for me": the host
+ * product runs, anything else = error) and reads the arrays back with `fetch` (which also releases the result).  The device
+ * library's amgx_galerkin / amgx_csr_result_fetch (amgx.h) are that pair; its result equals the host product bit for bit.
+ * run = NULL removes the hook.  Not thread-safe against a running amgh_setup. */
+typedef int (*amgh_galerkin_fn)(const amgh_matrix* PT, const amgh_matrix* A, const amgh_matrix* P, void** result, int64_t* n_rows, int64_t* nnz);
+typedef int (*amgh_galerkin_fetch_fn)(void* result, int64_t* rowptr, int32_t* col, double* val);
+int amgh_set_galerkin_hook(amgh_galerkin_fn run, amgh_galerkin_fetch_fn fetch, int64_t min_rows);
+
 /* synthetic P1 problems on Kuhn grids (stand-in for the calling FEM package) */
 int amgh_kuhn_pattern(int dim, const int64_t* shape, int64_t* rowptr_out);
 int amgh_kuhn_assemble(int dim, const int64_t* shape, const double* coords, int kind, int bs, double mu, double lam,

@@ -355,6 +355,21 @@ int amgx_dist_rhs_buffer(amgx_dist d, double** b, int64_t* n_owned, int64_t* n_e
 /* borrowed handles of the rank-partitioned levels and of the replicated tail, for queries / measurement only */
 int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail);
 
+/* ---- setup products on the device (cold path; host arrays in, host arrays out) ---------------------------------------------
+ * C = A B (MatMultABImpl, src/base/linalg/utils_sparseMM.cpp:107-238) and the Galerkin product A_c = (P^T A) P
+ * (RestrictMatrix, utils_sparseMM.hpp:93-109; the intermediate P^T A stays on the device) for scalar CSR matrices, columns
+ * ascending per row.  Entry (i, j) is accumulated as c = fma(a_ik, b_kj, c) over k ascending from c = 0 -- the order and the
+ * fused multiply-add of the host library's product (csrc/host/sparse.cpp), so the result is the same bit for bit.
+ * Returns 0 = done (*out holds the result on the device, *n_rows / *nnz its size: allocate and call amgx_csr_result_fetch,
+ * which copies the arrays out and releases the result), 2 = not supported (block matrices, a row with more than 8192
+ * products): the caller keeps its own product, 1 = error (amgx_last_error(NULL)).
+ * The host setup library takes the pair (amgx_galerkin, amgx_csr_result_fetch) through amgh_set_galerkin_hook (amgh.h). */
+typedef struct amgx_csr_result_t* amgx_csr_result;
+int amgx_device_count(int32_t* n);      /* visible HIP devices (0 without a GPU or driver; never an error) */
+int amgx_spgemm(const amgx_matrix* A, const amgx_matrix* B, amgx_csr_result* out, int64_t* n_rows, int64_t* nnz);
+int amgx_galerkin(const amgx_matrix* PT, const amgx_matrix* A, const amgx_matrix* P, amgx_csr_result* out, int64_t* n_rows, int64_t* nnz);
+int amgx_csr_result_fetch(amgx_csr_result res, int64_t* rowptr, int32_t* col, double* val);
+
 /* stand-alone halo map = DCCMap (dcc_map.hpp:20-90): mode 0 owner -> ghost overwrite (StartCO2CU / ApplyCO2CU,
  * dcc_map.cpp:138-178), mode 1 ghost -> owner add with the ghost entries zeroed (StartDIS2CO / ApplyDIS2CO, :76-136).
  * vecs: device vectors of (n_owned + n_ghost) * bs entries, ordered on the communicator's stream. */

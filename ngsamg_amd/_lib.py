@@ -95,6 +95,7 @@ def host():
     lib.amgh_transpose_count.argtypes = [C.POINTER(amgh_matrix), c_i64p]
     lib.amgh_transpose_fill.argtypes = [C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
     lib.amgh_matmul.argtypes = [C.POINTER(amgh_matrix), C.POINTER(amgh_matrix), c_i64p, c_i32p, c_f64p]
+    lib.amgh_set_galerkin_hook.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.amgh_kuhn_pattern.argtypes = [C.c_int, c_i64p, c_i64p]
     lib.amgh_kuhn_assemble.argtypes = [C.c_int, c_i64p, c_f64p, C.c_int, C.c_int, C.c_double, C.c_double,
                                        c_f64p, c_i64p, c_i32p, c_f64p, c_f64p]
@@ -243,6 +244,7 @@ AMGX_SYMBOLS = [
     "amgx_dist_rhs_buffer", "amgx_dist_handles", "amgx_halo_create", "amgx_halo_destroy", "amgx_halo_exchange",
     "amgx_gss4_create", "amgx_gss4_destroy", "amgx_gss4_last_error", "amgx_gss4_set_stream", "amgx_gss4_synchronize",
     "amgx_gss4_info", "amgx_gss4_smooth", "amgx_gss4_smooth_res", "amgx_gss4_mult_add",
+    "amgx_device_count", "amgx_spgemm", "amgx_galerkin", "amgx_csr_result_fetch",
 ]
 
 AMGH_SYMBOLS = [
@@ -250,6 +252,7 @@ AMGH_SYMBOLS = [
     "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
     "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble", "amgh_bgs_dinv", "amgh_bgs_coloring",
     "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext", "amgh_hybrid_dinv_block", "amgh_compact_blocks", "amgh_coloring_blockids", "amgh_hybrid_dinv_block_ids",
+    "amgh_set_galerkin_hook",
 ]
 
 
@@ -323,5 +326,50 @@ def hip():
     lib.amgx_gss4_smooth.argtypes = [vp, C.c_int, dp, dp, C.c_int]
     lib.amgx_gss4_smooth_res.argtypes = [vp, C.c_int, dp, dp, C.c_int]
     lib.amgx_gss4_mult_add.argtypes = [vp, C.c_double, dp, dp, C.c_int]
+    # setup products on the device
+    lib.amgx_device_count.argtypes = [c_i32p]
+    lib.amgx_spgemm.argtypes = [C.POINTER(amgx_matrix), C.POINTER(amgx_matrix), C.POINTER(vp), c_i64p, c_i64p]
+    lib.amgx_galerkin.argtypes = [C.POINTER(amgx_matrix), C.POINTER(amgx_matrix), C.POINTER(amgx_matrix), C.POINTER(vp), c_i64p, c_i64p]
+    lib.amgx_csr_result_fetch.argtypes = [vp, c_i64p, c_i32p, c_f64p]
     _hip = lib
     return lib
+
+
+_device_setup = None
+
+
+def device_setup(enable=None, min_rows=None):
+    """Hand the scalar Galerkin products of amgh_setup to the device library (amgh_set_galerkin_hook <- amgx_galerkin).
+
+    Called by Hierarchy() before every setup: installs the pair once when a GPU is visible and NGSAMG_DEVICE_SETUP is not 0
+    (levels with at least NGSAMG_DEVICE_SETUP_MIN_ROWS fine rows, default 100000).  enable=False removes the hook, enable=True
+    insists on it (raises without a GPU).  The device product equals the host product bit for bit (tests/test_gpu_spgemm.py);
+    without a GPU the host product runs -- the setup is the cold path, the apply path has no such alternative."""
+    global _device_setup
+    if enable is None:
+        if _device_setup is not None and min_rows is None:
+            return _device_setup
+        enable = os.environ.get("NGSAMG_DEVICE_SETUP", "1") != "0"
+        insist = False
+    else:
+        insist = bool(enable)
+    h = host()
+    if not enable:
+        hcheck(h.amgh_set_galerkin_hook(None, None, 0))
+        _device_setup = False
+        return False
+    ok = os.path.exists(os.path.join(LIBDIR, "libngsamg_hip.so")) or bool(os.environ.get("NGSAMG_HIP_LIB"))
+    n = C.c_int32(0)
+    if ok:
+        d = hip()
+        ok = d.amgx_device_count(C.byref(n)) == 0 and n.value > 0
+    if not ok:
+        if insist:
+            raise NgsAMGError("device_setup: no HIP device (or libngsamg_hip.so missing)")
+        _device_setup = False
+        return False
+    if min_rows is None:
+        min_rows = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "100000"))
+    hcheck(h.amgh_set_galerkin_hook(C.cast(d.amgx_galerkin, C.c_void_p), C.cast(d.amgx_csr_result_fetch, C.c_void_p), int(min_rows)))
+    _device_setup = True
+    return True

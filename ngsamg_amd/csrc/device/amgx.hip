@@ -101,6 +101,14 @@ struct DevBuf {
 
 enum Fmt : int { FMT_CSRVEC = 0, FMT_SELL = 1, FMT_BSELL = 2, FMT_RB = 4 };     // (3 is reported for windowed SELL, see amgx_matrix_info)
 
+// gathered-vector access of the BSELL kernels (BSellMat::xmode); AMGX_BSELL_XMODE overrides (same arithmetic in every mode).
+// Same box, cfg 3 GS / cfg 5 GS / cfg 5 block-Jacobi applications per second (profiles/r04/gs_experiments.txt):
+//   0 (BS 8-byte loads) 281.9 / 160.6 / 193.1    1 (16-byte loads) 277.7 / 160.4 / 189.3    2 (one load + lane exchange) 246.2 / 149.9 / 189.3
+static int bsell_xmode() {
+  static const int m = [] { const char* e = std::getenv("AMGX_BSELL_XMODE"); return e ? std::max(0, std::min(2, std::atoi(e))) : 0; }();
+  return m;
+}
+
 struct DevMatrix {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int br = 1, bc = 1;
@@ -139,7 +147,7 @@ struct DevMatrix {
     DevBuf<int64_t> slice_ptr;
     DevBuf<int32_t> col;
     DevBuf<double> val;
-    BSellMat view() const { return BSellMat{slice_ptr.p, col.p, val.p}; }
+    BSellMat view() const { return BSellMat{slice_ptr.p, col.p, val.p, bsell_xmode()}; }
   } bsell;
   bool empty() const { return n_rows == 0; }
 };
@@ -2231,6 +2239,7 @@ static void build_gs(const amgx_level_desc& d, DevLevel& L) {
 
 }  // namespace amgx
 #include "devbuild.hpp"
+#include "spgemm.hpp"
 namespace amgx {
 
 // Block-hybrid Gauss-Seidel data (gsb_sweep_kernel).  Validated like the colourings above: two coupled rows of one block
@@ -3668,6 +3677,67 @@ int amgx_destroy(amgx_handle h) {
   if (h->h) { (void)hipSetDevice(h->h->device); (void)hipDeviceSynchronize(); delete h->h; }
   delete h;
   return 0;
+}
+
+int amgx_device_count(int32_t* n) {
+  if (!n) return 1;
+  int nd = 0;
+  *n = (hipGetDeviceCount(&nd) == hipSuccess) ? nd : 0;
+  return 0;
+}
+
+// ---- setup products on the device (spgemm.hpp) -------------------------------------------------------
+int amgx_spgemm(const amgx_matrix* A, const amgx_matrix* B, amgx_csr_result* out, int64_t* n_rows, int64_t* nnz) {
+  try {
+    if (!A || !B || !out) throw amgx::Err("amgx_spgemm: null argument");
+    *out = nullptr;
+    if (A->br != 1 || A->bc != 1 || B->br != 1 || B->bc != 1) return 2;
+    if (A->n_cols != B->n_rows) throw amgx::Err("amgx_spgemm: dimension mismatch");
+    amgx::DevCsrSrc a, b;
+    a.upload(*A);
+    b.upload(*B);
+    auto r = std::make_unique<amgx::DevCsrSrc>();
+    if (!amgx::dev_spgemm(a, b, *r)) return 2;
+    if (n_rows) *n_rows = r->n_rows;
+    if (nnz) *nnz = r->nnz;
+    *out = reinterpret_cast<amgx_csr_result>(r.release());
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
+}
+
+int amgx_galerkin(const amgx_matrix* PT, const amgx_matrix* A, const amgx_matrix* P, amgx_csr_result* out, int64_t* n_rows, int64_t* nnz) {
+  try {
+    if (!PT || !A || !P || !out) throw amgx::Err("amgx_galerkin: null argument");
+    *out = nullptr;
+    for (const amgx_matrix* m : {PT, A, P}) if (m->br != 1 || m->bc != 1) return 2;
+    if (PT->n_cols != A->n_rows || A->n_cols != P->n_rows) throw amgx::Err("amgx_galerkin: dimension mismatch");
+    amgx::DevCsrSrc pta;
+    {
+      amgx::DevCsrSrc pt, a;
+      pt.upload(*PT);
+      a.upload(*A);
+      if (!amgx::dev_spgemm(pt, a, pta)) return 2;
+    }
+    amgx::DevCsrSrc p;
+    p.upload(*P);
+    auto r = std::make_unique<amgx::DevCsrSrc>();
+    if (!amgx::dev_spgemm(pta, p, *r)) return 2;
+    if (n_rows) *n_rows = r->n_rows;
+    if (nnz) *nnz = r->nnz;
+    *out = reinterpret_cast<amgx_csr_result>(r.release());
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
+}
+
+int amgx_csr_result_fetch(amgx_csr_result res, int64_t* rowptr, int32_t* col, double* val) {
+  std::unique_ptr<amgx::DevCsrSrc> r(reinterpret_cast<amgx::DevCsrSrc*>(res));
+  try {
+    if (!r) throw amgx::Err("amgx_csr_result_fetch: null result");
+    if (rowptr) HIPCHK(hipMemcpy(rowptr, r->rowptr.p, (size_t)(r->n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (col && r->nnz) HIPCHK(hipMemcpy(col, r->col.p, (size_t)r->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (val && r->nnz) HIPCHK(hipMemcpy(val, r->val.p, (size_t)r->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+  } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
 }
 
 int amgx_set_stream(amgx_handle hh, void* s) {

@@ -456,6 +456,7 @@ struct BSellMat {
   const int64_t* slice_ptr;   // [n_slices+1] cumulative block steps
   const int32_t* col;         // [steps * RB]
   const double* val;          // [steps * BS * 64]
+  int xmode;                  // gathered-vector access: 0 = BS 8-byte loads per lane, 1 = 16-byte loads, 2 = one load + lane exchange
 };
 
 #ifndef BSELL_UNROLL
@@ -464,8 +465,9 @@ struct BSellMat {
 // one block step of a BSELL row product: acc += (row r of the BS x BS block at vk) . x_block.
 // V2 (even block sizes, x 16-byte aligned: c * BS * 8 is then a multiple of 16): the x block is read with 16-byte loads.  Counters at
 // cfg 3 (profiles/r04/pmc_cfg3_gs_sq.csv): the 6x6 kernels spend 46 ... 78 % of their wave cycles stalled on instruction ISSUE -- per
-// block step six 8-byte gathers (ten distinct lines each: one per block row of the wave) next to three streaming loads; 16-byte loads
-// halve the gather instructions.
+// block step six 8-byte gathers (ten distinct lines each: one per block row of the wave) next to three streaming loads.  Halving the
+// gather instructions (V2) or replacing them by one load + a lane exchange (bsell_block_step_shfl) did NOT pay (BSellMat::xmode 1 / 2,
+// measured neutral / 7-13 % slower, see amgx.hip bsell_xmode): both stay opt-in.
 template <int BS, bool V2>
 __device__ __forceinline__ void bsell_block_step(const double* __restrict__ vk, const double* __restrict__ xv, int lane, double& acc) {
   if (V2 && (BS % 2) == 0) {
@@ -486,6 +488,22 @@ __device__ __forceinline__ void bsell_block_step(const double* __restrict__ vk, 
     }
     if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xv[BS - 1];
   }
+}
+// the same step with ONE 8-byte gather per lane: lane r of a block row reads x[c * BS + r] and the BS lanes of the block row exchange
+// their values through the cross-lane network (base = first lane of the block row).  Same products in the same order.
+template <int BS>
+__device__ __forceinline__ void bsell_block_step_shfl(const double* __restrict__ vk, const double* __restrict__ xv, int lane, int r, int base,
+                                                      double& acc) {
+  const double mine = xv[r];
+  double xb[BS];
+#pragma unroll
+  for (int c = 0; c < BS; ++c) xb[c] = __shfl(mine, base + c, WAVE);
+#pragma unroll
+  for (int cp = 0; cp < BS / 2; ++cp) {
+    const double v0 = ld_nt(vk + cp * (2 * WAVE) + lane * 2), v1 = ld_nt(vk + cp * (2 * WAVE) + lane * 2 + 1);
+    acc += v0 * xb[2 * cp] + v1 * xb[2 * cp + 1];
+  }
+  if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xb[BS - 1];
 }
 
 template <int BS, int EP>
@@ -519,8 +537,14 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int s
     }
   }
   double acc = 0.0;
-  const bool x16 = (BS % 2) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;      // (wave-uniform)
-  if (x16) {
+  const bool x16 = M.xmode == 1 && (BS % 2) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;      // (wave-uniform)
+  if (M.xmode == 2) {
+    const int xbase = lane - r;
+    for (int k = 0; k < w; ++k) {
+      const int c = cb[k * RB + rbl];
+      bsell_block_step_shfl<BS>(vb + (int64_t)k * (BS * WAVE), x + (int64_t)c * BS, lane, r, xbase, acc);
+    }
+  } else if (x16) {
 #pragma unroll BSELL_UNROLL
     for (int k = 0; k < w; ++k) {
       const int c = cb[k * RB + rbl];
@@ -528,10 +552,10 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int s
     }
   } else {
 #pragma unroll BSELL_UNROLL
-  for (int k = 0; k < w; ++k) {
-    const int c = cb[k * RB + rbl];        // cached load: the RB*4-byte column chunks of consecutive steps share cache lines
-    bsell_block_step<BS, false>(vb + (int64_t)k * (BS * WAVE), x + (int64_t)c * BS, lane, acc);
-  }
+    for (int k = 0; k < w; ++k) {
+      const int c = cb[k * RB + rbl];        // cached load: the RB*4-byte column chunks of consecutive steps share cache lines
+      bsell_block_step<BS, false>(vb + (int64_t)k * (BS * WAVE), x + (int64_t)c * BS, lane, acc);
+    }
   }
   double out = 0.0;
   if (EP == EP_JAC) {
@@ -1045,7 +1069,12 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
       const double* __restrict__ vb = OFF.val + k0 * (BS * WAVE);
       const int32_t* __restrict__ cb = OFF.col + k0 * RB;
       double acc = 0.0;
-      if ((BS % 2) == 0 && (reinterpret_cast<uintptr_t>(xin) & 15) == 0) {
+      if (OFF.xmode == 2) {
+        for (int k = 0; k < w; ++k) {
+          const int c = cb[k * RB + rbl];
+          bsell_block_step_shfl<BS>(vb + (int64_t)k * (BS * WAVE), xin + (int64_t)c * BS, lane, r, lane - r, acc);
+        }
+      } else if (OFF.xmode == 1 && (BS % 2) == 0 && (reinterpret_cast<uintptr_t>(xin) & 15) == 0) {
 #pragma unroll 2
         for (int k = 0; k < w; ++k) {
           const int c = cb[k * RB + rbl];

@@ -41,6 +41,13 @@ BCSR matmul(const BCSR& A, const BCSR& B);
 
 // Galerkin product in the reference's order (P^T A) P  (utils_sparseMM.hpp:93-109)
 BCSR restrict_matrix(const BCSR& PT, const BCSR& A, const BCSR& P);
+// accelerator hook of restrict_matrix (amgh.h: amgh_set_galerkin_hook); the matrix arguments are amgh_matrix views
+struct GalerkinHook {
+  int (*run)(const void* PT, const void* A, const void* P, void** result, int64_t* n_rows, int64_t* nnz) = nullptr;
+  int (*fetch)(void* result, int64_t* rowptr, int32_t* col, double* val) = nullptr;
+  int64_t min_rows = 0;
+};
+GalerkinHook& galerkin_hook();
 
 // y = A x  (y overwritten); x, y are AoS block vectors
 void spmv(const BCSR& A, const double* x, double* y);

@@ -352,6 +352,16 @@ int amgh_matmul(const amgh_matrix* A, const amgh_matrix* B, int64_t* rowptr_out,
   });
 }
 
+int amgh_set_galerkin_hook(amgh_galerkin_fn run, amgh_galerkin_fetch_fn fetch, int64_t min_rows) {
+  return guard([&] {
+    if ((run == nullptr) != (fetch == nullptr)) throw amgh::Error("amgh_set_galerkin_hook: run and fetch come as a pair");
+    amgh::GalerkinHook& h = amgh::galerkin_hook();
+    h.run = reinterpret_cast<decltype(h.run)>(run);
+    h.fetch = fetch;
+    h.min_rows = min_rows;
+  });
+}
+
 int amgh_kuhn_pattern(int dim, const int64_t* shape, int64_t* rowptr_out) {
   return guard([&] {
     if (dim != 2 && dim != 3) throw amgh::Error("kuhn: dim must be 2 or 3");

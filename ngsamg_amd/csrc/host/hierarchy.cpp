@@ -326,6 +326,14 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   std::vector<int32_t> size;               // base vertices per current vertex
   std::vector<int32_t> map;
   int64_t ncur = 0;
+  const bool tlog = std::getenv("NGSAMG_SETUP_LOG") != nullptr;
+  double tl = omp_get_wtime();
+  auto lap = [&](const char* what, int round) {
+    if (!tlog) return;
+    const double t = omp_get_wtime();
+    std::fprintf(stderr, "[setup_levels]     spw round %d  %-22s %8.1f ms\n", round, what, 1e3 * (t - tl));
+    tl = t;
+  };
   for (int round = 0; round < num_rounds; round++) {
     const int64_t m = g->n;
     std::vector<uint8_t> handled(m, 0);
@@ -355,11 +363,13 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
       }
       if (!handled[v]) make_pair(v);
     }
+    lap("pairing", round);
     if (nn == 0) break;
     // compose with the base-level map, contract the graph, carry the scales
     if (round == 0) { for (int64_t i = 0; i < n; i++) agg[i] = free[i] ? map[i] : -1; }
     else for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = map[agg[i]];
     Graph next = contract(*g, map, nn);
+    lap("contract", round);
     std::vector<double> nmt(nn, 0.0);
     for (int64_t I = 0; I < nn; I++) for (int64_t k = next.ptr[I]; k < next.ptr[I + 1]; k++) nmt[I] = std::max(nmt[I], next.w[k]);
     for (int64_t i = 0; i < m; i++) if (map[i] >= 0) nmt[map[i]] = std::max(nmt[map[i]], mt[i]);

@@ -112,7 +112,38 @@ BCSR matmul(const BCSR& A, const BCSR& B) {
   return matmul_impl<false>(A, B);
 }
 
+GalerkinHook& galerkin_hook() {
+  static GalerkinHook h;
+  return h;
+}
+
+namespace {
+// layout of amgh_matrix (include/amgh.h)
+struct MatView { int64_t n_rows, n_cols; int32_t br, bc; const int64_t* rowptr; const int32_t* col; const double* val; };
+MatView view_of(const BCSR& M) { return MatView{M.n_rows, M.n_cols, M.br, M.bc, M.rowptr.data(), M.col.data(), M.val.data()}; }
+}  // namespace
+
 BCSR restrict_matrix(const BCSR& PT, const BCSR& A, const BCSR& P) {
+  const GalerkinHook& hk = galerkin_hook();
+  const bool scalar = PT.bsz() == 1 && A.bsz() == 1 && P.bsz() == 1;
+  if (hk.run && hk.fetch && scalar && A.n_rows >= hk.min_rows) {
+    const MatView vpt = view_of(PT), va = view_of(A), vp = view_of(P);
+    void* res = nullptr;
+    int64_t nr = 0, nnz = 0;
+    const int rc = hk.run(&vpt, &va, &vp, &res, &nr, &nnz);
+    if (rc == 0) {
+      BCSR C;
+      C.n_rows = PT.n_rows; C.n_cols = P.n_cols; C.br = 1; C.bc = 1;
+      if (nr != C.n_rows) { hk.fetch(res, nullptr, nullptr, nullptr); throw Error("galerkin hook: result has the wrong number of rows"); }
+      C.rowptr.resize(nr + 1);
+      C.col.resize(nnz);
+      C.val.resize(nnz);
+      if (hk.fetch(res, C.rowptr.data(), C.col.data(), C.val.data()) != 0) throw Error("galerkin hook: fetch failed");
+      if (C.rowptr.back() != nnz) throw Error("galerkin hook: inconsistent result");
+      return C;
+    }
+    if (rc != 2) throw Error("galerkin hook failed");
+  }
   BCSR PTA = matmul(PT, A);
   return matmul(PTA, P);
 }

@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import NgsAMGError
+from ._lib import Matrix, NgsAMGError
 
 # "hgs" = Gauss-Seidel in the block-hybrid form (one launch per sweep, amgx_level_desc.gs_block_rows); "gs" = multicolour
 _SM = {"jacobi": _lib.AMGX_SM_JACOBI, "gs": _lib.AMGX_SM_GS, "hgs": _lib.AMGX_SM_GS, "bgs": _lib.AMGX_SM_BGS}
@@ -434,6 +434,42 @@ class DeviceAMGMatrix:
 # ---------------------------------------------------------------------------------------------
 # byte model of SURVEY.md section 8d / BASELINE.md (algorithmic bytes per cycle)
 # ---------------------------------------------------------------------------------------------
+
+def _fetch_result(lib, res, n_rows, n_cols, nnz):
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    col = np.zeros(max(1, nnz), dtype=np.int32)
+    val = np.zeros(max(1, nnz))
+    if lib.amgx_csr_result_fetch(res, _lib.ptr(rp, C.c_int64), _lib.ptr(col, C.c_int32), _lib.ptr(val, C.c_double)) != 0:
+        raise NgsAMGError(lib.amgx_last_error(None).decode())
+    return Matrix(n_rows, n_cols, 1, 1, rp, col[:nnz], val[:nnz])
+
+
+def device_spmm(A, B):
+    """C = A B on the device (amgx_spgemm; scalar CSR, bit-identical to the host library's amgh_matmul).
+    None: the device library does not take this product (block matrices, a row with more than 8192 products)."""
+    lib = _lib.hip()
+    da, db = A.desc(_lib.amgx_matrix), B.desc(_lib.amgx_matrix)
+    res, nr, nnz = C.c_void_p(), C.c_int64(), C.c_int64()
+    rc = lib.amgx_spgemm(C.byref(da), C.byref(db), C.byref(res), C.byref(nr), C.byref(nnz))
+    if rc == 2:
+        return None
+    if rc != 0:
+        raise NgsAMGError(lib.amgx_last_error(None).decode())
+    return _fetch_result(lib, res, int(nr.value), B.n_cols, int(nnz.value))
+
+
+def device_galerkin(PT, A, P):
+    """A_c = (P^T A) P on the device (amgx_galerkin); None as device_spmm."""
+    lib = _lib.hip()
+    dt, da, dp = PT.desc(_lib.amgx_matrix), A.desc(_lib.amgx_matrix), P.desc(_lib.amgx_matrix)
+    res, nr, nnz = C.c_void_p(), C.c_int64(), C.c_int64()
+    rc = lib.amgx_galerkin(C.byref(dt), C.byref(da), C.byref(dp), C.byref(res), C.byref(nr), C.byref(nnz))
+    if rc == 2:
+        return None
+    if rc != 0:
+        raise NgsAMGError(lib.amgx_last_error(None).decode())
+    return _fetch_result(lib, res, int(nr.value), P.n_cols, int(nnz.value))
+
 
 def matrix_bytes(M):
     """B(M) = nnz*(8*br*bc + 4) + 4*(n+1): fp64 values, int32 columns, int32 row pointers."""

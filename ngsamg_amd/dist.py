@@ -374,12 +374,21 @@ def _bs(s):
     return int(getattr(s, "bs", 1))
 
 
+_DEVICE_SPMM_MIN_ROWS = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "100000"))
+
+
 def _spmm(A, B, br=1, bk=1, bc=1):
     """C = A B through the host library (OpenMP Gustavson, sorted columns).  A has br x bk blocks, B bk x bc blocks (scalar
     scipy matrices in AoS numbering): the product runs on the block matrices -- one index operation per block instead of per
     entry (36x fewer for the 6 x 6 levels; it was the largest single cost of the distributed elasticity setup)"""
     lib = _lib.host()
     MA, MB = _mat(A, br, bk), _mat(B, bk, bc)
+    if br == bk == bc == 1 and MA.n_rows >= _DEVICE_SPMM_MIN_ROWS and _lib.device_setup():
+        # scalar products of the big levels on the device (amgx_spgemm: the same bits as the host product)
+        from .device import device_spmm
+        Cd = device_spmm(MA, MB)
+        if Cd is not None:
+            return sp.csr_matrix((Cd.val, Cd.col, Cd.rowptr), shape=(MA.n_rows, MB.n_cols))
     da, db = MA.desc(), MB.desc()
     rp = np.zeros(MA.n_rows + 1, dtype=np.int64)
     _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), None, None))

@@ -120,6 +120,7 @@ class Hierarchy:
 
     def __init__(self, A: Matrix, free=None, coords=None, dim=3, energy=0, **options):
         lib = _lib.host()
+        _lib.device_setup()          # Galerkin products on the device when one is visible (bit-identical; amgh.h: amgh_set_galerkin_hook)
         self.options = make_options(dim, energy, **options)
         self.dim = int(dim)
         self.energy = int(energy)

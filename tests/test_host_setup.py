@@ -390,3 +390,42 @@ def test_block_coloured_gauss_seidel_order_is_inside_the_iteration_tolerance(rot
     it_hy = Oracle(hlv, sm_type=htypes).pcg(b, tol=1e-8, maxit=200)[1]
     assert it_bc <= int(np.ceil(1.15 * it_seq)), (it_bc, it_seq)
     assert it_bc <= it_hy, (it_bc, it_hy)
+
+
+def test_galerkin_hook_protocol():
+    """amgh_set_galerkin_hook: the hook sees the scalar products of levels with at least min_rows rows; 2 = "not for me" leaves the
+    host product in place (same hierarchy); an error code fails the setup; run / fetch come as a pair."""
+    import ctypes as C
+    from ngsamg_amd import _lib
+    from ngsamg_amd.hierarchy import Hierarchy
+    lib = _lib.host()
+    prob = fem.poisson_fast((12, 11, 10), dirichlet="right")
+    A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
+    RUN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64))
+    FETCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double))
+    seen = []
+    code = [2]
+
+    def run(pt, a, p, res, nr, nnz):
+        seen.append(C.cast(a, C.POINTER(_lib.amgh_matrix)).contents.n_rows)
+        return code[0]
+
+    run_c, fetch_c = RUN(run), FETCH(lambda *a: 1)
+    saved = _lib._device_setup
+    try:
+        _lib.device_setup(False)
+        H0 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=20, spw=1)
+        _lib._device_setup = False          # Hierarchy() must not replace the test's hook
+        _lib.hcheck(lib.amgh_set_galerkin_hook(C.cast(run_c, C.c_void_p), C.cast(fetch_c, C.c_void_p), 100))
+        H1 = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=20, spw=1)
+        sizes = [l.A.n_rows for l in H0.levels[:-1]]
+        assert seen == [n for n in sizes if n >= 100] and len(seen) >= 1
+        for a, b in zip(H0.levels, H1.levels):
+            assert np.array_equal(a.A.col, b.A.col) and np.array_equal(a.A.val, b.A.val)
+        code[0] = 1
+        with pytest.raises(NgsAMGError, match="galerkin hook failed"):
+            Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=20, spw=1)
+        assert lib.amgh_set_galerkin_hook(C.cast(run_c, C.c_void_p), None, 0) != 0
+    finally:
+        lib.amgh_set_galerkin_hook(None, None, 0)
+        _lib._device_setup = saved
