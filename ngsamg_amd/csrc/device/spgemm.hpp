@@ -137,11 +137,8 @@ static void spg_launch(spg::SpgArgs a, int64_t n_list) {
   constexpr int GROUPS = spg::SPG_BLOCK / G;
   constexpr size_t PER = (size_t)CAP * 4 + 16 + (FILL ? (size_t)CAP * 8 + (size_t)CAP * 4 : 0);
   constexpr size_t lds = PER * GROUPS;
-  static bool attr = false;
-  if (!attr) {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spg::spg_row_kernel<G, CAP, FILL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  // (per launch: the attribute belongs to the current device's copy of the kernel)
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&spg::spg_row_kernel<G, CAP, FILL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t grid = (n_list + GROUPS - 1) / GROUPS;
   if (grid > 0x7fffffffLL) throw Err("spgemm: too many rows for one launch");
   a.n_list = n_list;
