@@ -414,6 +414,7 @@ def main():
     torch.cuda.set_device(device)
 
     from ngsamg_amd import fem
+    from ngsamg_amd import _lib as _lib_mod
     from ngsamg_amd._lib import Matrix
     from ngsamg_amd.hierarchy import Hierarchy
     from ngsamg_amd.device import DeviceAMGMatrix, vcycle_bytes, matrix_bytes
@@ -829,6 +830,9 @@ def main():
                        "post_smoothing": ("folded into the prolongation: x' = z + (I - w Dinv A) P x_c, same result up to rounding "
                                           "(AMGX_NO_FOLD=1 runs the literal kernel sequence)") if folded else "literal",
                        "parallelism": "1 GPU"},
+            # cold path, untimed: host assembly / hierarchy setup (Galerkin products on the device when NGSAMG_DEVICE_SETUP != 0) / amgx_create
+            "setup_s": {"assembly": round(t1 - t0, 2), "hierarchy": round(t2 - t1, 2), "amgx_create": round(t3 - t2, 2),
+                        "galerkin_on_device": bool(_lib_mod._device_setup)},
             "x_norm": x_norm,
             "device_memory": {"hierarchy_bytes": hier_bytes, "level0_csr_bytes": int(matrix_bytes(lv0.A)),
                               "ratio_to_level0_csr": round(hier_bytes / max(1, matrix_bytes(lv0.A)), 2)},

@@ -137,8 +137,8 @@ int amgh_transpose_fill(const amgh_matrix* A, const int64_t* rowptr_T, int32_t* 
 /* C = A*B in two calls: first with col_out == NULL to obtain rowptr (size n_rows+1), then fill */
 int amgh_matmul(const amgh_matrix* A, const amgh_matrix* B, int64_t* rowptr_out, int32_t* col_out, double* val_out);
 
-/* Galerkin product on an accelerator: when a pair is installed, amgh_setup hands the scalar products (P^T A) P of levels
- * with at least `min_rows` fine rows to `run` (which returns 0 = done with *n_rows / *nnz set, 2 = "not for me": the host
+/* Galerkin product on an accelerator: when a pair is installed, amgh_setup hands the products (P^T A) P of levels
+ * with at least `min_rows` fine (block) rows to `run` (which returns 0 = done with *n_rows / *nnz set, 2 = "not for me": the host
  * product runs, anything else = error) and reads the arrays back with `fetch` (which also releases the result).  The device
  * library's amgx_galerkin / amgx_csr_result_fetch (amgx.h) are that pair; its result equals the host product bit for bit.
  * run = NULL removes the hook.  Not thread-safe against a running amgh_setup. */

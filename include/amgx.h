@@ -357,12 +357,14 @@ int amgx_dist_handles(amgx_dist d, amgx_handle* top, amgx_handle* tail);
 
 /* ---- setup products on the device (cold path; host arrays in, host arrays out) ---------------------------------------------
  * C = A B (MatMultABImpl, src/base/linalg/utils_sparseMM.cpp:107-238) and the Galerkin product A_c = (P^T A) P
- * (RestrictMatrix, utils_sparseMM.hpp:93-109; the intermediate P^T A stays on the device) for scalar CSR matrices, columns
- * ascending per row.  Entry (i, j) is accumulated as c = fma(a_ik, b_kj, c) over k ascending from c = 0 -- the order and the
- * fused multiply-add of the host library's product (csrc/host/sparse.cpp), so the result is the same bit for bit.
- * Returns 0 = done (*out holds the result on the device, *n_rows / *nnz its size: allocate and call amgx_csr_result_fetch,
- * which copies the arrays out and releases the result), 2 = not supported (block matrices, a row with more than 8192
- * products): the caller keeps its own product, 1 = error (amgx_last_error(NULL)).
+ * (RestrictMatrix, utils_sparseMM.hpp:93-109; the intermediate P^T A stays on the device) for (block-)CSR matrices (result blocks
+ * of at most 36 entries: 1x1 ... 6x6), columns ascending per row.  Entry (i, j) is accumulated as c = fma(a_ik, b_kj, c) over k
+ * ascending from c = 0 (blocks: c[r][s] = fma(a[r][q], b[q][s], c[r][s]), q ascending inside every block product) -- the order and
+ * the fused multiply-add of the host library's product (csrc/host/sparse.cpp), so the result is the same bit for bit.
+ * Returns 0 = done (*out holds the result on the device, *n_rows / *nnz its size in block rows / blocks: allocate and call
+ * amgx_csr_result_fetch, which copies the arrays out and releases the result), 2 = not supported (larger blocks, a row with more
+ * than 8192 products or, block matrices, more distinct columns than one wave's table holds): the caller keeps its own product,
+ * 1 = error (amgx_last_error(NULL)).
  * The host setup library takes the pair (amgx_galerkin, amgx_csr_result_fetch) through amgh_set_galerkin_hook (amgh.h). */
 typedef struct amgx_csr_result_t* amgx_csr_result;
 int amgx_device_count(int32_t* n);      /* visible HIP devices (0 without a GPU or driver; never an error) */

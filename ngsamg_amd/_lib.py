@@ -339,10 +339,10 @@ _device_setup = None
 
 
 def device_setup(enable=None, min_rows=None):
-    """Hand the scalar Galerkin products of amgh_setup to the device library (amgh_set_galerkin_hook <- amgx_galerkin).
+    """Hand the Galerkin products of amgh_setup to the device library (amgh_set_galerkin_hook <- amgx_galerkin).
 
     Called by Hierarchy() before every setup: installs the pair once when a GPU is visible and NGSAMG_DEVICE_SETUP is not 0
-    (levels with at least NGSAMG_DEVICE_SETUP_MIN_ROWS fine rows, default 100000).  enable=False removes the hook, enable=True
+    (levels with at least NGSAMG_DEVICE_SETUP_MIN_ROWS fine rows, default 20000).  enable=False removes the hook, enable=True
     insists on it (raises without a GPU).  The device product equals the host product bit for bit (tests/test_gpu_spgemm.py);
     without a GPU the host product runs -- the setup is the cold path, the apply path has no such alternative."""
     global _device_setup
@@ -369,7 +369,7 @@ def device_setup(enable=None, min_rows=None):
         _device_setup = False
         return False
     if min_rows is None:
-        min_rows = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "100000"))
+        min_rows = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "20000"))
     hcheck(h.amgh_set_galerkin_hook(C.cast(d.amgx_galerkin, C.c_void_p), C.cast(d.amgx_csr_result_fetch, C.c_void_p), int(min_rows)))
     _device_setup = True
     return True

@@ -3691,12 +3691,12 @@ int amgx_spgemm(const amgx_matrix* A, const amgx_matrix* B, amgx_csr_result* out
   try {
     if (!A || !B || !out) throw amgx::Err("amgx_spgemm: null argument");
     *out = nullptr;
-    if (A->br != 1 || A->bc != 1 || B->br != 1 || B->bc != 1) return 2;
-    if (A->n_cols != B->n_rows) throw amgx::Err("amgx_spgemm: dimension mismatch");
-    amgx::DevCsrSrc a, b;
+    if (A->n_cols != B->n_rows || A->bc != B->br) throw amgx::Err("amgx_spgemm: dimension mismatch");
+    if (A->br * B->bc > 36 || A->br < 1 || A->bc < 1 || B->bc < 1) return 2;
+    amgx::SpCsr a, b;
     a.upload(*A);
     b.upload(*B);
-    auto r = std::make_unique<amgx::DevCsrSrc>();
+    auto r = std::make_unique<amgx::SpCsr>();
     if (!amgx::dev_spgemm(a, b, *r)) return 2;
     if (n_rows) *n_rows = r->n_rows;
     if (nnz) *nnz = r->nnz;
@@ -3709,18 +3709,19 @@ int amgx_galerkin(const amgx_matrix* PT, const amgx_matrix* A, const amgx_matrix
   try {
     if (!PT || !A || !P || !out) throw amgx::Err("amgx_galerkin: null argument");
     *out = nullptr;
-    for (const amgx_matrix* m : {PT, A, P}) if (m->br != 1 || m->bc != 1) return 2;
-    if (PT->n_cols != A->n_rows || A->n_cols != P->n_rows) throw amgx::Err("amgx_galerkin: dimension mismatch");
-    amgx::DevCsrSrc pta;
+    if (PT->n_cols != A->n_rows || A->n_cols != P->n_rows || PT->bc != A->br || A->bc != P->br) throw amgx::Err("amgx_galerkin: dimension mismatch");
+    for (const amgx_matrix* m : {PT, A, P}) if (m->br < 1 || m->bc < 1 || m->br * m->bc > 36) return 2;
+    if (PT->br * P->bc > 36) return 2;
+    amgx::SpCsr pta;
     {
-      amgx::DevCsrSrc pt, a;
+      amgx::SpCsr pt, a;
       pt.upload(*PT);
       a.upload(*A);
       if (!amgx::dev_spgemm(pt, a, pta)) return 2;
     }
-    amgx::DevCsrSrc p;
+    amgx::SpCsr p;
     p.upload(*P);
-    auto r = std::make_unique<amgx::DevCsrSrc>();
+    auto r = std::make_unique<amgx::SpCsr>();
     if (!amgx::dev_spgemm(pta, p, *r)) return 2;
     if (n_rows) *n_rows = r->n_rows;
     if (nnz) *nnz = r->nnz;
@@ -3730,12 +3731,12 @@ int amgx_galerkin(const amgx_matrix* PT, const amgx_matrix* A, const amgx_matrix
 }
 
 int amgx_csr_result_fetch(amgx_csr_result res, int64_t* rowptr, int32_t* col, double* val) {
-  std::unique_ptr<amgx::DevCsrSrc> r(reinterpret_cast<amgx::DevCsrSrc*>(res));
+  std::unique_ptr<amgx::SpCsr> r(reinterpret_cast<amgx::SpCsr*>(res));
   try {
     if (!r) throw amgx::Err("amgx_csr_result_fetch: null result");
     if (rowptr) HIPCHK(hipMemcpy(rowptr, r->rowptr.p, (size_t)(r->n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
     if (col && r->nnz) HIPCHK(hipMemcpy(col, r->col.p, (size_t)r->nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (val && r->nnz) HIPCHK(hipMemcpy(val, r->val.p, (size_t)r->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (val && r->nnz) HIPCHK(hipMemcpy(val, r->val.p, (size_t)r->nnz * r->br * r->bc * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
   } catch (const std::exception& e) { g_create_err = e.what(); return 1; }
 }

@@ -125,19 +125,18 @@ MatView view_of(const BCSR& M) { return MatView{M.n_rows, M.n_cols, M.br, M.bc, 
 
 BCSR restrict_matrix(const BCSR& PT, const BCSR& A, const BCSR& P) {
   const GalerkinHook& hk = galerkin_hook();
-  const bool scalar = PT.bsz() == 1 && A.bsz() == 1 && P.bsz() == 1;
-  if (hk.run && hk.fetch && scalar && A.n_rows >= hk.min_rows) {
+  if (hk.run && hk.fetch && A.n_rows >= hk.min_rows) {
     const MatView vpt = view_of(PT), va = view_of(A), vp = view_of(P);
     void* res = nullptr;
     int64_t nr = 0, nnz = 0;
     const int rc = hk.run(&vpt, &va, &vp, &res, &nr, &nnz);
     if (rc == 0) {
       BCSR C;
-      C.n_rows = PT.n_rows; C.n_cols = P.n_cols; C.br = 1; C.bc = 1;
+      C.n_rows = PT.n_rows; C.n_cols = P.n_cols; C.br = PT.br; C.bc = P.bc;
       if (nr != C.n_rows) { hk.fetch(res, nullptr, nullptr, nullptr); throw Error("galerkin hook: result has the wrong number of rows"); }
       C.rowptr.resize(nr + 1);
       C.col.resize(nnz);
-      C.val.resize(nnz);
+      C.val.resize(nnz * C.bsz());
       if (hk.fetch(res, C.rowptr.data(), C.col.data(), C.val.data()) != 0) throw Error("galerkin hook: fetch failed");
       if (C.rowptr.back() != nnz) throw Error("galerkin hook: inconsistent result");
       return C;

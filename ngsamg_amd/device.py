@@ -435,18 +435,18 @@ class DeviceAMGMatrix:
 # byte model of SURVEY.md section 8d / BASELINE.md (algorithmic bytes per cycle)
 # ---------------------------------------------------------------------------------------------
 
-def _fetch_result(lib, res, n_rows, n_cols, nnz):
+def _fetch_result(lib, res, n_rows, n_cols, nnz, br=1, bc=1):
     rp = np.zeros(n_rows + 1, dtype=np.int64)
     col = np.zeros(max(1, nnz), dtype=np.int32)
-    val = np.zeros(max(1, nnz))
+    val = np.zeros(max(1, nnz) * br * bc)
     if lib.amgx_csr_result_fetch(res, _lib.ptr(rp, C.c_int64), _lib.ptr(col, C.c_int32), _lib.ptr(val, C.c_double)) != 0:
         raise NgsAMGError(lib.amgx_last_error(None).decode())
-    return Matrix(n_rows, n_cols, 1, 1, rp, col[:nnz], val[:nnz])
+    return Matrix(n_rows, n_cols, br, bc, rp, col[:nnz], val[:nnz * br * bc])
 
 
 def device_spmm(A, B):
-    """C = A B on the device (amgx_spgemm; scalar CSR, bit-identical to the host library's amgh_matmul).
-    None: the device library does not take this product (block matrices, a row with more than 8192 products)."""
+    """C = A B on the device (amgx_spgemm; (block-)CSR, bit-identical to the host library's amgh_matmul).
+    None: the device library does not take this product (result blocks beyond 6 x 6, a row with more than 8192 products)."""
     lib = _lib.hip()
     da, db = A.desc(_lib.amgx_matrix), B.desc(_lib.amgx_matrix)
     res, nr, nnz = C.c_void_p(), C.c_int64(), C.c_int64()
@@ -455,7 +455,7 @@ def device_spmm(A, B):
         return None
     if rc != 0:
         raise NgsAMGError(lib.amgx_last_error(None).decode())
-    return _fetch_result(lib, res, int(nr.value), B.n_cols, int(nnz.value))
+    return _fetch_result(lib, res, int(nr.value), B.n_cols, int(nnz.value), A.br, B.bc)
 
 
 def device_galerkin(PT, A, P):
@@ -468,7 +468,7 @@ def device_galerkin(PT, A, P):
         return None
     if rc != 0:
         raise NgsAMGError(lib.amgx_last_error(None).decode())
-    return _fetch_result(lib, res, int(nr.value), P.n_cols, int(nnz.value))
+    return _fetch_result(lib, res, int(nr.value), P.n_cols, int(nnz.value), PT.br, P.bc)
 
 
 def matrix_bytes(M):

@@ -374,7 +374,7 @@ def _bs(s):
     return int(getattr(s, "bs", 1))
 
 
-_DEVICE_SPMM_MIN_ROWS = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "100000"))
+_DEVICE_SPMM_MIN_ROWS = int(os.environ.get("NGSAMG_DEVICE_SETUP_MIN_ROWS", "20000"))
 
 
 def _spmm(A, B, br=1, bk=1, bc=1):
@@ -383,12 +383,14 @@ def _spmm(A, B, br=1, bk=1, bc=1):
     entry (36x fewer for the 6 x 6 levels; it was the largest single cost of the distributed elasticity setup)"""
     lib = _lib.host()
     MA, MB = _mat(A, br, bk), _mat(B, bk, bc)
-    if br == bk == bc == 1 and MA.n_rows >= _DEVICE_SPMM_MIN_ROWS and _lib.device_setup():
-        # scalar products of the big levels on the device (amgx_spgemm: the same bits as the host product)
+    if MA.n_rows >= _DEVICE_SPMM_MIN_ROWS and br * bc <= 36 and _lib.device_setup():
+        # products of the big levels on the device (amgx_spgemm: the same bits as the host product)
         from .device import device_spmm
         Cd = device_spmm(MA, MB)
         if Cd is not None:
-            return sp.csr_matrix((Cd.val, Cd.col, Cd.rowptr), shape=(MA.n_rows, MB.n_cols))
+            if br == 1 and bc == 1:
+                return sp.csr_matrix((Cd.val, Cd.col, Cd.rowptr), shape=(MA.n_rows, MB.n_cols))
+            return sp.bsr_matrix((np.asarray(Cd.val).reshape(-1, br, bc), Cd.col, Cd.rowptr), shape=(MA.n_rows * br, MB.n_cols * bc)).tocsr()
     da, db = MA.desc(), MB.desc()
     rp = np.zeros(MA.n_rows + 1, dtype=np.int64)
     _lib.hcheck(lib.amgh_matmul(C.byref(da), C.byref(db), _lib.ptr(rp, C.c_int64), None, None))
