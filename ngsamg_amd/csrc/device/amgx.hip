@@ -104,8 +104,9 @@ enum Fmt : int { FMT_CSRVEC = 0, FMT_SELL = 1, FMT_BSELL = 2, FMT_RB = 4 };     
 // gathered-vector access of the BSELL kernels (BSellMat::xmode); AMGX_BSELL_XMODE overrides (same arithmetic in every mode).
 // Same box, cfg 3 GS / cfg 5 GS / cfg 5 block-Jacobi applications per second (profiles/r04/gs_experiments.txt):
 //   0 (BS 8-byte loads) 281.9 / 160.6 / 193.1    1 (16-byte loads) 277.7 / 160.4 / 189.3    2 (one load + lane exchange) 246.2 / 149.9 / 189.3
+// another box: 0 270.4 / 158.5 / 194.1; column indices 2 / 3 / 4 steps ahead (3 / 5 / 4): 261.6 / 154.7 / 193.9, 267.1 / 157.2 / 186.6, 229.5 / 126.7 / 186.3
 static int bsell_xmode() {
-  static const int m = [] { const char* e = std::getenv("AMGX_BSELL_XMODE"); return e ? std::max(0, std::min(2, std::atoi(e))) : 0; }();
+  static const int m = [] { const char* e = std::getenv("AMGX_BSELL_XMODE"); return e ? std::max(0, std::min(5, std::atoi(e))) : 0; }();
   return m;
 }
 

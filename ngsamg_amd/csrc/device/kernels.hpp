@@ -456,7 +456,8 @@ struct BSellMat {
   const int64_t* slice_ptr;   // [n_slices+1] cumulative block steps
   const int32_t* col;         // [steps * RB]
   const double* val;          // [steps * BS * 64]
-  int xmode;                  // gathered-vector access: 0 = BS 8-byte loads per lane, 1 = 16-byte loads, 2 = one load + lane exchange
+  int xmode;                  // row product: 0 = plain loop, BS 8-byte gathers per lane, 1 = 16-byte gathers, 2 = one load + lane exchange,
+                              // 3 / 4 / 5 = column indices one batch of 2 / 4 / 3 steps ahead (bsell_row_dot_ahead)
 };
 
 #ifndef BSELL_UNROLL
@@ -506,6 +507,35 @@ __device__ __forceinline__ void bsell_block_step_shfl(const double* __restrict__
   if (BS & 1) acc += ld_nt(vk + (BS / 2) * (2 * WAVE) + lane) * xb[BS - 1];
 }
 
+// Row product of one BSELL slice with the column indices one batch AHEAD: the plain loop asks for a step's column index, waits,
+// asks for the gathered block and waits again (ISA of the round-4 kernel: s_waitcnt on the index loads before the gathers, vmcnt(0)
+// at the end of every iteration) -- two dependent memory round trips per iteration and nothing in flight across iterations.  Here
+// the indices of batch n + 1 are requested before the values and gathers of batch n, so an iteration waits for ONE round trip.
+// Same products in the same order.
+template <int BS, bool V2, int U>
+__device__ __forceinline__ double bsell_row_dot_ahead(const double* __restrict__ vb, const int32_t* __restrict__ cb, int w, int rbl, int lane,
+                                                      const double* x) {
+  constexpr int RB = WAVE / BS;
+  double acc = 0.0;
+  int cn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) cn[u] = u < w ? cb[u * RB + rbl] : 0;
+  int k = 0;
+  for (; k + U <= w; k += U) {
+    int cc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cc[u] = cn[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int kk = k + U + u; cn[u] = kk < w ? cb[kk * RB + rbl] : 0; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) bsell_block_step<BS, V2>(vb + (int64_t)(k + u) * (BS * WAVE), x + (int64_t)cc[u] * BS, lane, acc);
+  }
+#pragma unroll
+  for (int u = 0; u < U - 1; ++u)
+    if (k + u < w) bsell_block_step<BS, V2>(vb + (int64_t)(k + u) * (BS * WAVE), x + (int64_t)cn[u] * BS, lane, acc);
+  return acc;
+}
+
 template <int BS, int EP>
 __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int slice0, int n_slices, BSellMat M,
                                                            const double* __restrict__ x, double* y, EpArgs ep) {
@@ -538,7 +568,11 @@ __global__ __launch_bounds__(BLOCK) void bsell_spmv_kernel(int64_t n_rows, int s
   }
   double acc = 0.0;
   const bool x16 = M.xmode == 1 && (BS % 2) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;      // (wave-uniform)
-  if (M.xmode == 2) {
+  if (M.xmode >= 3) {
+    if (M.xmode == 3) acc = bsell_row_dot_ahead<BS, false, 2>(vb, cb, w, rbl, lane, x);
+    else if (M.xmode == 4) acc = bsell_row_dot_ahead<BS, false, 4>(vb, cb, w, rbl, lane, x);
+    else acc = bsell_row_dot_ahead<BS, false, 3>(vb, cb, w, rbl, lane, x);
+  } else if (M.xmode == 2) {
     const int xbase = lane - r;
     for (int k = 0; k < w; ++k) {
       const int c = cb[k * RB + rbl];
@@ -1069,7 +1103,11 @@ __global__ __launch_bounds__(BLOCK) void bgsb_sweep_kernel(int BB, int block0, c
       const double* __restrict__ vb = OFF.val + k0 * (BS * WAVE);
       const int32_t* __restrict__ cb = OFF.col + k0 * RB;
       double acc = 0.0;
-      if (OFF.xmode == 2) {
+      if (OFF.xmode >= 3) {
+        if (OFF.xmode == 3) acc = bsell_row_dot_ahead<BS, false, 2>(vb, cb, w, rbl, lane, xin);
+        else if (OFF.xmode == 4) acc = bsell_row_dot_ahead<BS, false, 4>(vb, cb, w, rbl, lane, xin);
+        else acc = bsell_row_dot_ahead<BS, false, 3>(vb, cb, w, rbl, lane, xin);
+      } else if (OFF.xmode == 2) {
         for (int k = 0; k < w; ++k) {
           const int c = cb[k * RB + rbl];
           bsell_block_step_shfl<BS>(vb + (int64_t)k * (BS * WAVE), xin + (int64_t)c * BS, lane, r, lane - r, acc);
