@@ -72,6 +72,45 @@ Graph strength_graph(const BCSR& A, const std::vector<uint8_t>& free, int dim, i
   return G;
 }
 
+// Numbering of the coarse vertices along a Z-order curve through the aggregates' centroids (experiment, NGSAMG_COARSE_ORDER=morton):
+// the agglomerator numbers aggregates in the order it forms them (roughly the fine numbering reversed, orphans appended), so on a
+// lexicographic grid 256 consecutive coarse rows span ~2.4 grid lines and their 52-entry stencils touch ~4000 distinct columns;
+// compact blocks of rows touch a third of that -- smaller gather footprints for every kernel of the coarse levels.
+static bool coarse_order_morton() {
+  static const bool on = [] { const char* e = std::getenv("NGSAMG_COARSE_ORDER"); return e && std::string(e) == "morton"; }();
+  return on;
+}
+static void renumber_morton(std::vector<int32_t>& agg, int64_t nc, const std::vector<double>& coords, int dim) {
+  const int64_t n = (int64_t)agg.size();
+  std::vector<double> cen((size_t)nc * dim, 0.0);
+  std::vector<int32_t> cnt(nc, 0);
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) { cnt[agg[i]]++; for (int d = 0; d < dim; d++) cen[(int64_t)agg[i] * dim + d] += coords[i * dim + d]; }
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int64_t I = 0; I < nc; I++) for (int d = 0; d < dim; d++) {
+    double& c = cen[I * dim + d];
+    c /= std::max(1, cnt[I]);
+    lo[d] = std::min(lo[d], c); hi[d] = std::max(hi[d], c);
+  }
+  const int bits = dim == 2 ? 30 : 20;
+  std::vector<std::pair<uint64_t, int32_t>> key(nc);
+#pragma omp parallel for schedule(static)
+  for (int64_t I = 0; I < nc; I++) {
+    uint64_t k = 0;
+    uint32_t q[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) {
+      const double w = hi[d] - lo[d];
+      const double t = w > 0 ? (cen[I * dim + d] - lo[d]) / w : 0.0;
+      q[d] = (uint32_t)std::min<double>((double)((1u << bits) - 1), std::max(0.0, t * (double)(1u << bits)));
+    }
+    for (int b = bits - 1; b >= 0; b--) for (int d = dim - 1; d >= 0; d--) k = (k << 1) | ((q[d] >> b) & 1u);
+    key[I] = {k, (int32_t)I};
+  }
+  std::sort(key.begin(), key.end());
+  std::vector<int32_t> perm(nc);
+  for (int64_t r = 0; r < nc; r++) perm[key[r].second] = (int32_t)r;
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = perm[agg[i]];
+}
+
 constexpr double ROBUST_SCALE_GAP = 16.0;
 
 // One pairwise matching round.  map[i] = new vertex id.  Returns the number of new vertices.
@@ -931,6 +970,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
                                   : aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
         lap("agglomeration");
         if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }
+        if (coarse_order_morton() && !cur_coords.empty() && !o.robust_soc) { renumber_morton(sagg, snc, cur_coords, dim); lap("coarse numbering"); }
         // robust_soc: what is left are vertices that must not be merged; a level that is barely smaller than its parent costs a
         // smoother and buys nothing (the coarsest-level inverse takes over)
         if (o.robust_soc && lev > 0 && (double)snc > 0.8 * (double)cur_free_n) { failed = substeps == 0; break; }
