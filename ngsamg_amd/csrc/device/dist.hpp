@@ -344,6 +344,10 @@ struct Dist {
   amgx_handle_t* view_tail = nullptr;
 
   int64_t n(int l) const { return top->lev[l].len(); }
+  // interior rows as the split launches see them: a level WITHOUT boundary rows (world size 1, or a rank whose piece touches no
+  // other) reports "everything", so that the last partial slice / chunk is not left to an extra boundary launch (5 launches of
+  // 4 ... 8 us per cycle at 108^3, profiles/r04/trace_dist_nv108_before.txt)
+  int64_t n_int_span(int l) const { return halo[l].n_int >= top->lev[l].n ? (int64_t)1 << 60 : halo[l].n_int; }
   int64_t next(int l) const { return top->lev[l].ext_len(); }
 };
 
@@ -537,11 +541,11 @@ struct DistCycle {
     for (int l = 0; l < k; ++l) {
       const int tk = c.exchange_begin(items(l, 0));
       if (M[0]->overlap)
-        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, Span{Handle::PART_INT, d->halo[l].n_int}); }
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, Span{Handle::PART_INT, d->n_int_span(l)}); }
       c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
-        d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+        d->top->pre_smooth_restrict(l, xl(d, i, l), d->bext[l].p, d->rl[l].p, bnext(d, l), true, M[0]->overlap ? Span{Handle::PART_BND, d->n_int_span(l)} : Span());
       }
     }
     gather_level_k();
@@ -549,13 +553,13 @@ struct DistCycle {
     int tk = -1;
     for (int l = k - 1; l >= 0; --l) {
       if (tk >= 0 && M[0]->overlap)
-        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, d->xext[l + 1].p, true, Span{Handle::PART_INT, d->halo[l].n_int}); }
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, d->xext[l + 1].p, true, Span{Handle::PART_INT, d->n_int_span(l)}); }
       const bool split = tk >= 0 && M[0]->overlap;
       if (tk >= 0) c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
         const double* xc = l + 1 < k ? d->xext[l + 1].p : d->xk_ext.p;
-        d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, xc, true, split ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+        d->top->post_smooth(l, xl(d, i, l), nullptr, d->rl[l].p, xc, true, split ? Span{Handle::PART_BND, d->n_int_span(l)} : Span());
       }
       tk = l > 0 ? c.exchange_begin(items(l, 1)) : -1;
     }
@@ -567,11 +571,11 @@ struct DistCycle {
     for (int l = 0; l < k; ++l) {
       const int tk = c.exchange_begin(items(l, 0));
       if (M[0]->overlap)
-        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, Span{Handle::PART_INT, d->halo[l].n_int}); }
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, Span{Handle::PART_INT, d->n_int_span(l)}); }
       c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
-        d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+        d->top->pre_smooth(d->top->lev[l], xl(d, i, l), d->bext[l].p, d->rl[l].p, false, M[0]->overlap ? Span{Handle::PART_BND, d->n_int_span(l)} : Span());
         d->top->transfer_f2c(l, d->rl[l].p, bnext(d, l));
       }
     }
@@ -585,11 +589,11 @@ struct DistCycle {
       }
       const int tk = c.exchange_begin(items(l, 2));
       if (M[0]->overlap)
-        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), Span{Handle::PART_INT, d->halo[l].n_int}); }
+        for (size_t i = 0; i < M.size(); ++i) { Dist* d = M[i]; d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), Span{Handle::PART_INT, d->n_int_span(l)}); }
       c.exchange_end(tk);
       for (size_t i = 0; i < M.size(); ++i) {
         Dist* d = M[i];
-        d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), M[0]->overlap ? Span{Handle::PART_BND, d->halo[l].n_int} : Span());
+        d->top->jacobi_fused(d->top->lev[l], d->text[l].p, d->bext[l].p, xl(d, i, l), M[0]->overlap ? Span{Handle::PART_BND, d->n_int_span(l)} : Span());
       }
     }
   }
@@ -959,9 +963,9 @@ struct DistKrylov {
     for (size_t i = 0; i < M.size(); ++i) it.push_back({&M[i]->halo[0], vext[i].p});
     const int tk = c.exchange_begin(it);
     const bool ov = M[0]->overlap;
-    if (ov) for (size_t i = 0; i < M.size(); ++i) rows(i, Handle::Span{Handle::PART_INT, M[i]->halo[0].n_int});
+    if (ov) for (size_t i = 0; i < M.size(); ++i) rows(i, Handle::Span{Handle::PART_INT, M[i]->n_int_span(0)});
     c.exchange_end(tk);
-    for (size_t i = 0; i < M.size(); ++i) rows(i, ov ? Handle::Span{Handle::PART_BND, M[i]->halo[0].n_int} : Handle::Span());
+    for (size_t i = 0; i < M.size(); ++i) rows(i, ov ? Handle::Span{Handle::PART_BND, M[i]->n_int_span(0)} : Handle::Span());
   }
   void precond(bool use_pre) {                   // w = C d
     if (!use_pre) { for (size_t i = 0; i < M.size(); ++i) M[i]->top->copy(w[i].p, d(i), M[i]->n(0)); return; }

@@ -429,3 +429,19 @@ def test_galerkin_hook_protocol():
     finally:
         lib.amgh_set_galerkin_hook(None, None, 0)
         _lib._device_setup = saved
+
+
+def test_device_setup_without_a_gpu_keeps_the_host_product():
+    """Hierarchy() asks for the device Galerkin product on every setup; without a GPU that is a no-op, insisting on it raises"""
+    import torch
+    from ngsamg_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the hook is installed (tests/test_gpu_spgemm.py)")
+    saved = _lib._device_setup
+    try:
+        _lib._device_setup = None
+        assert _lib.device_setup() is False
+        with pytest.raises(NgsAMGError, match="no HIP device"):
+            _lib.device_setup(True)
+    finally:
+        _lib._device_setup = saved
