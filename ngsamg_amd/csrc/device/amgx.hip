@@ -1200,6 +1200,7 @@ struct Handle {
   std::vector<GraphKey> graph_age;      // capture order
   // staging for host-pointer calls
   DevBuf<double> stage[3];
+  DevBuf<double> kr_ws[6];              // work vectors of amgx_pcg / amgx_gmres (krylov.hpp), kept between solves
   DevBuf<double> stage_raw[3];          // host vectors of permuted levels: raw copy before / after the renumbering
   // Gauss-Seidel levels are stored in colour-major numbering (see LevelPerm in create()); perm[l][new] = old row of the
   // caller's numbering, empty = identity.  Every C-ABI entry point translates its vectors (struct Staged).

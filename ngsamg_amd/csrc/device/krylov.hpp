@@ -204,6 +204,15 @@ struct Krylov {
     HIPCHK(hipStreamSynchronize(h.stream));
   }
   int grid() const { return Handle::grid_for(n); }
+  // work vectors live in the handle (grow-only) and keep their addresses from solve to solve: the cycle's graph is keyed on the
+  // (right-hand side, result) pointers, so a solver that allocated per call paid a fresh capture + instantiation -- and the
+  // hipMalloc / hipFree of its vectors (GMRES(30) at cfg 2: 2.6 GB) -- on every solve
+  struct WsBuf { double* p; };
+  WsBuf ws(int slot, size_t count) {
+    DevBuf<double>& b = h.kr_ws[slot];
+    if (b.n < count) b.alloc(count);
+    return WsBuf{b.p};
+  }
 
   // x = b - A x style helpers through the handle's SpMV kernels
   void precond(const double* r, double* z, bool use_pre) {
@@ -214,8 +223,7 @@ struct Krylov {
   // preconditioned CG (NGSolve CGSolver as the reference's drivers use it: err_k = sqrt(|<C r_k, r_k>|), stop at
   // err_k <= tol * err_0; reference tests/h1/amg_utils.py:337-363).  x holds the initial guess.
   int pcg(const double* b, double* x, double tol, int maxit, bool use_pre, double* errs) {
-    DevBuf<double> d, w, s;
-    d.alloc(n); w.alloc(n); s.alloc(n);
+    WsBuf d = ws(0, n), w = ws(1, n), s = ws(2, n);
     constexpr int SAS = 2;                                   // scalar slots: 0 / 1 = <w, d> of the last two iterations, 2 = <s, A s>
     h.residual(h.lev[0].A, x, b, d.p);                       // d = b - A x
     precond(d.p, w.p, use_pre);
@@ -250,8 +258,7 @@ struct Krylov {
   // the recurrence of pcg() (alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1}) equals <C r, r> / <p, A p>); the rounding
   // differs, histories agree to ~1e-6 (tests/test_gpu_krylov.py).  err_k = sqrt(|<C r_k, r_k>|) as in pcg().
   int pcg_sr(const double* b, double* x, double tol, int maxit, double* errs) {
-    DevBuf<double> r, u, w, p, s;
-    r.alloc(n); u.alloc(n); w.alloc(n); p.alloc(n); s.alloc(n);
+    WsBuf r = ws(0, n), u = ws(1, n), w = ws(2, n), p = ws(3, n), s = ws(4, n);
     h.zero(p.p, n); h.zero(s.p, n);
     const double one = 1.0;
     HIPCHK(hipMemcpyAsync(sc.p + SR_FIRST, &one, sizeof(double), hipMemcpyHostToDevice, h.stream));
@@ -290,8 +297,9 @@ struct Krylov {
     // (the basis lives in HBM: (restart + 1) vectors; multi_dot handles up to 48 of them per pass)
     if (restart > 40) throw Err("amgx_gmres: restart lengths above 40 are not supported (got " + std::to_string(restart) + ")");
     const int m = std::max(1, restart);
-    DevBuf<double> V, w, t, hdev;
-    V.alloc((size_t)(m + 1) * n); w.alloc(n); t.alloc(n); hdev.alloc(64);
+    WsBuf V = ws(5, (size_t)(m + 1) * n), w = ws(1, n), t = ws(2, n);
+    DevBuf<double> hdev;
+    hdev.alloc(64);
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), hcol(m + 1), hc2(m + 1), y(m);
     int it = 0;
     double err0 = -1.0;
