@@ -1107,6 +1107,7 @@ static bool build_sell_lw_windowed(int64_t n, int64_t n_cols, const int64_t* row
   const int win = SELL_WIN;
   const int64_t nnz = rowptr[n];
   const int64_t nw = (n + win - 1) / win;
+  SetupClock clk;
   std::vector<int32_t> cnt((size_t)nw + 1, 0);
   RawVec<int32_t> lcol;
   lcol.resize((size_t)std::max<int64_t>(1, nnz));
@@ -1139,6 +1140,7 @@ static bool build_sell_lw_windowed(int64_t n, int64_t n_cols, const int64_t* row
       lists[q] = u;
     }
   }, 4);
+  clk.lap("  lw-win: window lists + local columns");
   int64_t overs = 0;
   for (int64_t v : n_over) overs += v;
   if (overs * 20 > nw && !tcap) return false;
@@ -1148,8 +1150,10 @@ static bool build_sell_lw_windowed(int64_t n, int64_t n_cols, const int64_t* row
   amgx_matrix L{};
   L.n_rows = n; L.n_cols = n_cols; L.br = L.bc = 1;
   L.rowptr = rowptr; L.col = lcol.data(); L.val = val;
+  clk.lap("  lw-win: list copy");
   HostSell S;
   build_sell(L, rows.data(), n, false, 1, S, false, &no16);
+  clk.lap("  lw-win: host SELL builder");
   D.n_rows = n; D.n_cols = n_cols; D.br = D.bc = 1; D.nnz = nnz;
   D.fmt = FMT_SELL; D.lanes = 1;
   D.n_slices = (int)(S.slice_ptr.size() - 1);
@@ -1160,6 +1164,7 @@ static bool build_sell_lw_windowed(int64_t n, int64_t n_cols, const int64_t* row
   D.sell.rowloc.upload(rowloc);
   d_cptr.upload(cnt);
   d_ccol.upload(ccol);
+  clk.lap("  lw-win: upload");
   return true;
 }
 
@@ -3253,11 +3258,36 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
           // (rank-partitioned levels too: the window of an interior chunk holds owned columns only, ghost columns are just columns)
           if (l == 0 || avgA < 24.0 || s.A.n_rows < lw_min_rows || std::getenv("AMGX_NO_LW") ||
               s.P.br != 1 || s.P.bc != 1 || s.P.rowptr[s.P.n_rows] >= (int64_t)2147483647 || std::getenv("AMGX_NO_FUSED_RESTRICT")) return false;
-          std::unique_ptr<double[]> sv(new double[(size_t)std::max<int64_t>(1, nnzA)]);
-          par_for(nnzA, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
           // two lanes per row (256-row chunks); levels whose 256-row chunks touch too many columns: four lanes (128-row chunks)
           int G = 0;
-          for (int g : {2, 4}) if (build_sell_lw(s.A, sv.get(), g, L.ApreLW, L.lw_cptr, L.lw_ccol)) { G = g; break; } else L.ApreLW = DevMatrix();
+          std::unique_ptr<double[]> sv;
+          auto host_lw = [&](int g, DevMatrix& M, DevBuf<int32_t>& cp, DevBuf<int32_t>& cc) {
+            if (!sv) {
+              sv.reset(new double[(size_t)std::max<int64_t>(1, nnzA)]);
+              par_for(nnzA, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; ++k) sv[k] = s.A.val[k] * (s.omega * s.dinv[s.A.col[k]]); }, 1 << 16);
+            }
+            return build_sell_lw(s.A, sv.get(), g, M, cp, cc);
+          };
+          // (device: window lists by a bitmap in LDS, devbuild.hpp dev_build_lw; AMGX_HOST_LW=1 keeps the host builder)
+          const bool dev_lw = dev_images && !std::getenv("AMGX_HOST_LW") && !std::getenv("AMGX_HOST_IMAGES");
+          for (int g : {2, 4}) {
+            bool ok = false;
+            if (dev_lw) {
+              int64_t cap = LW_CAP;
+              const char* tcap = std::getenv("AMGX_LW_TEST_CAP");
+              if (tcap) cap = std::min<int64_t>(cap, std::atoll(tcap));
+              ok = dev_build_lw(csrA, false, g, cap, tcap != nullptr, L.dinv.p, s.omega, L.ApreLW, L.lw_cptr, L.lw_ccol);
+              if (ok && verify_images) {
+                DevMatrix H; DevBuf<int32_t> hp, hc;
+                if (!host_lw(g, H, hp, hc)) throw Err("AMGX_VERIFY_IMAGES: A' (local window): the host builder declines what the device builder forms");
+                verify_same_lw(L.ApreLW, L.lw_cptr, L.lw_ccol, H, hp, hc, "A' (local window)");
+              }
+              if (!ok) { L.ApreLW = DevMatrix(); L.lw_cptr.release(); L.lw_ccol.release(); }
+            }
+            if (!ok) ok = host_lw(g, L.ApreLW, L.lw_cptr, L.lw_ccol);
+            if (ok) { G = g; break; }
+            L.ApreLW = DevMatrix();
+          }
           if (!G) return false;
           L.fused_block = 512;
           build_restrict(s.P, L.RF, 512 / G, 4 * 512, 512);
@@ -3373,10 +3403,29 @@ static Handle* create(const amgx_hierarchy_desc* d, int dense_first = 1) {
                 DevCsrSrc csrP, csrQ;
                 csrP.upload(s.P);
                 if (dev_fold_prolongation(csrA, csrP, L.dinv.p, s.omega, csrQ) && dev_upload_matrix(csrQ, L.Q, false, qpad, SELL_WIN, nullptr)) {
-                  if (qlw_wanted(s.A.n_rows)) {
+                  bool qlw_done = false;
+                  if (qlw_wanted(s.A.n_rows) && !std::getenv("AMGX_HOST_LW")) {
+                    int64_t cap = QW_CAP;
+                    const char* tcap = std::getenv("AMGX_LW_TEST_CAP");
+                    if (tcap) cap = std::min<int64_t>(cap, std::max<int64_t>(8, std::atoll(tcap) / 4));
+                    qlw_done = dev_build_lw(csrQ, true, 1, cap, tcap != nullptr, nullptr, 0.0, L.QLW, L.qlw_cptr, L.qlw_ccol);
+                    if (!qlw_done) { L.QLW = DevMatrix(); L.qlw_cptr.release(); L.qlw_ccol.release(); }
+                    else if (verify_images) {
+                      std::vector<int64_t> rp = db_download(csrQ.rowptr, (size_t)s.A.n_rows + 1);
+                      std::vector<int32_t> cc = db_download(csrQ.col, (size_t)std::max<int64_t>(1, csrQ.nnz));
+                      std::vector<double> vv = db_download(csrQ.val, (size_t)std::max<int64_t>(1, csrQ.nnz));
+                      DevMatrix H; DevBuf<int32_t> hp, hc;
+                      if (!build_sell_lw_windowed(s.A.n_rows, csrQ.n_cols, rp.data(), cc.data(), vv.data(), H, hp, hc))
+                        throw Err("AMGX_VERIFY_IMAGES: Q (local window): the host builder declines what the device builder forms");
+                      verify_same_lw(L.QLW, L.qlw_cptr, L.qlw_ccol, H, hp, hc, "Q (local window)");
+                    }
+                  }
+                  if (qlw_wanted(s.A.n_rows) && !qlw_done) {
+                    SetupClock qclk;
                     std::vector<int64_t> rp = db_download(csrQ.rowptr, (size_t)s.A.n_rows + 1);
                     std::vector<int32_t> cc = db_download(csrQ.col, (size_t)std::max<int64_t>(1, csrQ.nnz));
                     std::vector<double> vv = db_download(csrQ.val, (size_t)std::max<int64_t>(1, csrQ.nnz));
+                    qclk.lap("  lw-win: download of Q", l);
                     if (!build_sell_lw_windowed(s.A.n_rows, csrQ.n_cols, rp.data(), cc.data(), vv.data(), L.QLW, L.qlw_cptr, L.qlw_ccol)) L.QLW = DevMatrix();
                   }
                   if (verify_images) {

@@ -78,6 +78,8 @@ struct DbFill {
   const int64_t* sp;
   int32_t* col32; uint16_t* col16; int32_t* cbase; double* out;
   uint8_t* comp; unsigned long long* counters;  // [0] slices in the 16-bit form, [1] bytes one product streams
+  const int32_t* vcol;                          // (local-window images: col = window-local index) the global column colscale is read at
+  const uint8_t* no16;                          // per row: slices holding such a row keep the 32-bit encoding (build_sell's no16)
 };
 
 // one wave per slice, G lanes per list entry: build_sell's fill pass
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
   const int64_t rk = a.rows ? r : q;
   const int64_t rr = a.rowrel ? rk : 0;
   const int32_t padcol = (r >= 0 && len) ? a.col[rb] : 0;
-  bool comp = true;
+  bool comp = !(a.no16 && r >= 0 && a.no16[r]);
   for (int j = 0; j < w; ++j) {
     const int e = G == 1 ? j : 2 * ((j >> 1) * G + (l % G)) + (j & 1);      // (lane, column) -> entry of the lane's row
     const bool has = e < len;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(DB_BLOCK) void db_fill_kernel(DbFill a) {
       const int64_t ks = rb + se;
       c = a.col[ks];
       v = a.val[ks];
-      if (a.colscale) v = v * (a.omega * a.colscale[c]);
+      if (a.colscale) v = v * (a.omega * a.colscale[a.vcol ? (int64_t)a.vcol[ks] : c]);
       if (a.wdiag && e == 0 && r < a.wdiag_rows) v = a.omega * a.wdiag[r];
     }
     long long mn = has ? (long long)(c - (a.rowrel ? r : 0)) : LLONG_MAX;
@@ -432,7 +434,8 @@ static int64_t dev_slice_offsets(const DevCsrSrc& A, const int32_t* d_rows, int6
 // build_sell + upload_sell for a matrix on the device: the image of the list `d_rows` [m] (null: natural order) with G lanes per
 // row; sp / stored = its slice offsets (dev_slice_offsets), consumed.  stream_bytes as HostSell::stream_bytes.
 static void dev_build_sell(const DevCsrSrc& A, const int32_t* d_rows, int64_t m, int G, bool rowrel, bool diag_first, const double* d_colscale,
-                           double omega, const double* d_wdiag, DevBuf<int64_t>& sp, int64_t stored, DevMatrix::Sell& S, int64_t* stream_bytes) {
+                           double omega, const double* d_wdiag, DevBuf<int64_t>& sp, int64_t stored, DevMatrix::Sell& S, int64_t* stream_bytes,
+                           const int32_t* d_col_stored = nullptr, const uint8_t* d_no16 = nullptr) {
   const int R = WAVE / G;
   const int64_t ns = (m + R - 1) / R;
   S.col32.alloc((size_t)std::max<int64_t>(1, stored));
@@ -445,8 +448,10 @@ static void dev_build_sell(const DevCsrSrc& A, const int32_t* d_rows, int64_t m,
   DevBuf<unsigned long long> counters;
   counters.alloc(2);
   HIPCHK(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
-  DbFill f{m, A.n_cols, ns, d_rows, G, rowrel ? 1 : 0, diag_first ? 1 : 0, A.rowptr.p, A.col.p, A.val.p,
-           d_colscale, omega, d_wdiag, A.n_rows, sp.p, S.col32.p, S.col16.p, S.cbase.p, S.val.p, comp.p, counters.p};
+  // (d_col_stored: the image stores these columns -- window-local indices -- while A.col stays the column of the value scaling)
+  DbFill f{m, A.n_cols, ns, d_rows, G, rowrel ? 1 : 0, diag_first ? 1 : 0, A.rowptr.p, d_col_stored ? d_col_stored : A.col.p, A.val.p,
+           d_colscale, omega, d_wdiag, A.n_rows, sp.p, S.col32.p, S.col16.p, S.cbase.p, S.val.p, comp.p, counters.p,
+           d_col_stored ? A.col.p : nullptr, d_no16};
   if (ns > 0) {
     hipLaunchKernelGGL(db_fill_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(DB_BLOCK), 0, 0, f);
     HIPCHK(hipGetLastError());
@@ -531,6 +536,169 @@ static bool dev_fold_prolongation(const DevCsrSrc& A, const DevCsrSrc& P, const 
   Q.val.alloc((size_t)std::max<int64_t>(1, nnz));
   hipLaunchKernelGGL((db_fold_kernel<true>), dim3(grid), dim3(BLOCK), 0, 0, a, Q.rowptr.p, Q.col.p, Q.val.p, over.p);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  return true;
+}
+
+// ---- local-window images (build_sell_lw, build_sell_lw_windowed) on the device --------------------------------------------
+// Per unit of U consecutive rows (a chunk of 512 / G rows, or a window of SELL_WIN rows): the sorted list of its distinct columns
+// and, per entry, the index of its column in that list.  The host sorts the unit's columns; here a workgroup marks them in a
+// bitmap over [min column, max column] in LDS and ranks every column by the set bits below it -- the same list, the same
+// indices.  A unit with more than `cap` distinct columns keeps its global columns and flags its rows (no16), as on the host; a
+// unit whose column RANGE does not fit the bitmap makes the builder decline the image (the host builder takes over).
+constexpr int DB_LW_BITS = 1 << 19;
+constexpr int DB_LW_WORDS = DB_LW_BITS / 32;
+struct DbLw {
+  int64_t n; int U, cap;
+  const int64_t* rowptr; const int32_t* col;
+  int32_t* lcol; uint8_t* no16; int32_t* cnt; int32_t* lists;      // cnt [units + 1], lists [units * cap]
+  unsigned long long* counters;                                     // [0] units beyond cap, [1] units the bitmap cannot hold
+};
+__global__ __launch_bounds__(512) void db_lw_list_kernel(DbLw a) {
+  extern __shared__ unsigned char db_lw_sh[];               // bitmap 64 KB | prefix counts 32 KB | reduction scratch 4 KB
+  uint32_t* bits = reinterpret_cast<uint32_t*>(db_lw_sh);
+  uint16_t* pre = reinterpret_cast<uint16_t*>(db_lw_sh + (size_t)DB_LW_WORDS * 4);
+  int* red = reinterpret_cast<int*>(db_lw_sh + (size_t)DB_LW_WORDS * 6);
+  const int t = threadIdx.x;
+  const int64_t u = blockIdx.x;
+  const int64_t r0 = u * a.U, r1 = min(a.n, r0 + (int64_t)a.U);
+  const int64_t e0 = a.rowptr[r0], e1 = a.rowptr[r1];
+  if (t == 0) a.cnt[u + 1] = 0;
+  if (e1 == e0) return;
+  int mn = INT32_MAX, mx = -1;
+  for (int64_t k = e0 + t; k < e1; k += 512) { const int c = a.col[k]; mn = min(mn, c); mx = max(mx, c); }
+  red[t] = mn; red[512 + t] = mx;
+  __syncthreads();
+  for (int o = 256; o > 0; o >>= 1) {
+    if (t < o) { red[t] = min(red[t], red[t + o]); red[512 + t] = max(red[512 + t], red[512 + t + o]); }
+    __syncthreads();
+  }
+  const int cmin = red[0], cmax = red[512];
+  __syncthreads();
+  const int64_t range = (int64_t)cmax - cmin + 1;
+  if (range > DB_LW_BITS) { if (t == 0) atomicAdd(a.counters + 1, 1ull); return; }
+  const int nw = (int)((range + 31) >> 5);
+  for (int w = t; w < nw; w += 512) bits[w] = 0u;
+  __syncthreads();
+  for (int64_t k = e0 + t; k < e1; k += 512) { const int d = a.col[k] - cmin; atomicOr(&bits[d >> 5], 1u << (d & 31)); }
+  __syncthreads();
+  const int per = (nw + 511) / 512;
+  const int w0 = min(nw, t * per), w1 = min(nw, w0 + per);
+  int sum = 0;
+  for (int w = w0; w < w1; ++w) sum += __popc(bits[w]);
+  red[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 512; o <<= 1) {                      // inclusive scan
+    const int x = t >= o ? red[t - o] : 0;
+    __syncthreads();
+    red[t] += x;
+    __syncthreads();
+  }
+  const int total = red[511];
+  const int off = red[t] - sum;
+  if (total > a.cap) {
+    for (int64_t r = r0 + t; r < r1; r += 512) a.no16[r] = 1;
+    for (int64_t k = e0 + t; k < e1; k += 512) a.lcol[k] = a.col[k];
+    if (t == 0) atomicAdd(a.counters + 0, 1ull);
+    return;
+  }
+  int run = off;
+  for (int w = w0; w < w1; ++w) { pre[w] = (uint16_t)run; run += __popc(bits[w]); }
+  __syncthreads();
+  for (int64_t k = e0 + t; k < e1; k += 512) {
+    const int d = a.col[k] - cmin, w = d >> 5;
+    a.lcol[k] = (int32_t)pre[w] + __popc(bits[w] & ((1u << (d & 31)) - 1u));
+  }
+  int32_t* __restrict__ out = a.lists + u * (int64_t)a.cap;
+  for (int w = w0; w < w1; ++w) {
+    uint32_t b = bits[w];
+    int idx = pre[w];
+    while (b) { const int bit = __ffs((int)b) - 1; out[idx++] = cmin + w * 32 + bit; b &= b - 1u; }
+  }
+  if (t == 0) a.cnt[u + 1] = total;
+}
+// in-place inclusive sum of v[1..n] (v[0] stays), 32-bit (db_scan_kernel's shape)
+__global__ __launch_bounds__(1024) void db_scan32_kernel(int64_t n, int32_t* __restrict__ v) {
+  __shared__ int64_t part[1024];
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024;
+  const int64_t a = 1 + (int64_t)t * chunk, b = min(n + 1, a + chunk);
+  int64_t s = 0;
+  for (int64_t i = a; i < b; ++i) s += v[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int64_t x = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  int64_t run = t ? part[t - 1] : 0;
+  for (int64_t i = a; i < b; ++i) { run += v[i]; v[i] = (int32_t)run; }
+}
+__global__ __launch_bounds__(256) void db_lw_compact_kernel(int cap, const int32_t* __restrict__ cptr, const int32_t* __restrict__ lists,
+                                                            int32_t* __restrict__ ccol) {
+  const int64_t u = blockIdx.x;
+  const int c0 = cptr[u], c1 = cptr[u + 1];
+  for (int k = threadIdx.x; k < c1 - c0; k += 256) ccol[c0 + k] = lists[u * (int64_t)cap + k];
+}
+
+// build_sell_lw (windowed = false: natural row order, G lanes per row, units of 512 / G rows, values scaled by omega * colscale[column])
+// and build_sell_lw_windowed (windowed = true: G = 1, rows of every SELL_WIN window by decreasing length) for a CSR matrix on
+// the device.  false: nothing built (too many units beyond `cap`, or a unit the bitmap cannot hold) -- the host builder decides.
+static bool dev_build_lw(const DevCsrSrc& A, bool windowed, int G, int64_t cap, bool test_cap, const double* d_colscale, double omega, DevMatrix& D,
+                         DevBuf<int32_t>& d_cptr, DevBuf<int32_t>& d_ccol) {
+  const int64_t n = A.n_rows, nnz = A.nnz;
+  if (n <= 0 || nnz <= 0 || cap > 65535) return false;
+  const int U = windowed ? SELL_WIN : 512 / G;
+  const int64_t nu = (n + U - 1) / U;
+  if (nu > 0x7fffffffLL || nu * cap > ((int64_t)1 << 33)) return false;
+  DevBuf<int32_t> lcol, lists, cnt;
+  DevBuf<uint8_t> no16;
+  DevBuf<unsigned long long> counters;
+  lcol.alloc((size_t)nnz); lists.alloc((size_t)(nu * cap)); cnt.alloc((size_t)nu + 1); no16.alloc((size_t)n); counters.alloc(2);
+  HIPCHK(hipMemset(no16.p, 0, (size_t)n));
+  HIPCHK(hipMemset(cnt.p, 0, (size_t)(nu + 1) * sizeof(int32_t)));
+  HIPCHK(hipMemset(counters.p, 0, 2 * sizeof(unsigned long long)));
+  DbLw a{n, U, (int)cap, A.rowptr.p, A.col.p, lcol.p, no16.p, cnt.p, lists.p, counters.p};
+  constexpr size_t lw_lds = (size_t)DB_LW_WORDS * 6 + 1024 * sizeof(int);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&db_lw_list_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw_lds));
+  hipLaunchKernelGGL(db_lw_list_kernel, dim3((unsigned)nu), dim3(512), lw_lds, 0, a);
+  HIPCHK(hipGetLastError());
+  unsigned long long hc[2];
+  HIPCHK(hipMemcpy(hc, counters.p, sizeof(hc), hipMemcpyDeviceToHost));
+  if (hc[1]) return false;
+  if ((int64_t)hc[0] * 20 > nu && !test_cap) return false;           // (more than 5 % of the units without a window)
+  hipLaunchKernelGGL(db_scan32_kernel, dim3(1), dim3(1024), 0, 0, nu, cnt.p);
+  HIPCHK(hipGetLastError());
+  int32_t total = 0;
+  HIPCHK(hipMemcpy(&total, cnt.p + nu, sizeof(int32_t), hipMemcpyDeviceToHost));
+  DevBuf<int32_t> ccol;
+  ccol.alloc((size_t)std::max<int32_t>(1, total));
+  if (total == 0) HIPCHK(hipMemset(ccol.p, 0, sizeof(int32_t)));
+  hipLaunchKernelGGL(db_lw_compact_kernel, dim3((unsigned)nu), dim3(256), 0, 0, (int)cap, cnt.p, lists.p, ccol.p);
+  HIPCHK(hipGetLastError());
+  lists.release();
+  DevBuf<int32_t> rows;
+  DevBuf<uint16_t> rowloc;
+  if (windowed) {
+    rows.alloc((size_t)n); rowloc.alloc((size_t)n);
+    hipLaunchKernelGGL((db_window_sort_kernel<SELL_WIN>), dim3((unsigned)nu), dim3(SELL_WIN), 0, 0, n, A.rowptr.p, rows.p, rowloc.p);
+    HIPCHK(hipGetLastError());
+  }
+  DevBuf<int64_t> sp;
+  const int64_t stored = dev_slice_offsets(A, windowed ? rows.p : nullptr, n, sp, G);
+  const int64_t ns = (n + WAVE / G - 1) / (WAVE / G);
+  int64_t bytes = 0;
+  dev_build_sell(A, windowed ? rows.p : nullptr, n, G, false, false, d_colscale, omega, nullptr, sp, stored, D.sell, &bytes, lcol.p, no16.p);
+  D.n_rows = n; D.n_cols = A.n_cols; D.br = D.bc = 1; D.nnz = nnz;
+  D.fmt = FMT_SELL; D.lanes = G;
+  D.n_slices = (int)ns;
+  D.stored = stored;
+  D.stream_bytes = bytes + 4 * (int64_t)std::max<int32_t>(1, total) + 4 * (nu + 1) + (windowed ? 2 * n : 0);
+  if (windowed) { D.sell.win = SELL_WIN; D.sell.rowloc = std::move(rowloc); }
+  d_cptr = std::move(cnt);
+  d_ccol = std::move(ccol);
   HIPCHK(hipDeviceSynchronize());
   return true;
 }
@@ -665,6 +833,20 @@ static void verify_same_image(const DevMatrix& a, const DevMatrix& b, const char
     throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": CSR images differ in the pattern");
   const auto vx = db_download(a.val, a.val.n), vy = db_download(b.val, b.val.n);
   if (std::memcmp(vx.data(), vy.data(), vx.size() * sizeof(double)) != 0) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": CSR images differ in the values");
+}
+
+// local-window images: the SELL image, the unit offsets and the column lists
+static void verify_same_lw(const DevMatrix& a, const DevBuf<int32_t>& ap, const DevBuf<int32_t>& ac, const DevMatrix& b, const DevBuf<int32_t>& bp,
+                           const DevBuf<int32_t>& bc, const char* what) {
+  verify_same_image(a, b, what);
+  if (a.sell.win != b.sell.win) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": window sizes differ");
+  if (a.sell.win && db_download(a.sell.rowloc, (size_t)a.n_rows) != db_download(b.sell.rowloc, (size_t)b.n_rows))
+    throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": row orders of the windows differ");
+  if (ap.n != bp.n || db_download(ap, ap.n) != db_download(bp, bp.n)) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": unit offsets differ");
+  const auto pa = db_download(ap, ap.n);
+  const size_t used = pa.empty() ? 0 : (size_t)pa.back();
+  if (ac.n < used || bc.n < used) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": column lists are too short");
+  if (db_download(ac, used) != db_download(bc, used)) throw Err(std::string("AMGX_VERIFY_IMAGES: ") + what + ": column lists differ");
 }
 
 }  // namespace amgx

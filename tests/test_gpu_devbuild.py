@@ -124,3 +124,22 @@ def test_device_built_images_on_rank_partitioned_levels(sm):
     ref = Oracle(glv, sm_type=oracle_sm_types(amg), bgs=oracle_bgs(amg, glv)).apply(np.concatenate(bh))
     got = np.concatenate([x.cpu().numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("shape,cap", [((26, 25, 24), None), ((40, 38, 30), None), ((40, 38, 30), 1500), ((40, 38, 30), 600)])
+def test_device_built_local_window_images_equal_host_built_ones(shape, cap):
+    """dev_build_lw (window lists by a bitmap in LDS) against build_sell_lw / build_sell_lw_windowed: SELL arrays, unit offsets, column
+    lists and the row order of the windows, with chunks beyond the capacity (AMGX_LW_TEST_CAP) keeping their global columns"""
+    p, H = poisson_case(shape, "right|top", 20)
+    e = dict(AMGX_DEV_IMAGES_MIN_ROWS=0, AMGX_LW_MIN_ROWS=300, AMGX_NO_DENSE_TAIL=1)
+    if cap:
+        e["AMGX_LW_TEST_CAP"] = cap
+    xv, dv = _apply(H, p, "jacobi", AMGX_VERIFY_IMAGES=1, **e)       # raises if any array of any image differs
+    used = [l for l in range(1, H.n_levels - 1) if dv.matrix_info(l, "ApreLW")["fmt"] == "sell-lw"]
+    assert used and dv.matrix_info(0, "QLW")["fmt"] == "sell-lw"
+    xh, dh = _apply(H, p, "jacobi", AMGX_HOST_LW=1, **e)
+    assert np.array_equal(xv, xh)
+    assert _formats(dv) == _formats(dh)
+    for l in range(H.n_levels):
+        for w in ("ApreLW", "QLW"):
+            assert dv.matrix_info(l, w) == dh.matrix_info(l, w)
