@@ -946,7 +946,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       std::vector<uint8_t> cur_free = F.free;
       std::vector<double> cur_coords = F.coords;
       std::vector<double> cur_vs = F.vscale;
-      BCSR Ptot;
+      BCSR Ptot, PTlast;
       bool failed = false;
       const bool tlog = std::getenv("NGSAMG_SETUP_LOG") != nullptr;
       double tl = omp_get_wtime();
@@ -999,7 +999,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         lap("block prolongation, P^T");
         BCSR nextA = restrict_matrix(PkT, *curA, Pk);
         lap("Galerkin product");
-        if (substeps == 0) { Ptot = std::move(Pk); agg = sagg; }
+        if (substeps == 0) { Ptot = std::move(Pk); PTlast = std::move(PkT); agg = sagg; }
         else {
           Ptot = matmul(Ptot, Pk);
           for (auto& a : agg) if (a >= 0) a = sagg[a];
@@ -1015,7 +1015,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       }
       if (failed || substeps == 0) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
       F.P = std::move(Ptot);
-      F.PT = transpose(F.P);
+      F.PT = substeps == 1 ? std::move(PTlast) : transpose(F.P);       // (one step: the transpose the Galerkin product used)
       F.agg = agg;
       C.A = std::move(tmpA);
       xc = std::move(cur_coords);
