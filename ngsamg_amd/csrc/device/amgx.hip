@@ -2446,13 +2446,41 @@ static void build_gsb(const amgx_level_desc& d, DevLevel& L, const amgx_matrix* 
       if (const char* e = std::getenv("AMGX_LW_MIN_ROWS")) lw_min_rows = std::atoll(e);
       if (P && avgA >= 24.0 && n >= lw_min_rows && d.A.n_cols == n && P->br == 1 && P->bc == 1 && P->rowptr[P->n_rows] < (int64_t)2147483647 &&
           !std::getenv("AMGX_NO_LW") && !std::getenv("AMGX_NO_FUSED_RESTRICT")) {
-        std::vector<int64_t> rp = db_download(part[1].rowptr, (size_t)n + 1);
-        std::vector<int32_t> cc = db_download(part[1].col, (size_t)std::max<int64_t>(1, part[1].nnz));
-        std::vector<double> vv = db_download(part[1].val, (size_t)std::max<int64_t>(1, part[1].nnz));
+        // (device builder first, devbuild.hpp dev_build_lw; the host builder works from the downloaded part)
+        std::vector<int64_t> rp;
+        std::vector<int32_t> cc;
+        std::vector<double> vv;
         amgx_matrix F = d.A;
-        F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+        auto host_lw = [&](int gg, DevMatrix& M, DevBuf<int32_t>& cp, DevBuf<int32_t>& cl) {
+          if (rp.empty()) {
+            rp = db_download(part[1].rowptr, (size_t)n + 1);
+            cc = db_download(part[1].col, (size_t)std::max<int64_t>(1, part[1].nnz));
+            vv = db_download(part[1].val, (size_t)std::max<int64_t>(1, part[1].nnz));
+            F.rowptr = rp.data(); F.col = cc.data(); F.val = vv.data();
+          }
+          return build_sell_lw(F, F.val, gg, M, cp, cl);
+        };
+        const bool dev_lw = !std::getenv("AMGX_HOST_LW");
+        const bool verify_lw = std::getenv("AMGX_VERIFY_IMAGES") != nullptr;
         int G = 0;
-        for (int gg : {2, 4}) if (build_sell_lw(F, F.val, gg, g.restLW, g.lw_cptr, g.lw_ccol)) { G = gg; break; } else g.restLW = DevMatrix();
+        for (int gg : {2, 4}) {
+          bool ok = false;
+          if (dev_lw) {
+            int64_t cap = LW_CAP;
+            const char* tcap = std::getenv("AMGX_LW_TEST_CAP");
+            if (tcap) cap = std::min<int64_t>(cap, std::atoll(tcap));
+            ok = dev_build_lw(part[1], false, gg, cap, tcap != nullptr, nullptr, 0.0, g.restLW, g.lw_cptr, g.lw_ccol);
+            if (ok && verify_lw) {
+              DevMatrix H; DevBuf<int32_t> hp, hc;
+              if (!host_lw(gg, H, hp, hc)) throw Err("AMGX_VERIFY_IMAGES: Gauss-Seidel rest (local window): the host builder declines what the device builder forms");
+              verify_same_lw(g.restLW, g.lw_cptr, g.lw_ccol, H, hp, hc, "Gauss-Seidel rest (local window)");
+            }
+            if (!ok) { g.restLW = DevMatrix(); g.lw_cptr.release(); g.lw_ccol.release(); }
+          }
+          if (!ok) ok = host_lw(gg, g.restLW, g.lw_cptr, g.lw_ccol);
+          if (ok) { G = gg; break; }
+          g.restLW = DevMatrix();
+        }
         if (G) {
           build_restrict(*P, L.RG, 512 / G, 4 * 512, 512);
           if (!L.RG.empty()) return;
