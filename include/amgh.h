@@ -64,6 +64,11 @@ typedef struct amgh_options {
                              /*   vertex_factory_impl.hpp:1836-2290); 3: the weight rule of rounds 1-2 of this build.  Block levels take the   */
                              /*   aux rule on their scalar edge weights for 1 and 2 (rigid-body blocks w Q(t)).  Default: 2 with spw = 1, else 3 */
   int32_t sp_max_per_row_classic;  /* ngs_amg_sp_max_per_row_classic (5, vertex_factory_impl.hpp:71)                                        */
+  int32_t edge_mats;         /* elasticity only, default 0.  1: the setup carries the energy's edge matrices from level to level (finest     */
+                             /*   level from the assembled matrix as BuildAlgMesh_ALG_blk does, elasticity_pc_impl.hpp:409-505; coarse ones by   */
+                             /*   AttachedEED::map_data, elasticity_impl.hpp:23-78) and builds the MATRIX-VALUED smoothed prolongation of the      */
+                             /*   reference (SemiAuxSProlMap with TM = Mat<BS,BS>, vertex_factory_impl.hpp:1836-2290): general BS x BS blocks     */
+                             /*   instead of w Q(t); the strength of connection reads the edges' approximate weights trace(E) / BS.              */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -60,6 +60,7 @@ void sym_eig(double* a, int n, double* evals, double* evecs);
 // pseudo inverse with the reference's rule (utils_denseLA.hpp:1460-1570): try the direct inverse,
 // else eigen-decomposition dropping eigenvalues <= max(rel_tol*mean, abs_tol)
 void pseudo_inverse_try_normal(double* a, int n);
+void pseudo_inverse_with_tol(double* a, int n);
 // Cholesky-based SPD inverse; falls back to pseudo inverse if not SPD. returns true if Cholesky succeeded
 bool spd_inverse(double* a, int n);
 

@@ -95,6 +95,12 @@ static void pseudo_inverse_eig(double* a, int n) {
   }
 }
 
+// CalcPseudoInverseWithTol (utils_denseLA.hpp:1474-1519): always the eigenvalue form, no attempt at a direct inverse
+void pseudo_inverse_with_tol(double* a, int n) {
+  if (n == 1) { a[0] = (std::fabs(a[0]) > ABS_ZERO_TOL) ? 1.0 / a[0] : 0.0; return; }
+  pseudo_inverse_eig(a, n);
+}
+
 void pseudo_inverse_try_normal(double* a, int n) {
   if (n == 1) { a[0] = (std::fabs(a[0]) > ABS_ZERO_TOL) ? 1.0 / a[0] : 0.0; return; }
   std::vector<double> keep(a, a + n * n);

@@ -657,6 +657,315 @@ BCSR block_prolongation(const BCSR& W, int bs_f, int bs_c, int dim, int energy,
   return P;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Elasticity with the energy's edge matrices (Options::edge_mats): the matrix-valued form of the reference's smoothed
+// prolongation.  State of a vertex = (displacement, rotation), BS = dim + dim (dim - 1) / 2 numbers; an edge (i, j) carries a
+// symmetric BS x BS matrix E in the frame of its midpoint m, its energy is |Q(m - x_i) u_i - Q(m - x_j) u_j|_E^2 with the
+// rigid-body transformation Q(t) = [I, S(t); 0, I] (state at x + t of the rigid motion given at x;
+// src/elasticity/elasticity_energy.hpp:28-118 with rot_scaling = 1, which is what BuildAlgMesh_ALG_blk sets and
+// AttachedEVD::map_data forwards, elasticity_pc_impl.hpp:479-480, elasticity_impl.hpp:153-155).
+constexpr int EM_MAX = 6;
+
+static inline int em_bs(int dim) { return dim + (dim * (dim - 1)) / 2; }
+
+static inline void rb_Q(int dim, const double* t, double* Q) {
+  const int BS = em_bs(dim);
+  for (int q = 0; q < BS * BS; q++) Q[q] = 0.0;
+  for (int r = 0; r < BS; r++) Q[r * BS + r] = 1.0;
+  if (dim == 2) { Q[0 * 3 + 2] = -t[1]; Q[1 * 3 + 2] = t[0]; }
+  else {
+    Q[0 * 6 + 4] = t[2];  Q[0 * 6 + 5] = -t[1];
+    Q[1 * 6 + 3] = -t[2]; Q[1 * 6 + 5] = t[0];
+    Q[2 * 6 + 3] = t[1];  Q[2 * 6 + 4] = -t[0];
+  }
+}
+static inline void em_mm(int n, const double* A, const double* B, double* C) {        // C = A B
+  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[r * n + k] * B[k * n + c]; C[r * n + c] = s; }
+}
+static inline void em_mtm(int n, const double* A, const double* B, double* C) {       // C = A^T B
+  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[k * n + r] * B[k * n + c]; C[r * n + c] = s; }
+}
+
+// Edge matrices of the finest level from the assembled matrix (VertexAMGPC::BuildAlgMesh_ALG_blk, elasticity_pc_impl.hpp:446-488):
+//   x = (sum_r |a_rr| + 2 sum_{r<c} |a_rc| over the block A_ij) / (bs^2 sqrt(sum_i sum_j)); the reference takes BOTH traces from the
+//   diagonal block of the edge's first (lower) vertex (`MAT(dis[j], dis[j])` in its second loop) -- restated as written;
+//   displacement-only vertices: E = x t t^T on the displacement part (a spring along the edge), vertices with rotations: E = x I.
+// The graph holds the edges between free vertices (the reference gives edges at Dirichlet vertices a dummy value that no formula
+// reads: those vertices are not mapped); its scalar weight is ENERGY::GetApproxWeight = trace(E) / BS (elasticity_energy.hpp:690-696).
+Graph fine_edge_mats(const BCSR& A, const std::vector<uint8_t>& free, const std::vector<double>& xf, int dim, std::vector<double>& E) {
+  const int BS = em_bs(dim), bs = A.br, BB = BS * BS;
+  Graph G = strength_graph(A, free, dim, 1);
+  const int64_t n = G.n;
+  std::vector<double> tr(n, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { double s = 0; for (int r = 0; r < bs; r++) s += A.val[(k * bs + r) * bs + r]; tr[i] = s; break; }
+  E.assign((size_t)G.ptr[n] * BB, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    if (!free[i]) continue;
+    int64_t p = G.ptr[i];
+    for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) {
+      const int32_t j = A.col[k];
+      if (j == i || !free[j]) continue;
+      const double* b = &A.val[(size_t)k * bs * bs];
+      const double* bu = b;
+      // the block as the reference reads it: rows of the edge's first vertex, columns of its second (the transposed block seen from j)
+      double x = 0;
+      for (int r = 0; r < bs; r++) {
+        x += std::fabs(bu[r * bs + r]);
+        for (int c = r + 1; c < bs; c++) x += 2.0 * std::fabs(j > i ? bu[r * bs + c] : bu[c * bs + r]);
+      }
+      const double s0 = tr[std::min<int64_t>(i, j)];
+      x /= (double)(bs * bs) * std::sqrt(s0 * s0);
+      double* e = &E[(size_t)p * BB];
+      if (bs == dim) {
+        double t[3] = {0, 0, 0}, len = 0;
+        for (int d = 0; d < dim; d++) { t[d] = xf[(int64_t)j * dim + d] - xf[i * dim + d]; len += t[d] * t[d]; }
+        len = std::sqrt(len);
+        for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++) e[r * BS + c] = x * (t[r] / len) * (t[c] / len);
+      } else {
+        for (int r = 0; r < BS; r++) e[r * BS + r] = x;
+      }
+      double trE = 0;
+      for (int r = 0; r < BS; r++) trE += e[r * BS + r];
+      G.w[p] = trE / BS;
+      p++;
+    }
+  }
+  return G;
+}
+
+// Edge matrices of the next level (AttachedEED::map_data, elasticity_impl.hpp:23-78): E_IJ = sum over the fine edges between the
+// aggregates I and J of Q^T E_ij Q with Q = Q(m_ij - m_IJ), the transformation from the coarse edge's midpoint to the fine one's.
+// Edges to unmapped vertices go into the reference's vertex weights (read only by its L2-dominance rule, off by default): dropped.
+Graph contract_edge_mats(const Graph& g, const std::vector<double>& E, int dim, const std::vector<int32_t>& agg, int64_t nc,
+                         const std::vector<double>& xf, const std::vector<double>& xc, std::vector<double>& Ec) {
+  const int BS = em_bs(dim), BB = BS * BS;
+  const int64_t n = g.n;
+  std::vector<int64_t> mptr(nc + 1, 0);
+  for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) mptr[agg[i] + 1]++;
+  for (int64_t I = 0; I < nc; I++) mptr[I + 1] += mptr[I];
+  std::vector<int32_t> mem(mptr[nc]);
+  { std::vector<int64_t> pos(mptr.begin(), mptr.end() - 1); for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) mem[pos[agg[i]]++] = (int32_t)i; }
+  Graph C;
+  C.n = nc;
+  std::vector<int64_t> cnt(nc + 1, 0);
+#pragma omp parallel
+  {
+    std::vector<int32_t> nb;
+#pragma omp for schedule(static)
+    for (int64_t I = 0; I < nc; I++) {
+      nb.clear();
+      for (int64_t q = mptr[I]; q < mptr[I + 1]; q++) { const int32_t i = mem[q]; for (int64_t k = g.ptr[i]; k < g.ptr[i + 1]; k++) { const int32_t J = agg[g.adj[k]]; if (J >= 0 && J != I) nb.push_back(J); } }
+      std::sort(nb.begin(), nb.end());
+      cnt[I + 1] = std::unique(nb.begin(), nb.end()) - nb.begin();
+    }
+  }
+  C.ptr.assign(nc + 1, 0);
+  for (int64_t I = 0; I < nc; I++) C.ptr[I + 1] = C.ptr[I] + cnt[I + 1];
+  C.adj.resize(C.ptr[nc]);
+  C.w.assign(C.ptr[nc], 0.0);
+  Ec.assign((size_t)C.ptr[nc] * BB, 0.0);
+#pragma omp parallel
+  {
+    std::vector<int32_t> nb;
+    double Q[EM_MAX * EM_MAX], EQ[EM_MAX * EM_MAX], QEQ[EM_MAX * EM_MAX];
+#pragma omp for schedule(static)
+    for (int64_t I = 0; I < nc; I++) {
+      nb.clear();
+      for (int64_t q = mptr[I]; q < mptr[I + 1]; q++) { const int32_t i = mem[q]; for (int64_t k = g.ptr[i]; k < g.ptr[i + 1]; k++) { const int32_t J = agg[g.adj[k]]; if (J >= 0 && J != I) nb.push_back(J); } }
+      std::sort(nb.begin(), nb.end());
+      nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+      int32_t* adj = &C.adj[C.ptr[I]];
+      std::copy(nb.begin(), nb.end(), adj);
+      for (int64_t q = mptr[I]; q < mptr[I + 1]; q++) {
+        const int32_t i = mem[q];
+        for (int64_t k = g.ptr[i]; k < g.ptr[i + 1]; k++) {
+          const int32_t j = g.adj[k], J = agg[j];
+          if (J < 0 || J == I) continue;
+          const int64_t p = C.ptr[I] + (std::lower_bound(nb.begin(), nb.end(), J) - nb.begin());
+          double t[3] = {0, 0, 0};
+          for (int d = 0; d < dim; d++) t[d] = 0.5 * (xf[(int64_t)i * dim + d] + xf[(int64_t)j * dim + d]) - 0.5 * (xc[I * dim + d] + xc[(int64_t)J * dim + d]);
+          rb_Q(dim, t, Q);
+          em_mm(BS, &E[(size_t)k * BB], Q, EQ);
+          em_mtm(BS, Q, EQ, QEQ);
+          double* e = &Ec[(size_t)p * BB];
+          for (int x = 0; x < BB; x++) e[x] += QEQ[x];
+        }
+      }
+      for (int64_t p = C.ptr[I]; p < C.ptr[I + 1]; p++) { double tr = 0; for (int r = 0; r < BS; r++) tr += Ec[(size_t)p * BB + r * BS + r]; C.w[p] = tr / BS; }
+    }
+  }
+  return C;
+}
+
+// Matrix-valued smoothed prolongation (VertexAMGFactory::SemiAuxSProlMap for TM = Mat<BS,BS>, vertex_factory_impl.hpp:1836-2290).
+// Column selection as in prolongation_weights_ref (the scalar weights are the edges' approximate weights); values:
+//   piecewise block  pw(j, J) = Q(x_j - X_J)                                   (ENERGY::CalcQHh, elasticity_energy_impl.hpp:71-77)
+//   classic row      P_i = pw_i - omega D^+ sum_j A_ij pw_j,  D = A_ii scaled to trace BS, pseudo-inverse, scaled back (:2088-2137)
+//   aux row          replacement-matrix row of the edges to the used neighbours: R_ii = sum_j Qij^T E Qij, R_ij = -Qij^T E Qji with
+//                    Qij = Q(m - x_i), Qji = Q(m - x_j); scaled by BS / trace(R_ii), R_ii^+ by CalcPseudoInverseWithTol;
+//                    P_i = pw_i - omega R_ii^+ (R_ii pw_i + sum_j R_ij pw_j)                                      (:2140-2262)
+// Rigid-body modes are reproduced exactly by every aux row (E acts on differences of rigid-body states at the edge midpoint).
+// A: the level matrix with BS x BS blocks, or nullptr (aux only: prol_type 1, or a displacement-only finest level, whose matrix
+// the reference's factory does not hold in TM form).  bs_f < BS: the displacement rows of every block (the finest level's embedding,
+// elasticity_pc_impl.hpp:668-685).
+BCSR prolongation_edge_mats(const BCSR* A, const Graph& G, const std::vector<double>& E, int dim, int bs_f, const std::vector<int32_t>& agg,
+                            int64_t nc, const std::vector<double>& xf, const std::vector<double>& xc, const Options& o) {
+  const int BS = em_bs(dim), BB = BS * BS;
+  const int64_t n = G.n;
+  const int maxr = std::max(1, o.sp_max_per_row), maxc = std::max(1, o.sp_max_per_row_classic), cap = std::max(maxr, maxc);
+  const double minf = o.sp_min_frac, omega = o.sp_omega;
+  std::vector<int32_t> cols((size_t)n * cap), len(n, 0);
+  std::vector<uint8_t> kind(n, 0);        // 0 piecewise, 1 classic, 2 aux
+#pragma omp parallel
+  {
+    std::vector<std::pair<int32_t, double>> trow;
+    std::vector<int32_t> cc;
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+      const int32_t I = agg[i];
+      if (I < 0) continue;
+      int32_t* oc = &cols[(size_t)i * cap];
+      int nniscv = 0;
+      for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) if (agg[G.adj[k]] == I) nniscv++;
+      if (nniscv == 0 || !o.enable_sp) { oc[0] = I; len[i] = 1; continue; }
+      cc.clear();
+      bool classic = false;
+      if (A) {
+        classic = true;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+          const int32_t cj = agg[A->col[k]];
+          if (cj < 0) { classic = false; break; }
+          auto it = std::lower_bound(cc.begin(), cc.end(), cj);
+          if (it == cc.end() || *it != cj) cc.insert(it, cj);
+        }
+        classic = classic && (int)cc.size() <= maxc;
+      }
+      if (!classic) {
+        trow.clear();
+        double in_wt = 0.0, dgwt = 0.0;
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          dgwt = std::max(dgwt, G.w[k]);
+          const int32_t J = agg[G.adj[k]];
+          if (J < 0) continue;
+          if (J == I) { in_wt += G.w[k]; continue; }
+          bool found = false;
+          for (auto& t : trow) if (t.first == J) { t.second += G.w[k]; found = true; break; }
+          if (!found) trow.push_back({J, G.w[k]});
+        }
+        std::stable_sort(trow.begin(), trow.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+        double cw_sum = 0.2 * in_wt;
+        cc.assign(1, I);
+        const size_t max_adds = std::min<size_t>((size_t)(maxr - 1), trow.size());
+        for (size_t j = 0; j < max_adds; j++) {
+          cw_sum += trow[j].second;
+          if (!(trow[j].second > minf * cw_sum) || trow[j].second < minf * dgwt) break;
+          cc.push_back(trow[j].first);
+        }
+        std::sort(cc.begin(), cc.end());
+      }
+      for (size_t q = 0; q < cc.size(); q++) oc[q] = cc[q];
+      len[i] = (int32_t)cc.size();
+      kind[i] = cc.size() == 1 ? 0 : classic ? 1 : 2;
+    }
+  }
+  BCSR P;
+  P.n_rows = n; P.n_cols = nc; P.br = bs_f; P.bc = BS;
+  P.rowptr.assign(n + 1, 0);
+  for (int64_t i = 0; i < n; i++) P.rowptr[i + 1] = P.rowptr[i] + len[i];
+  P.col.resize(P.rowptr[n]);
+  P.val.assign((size_t)P.rowptr[n] * bs_f * BS, 0.0);
+  auto pw = [&](int64_t j, int32_t J, double* Q) {
+    double t[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) t[d] = xf[j * dim + d] - xc[(int64_t)J * dim + d];
+    rb_Q(dim, t, Q);
+  };
+#pragma omp parallel
+  {
+    std::vector<double> vals((size_t)cap * BB), rm;
+    std::vector<int32_t> unb;
+    double Qij[EM_MAX * EM_MAX], Qji[EM_MAX * EM_MAX], QM[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX], T2[EM_MAX * EM_MAX], d[EM_MAX * EM_MAX], ds[EM_MAX * EM_MAX], PW[EM_MAX * EM_MAX];
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+      const int m = len[i];
+      if (m == 0) continue;
+      const int32_t I = agg[i];
+      const int32_t* cc = &cols[(size_t)i * cap];
+      std::fill(vals.begin(), vals.begin() + (size_t)m * BB, 0.0);
+      auto colidx = [&](int32_t J) -> int { const int32_t* it = std::lower_bound(cc, cc + m, J); return (it != cc + m && *it == J) ? (int)(it - cc) : -1; };
+      auto sub_omega_d = [&](int ci, const double* od) {        // vals[ci] -= omega d od
+        em_mm(BS, d, od, T2);
+        double* v = &vals[(size_t)ci * BB];
+        for (int x = 0; x < BB; x++) v[x] -= omega * T2[x];
+      };
+      if (kind[i] == 0) {
+        pw(i, cc[0], &vals[0]);
+      } else if (kind[i] == 1) {
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) if (A->col[k] == i) { std::copy(&A->val[(size_t)k * BB], &A->val[(size_t)k * BB] + BB, d); break; }
+        double tr = 0;
+        for (int r = 0; r < BS; r++) tr += d[r * BS + r];
+        const double trinv = (double)BS / tr;
+        for (int x = 0; x < BB; x++) d[x] *= trinv;
+        pseudo_inverse_with_tol(d, BS);
+        for (int x = 0; x < BB; x++) d[x] *= trinv;
+        for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; k++) {
+          const int32_t j = A->col[k];
+          const int ci = colidx(agg[j]);
+          if (ci < 0) continue;
+          pw(j, agg[j], PW);
+          if (j == i) { double* v = &vals[(size_t)ci * BB]; for (int x = 0; x < BB; x++) v[x] += PW[x]; }
+          em_mm(BS, &A->val[(size_t)k * BB], PW, T);
+          sub_omega_d(ci, T);
+        }
+      } else {
+        unb.clear();
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) { const int32_t J = agg[G.adj[k]]; if (J >= 0 && colidx(J) >= 0) unb.push_back((int32_t)(k - G.ptr[i])); }
+        rm.assign(unb.size() * BB, 0.0);
+        for (int x = 0; x < BB; x++) ds[x] = 0.0;
+        for (size_t q = 0; q < unb.size(); q++) {
+          const int64_t k = G.ptr[i] + unb[q];
+          const int32_t j = G.adj[k];
+          double ti[3] = {0, 0, 0}, tj[3] = {0, 0, 0};
+          for (int dd = 0; dd < dim; dd++) { const double mid = 0.5 * (xf[i * dim + dd] + xf[(int64_t)j * dim + dd]); ti[dd] = mid - xf[i * dim + dd]; tj[dd] = mid - xf[(int64_t)j * dim + dd]; }
+          rb_Q(dim, ti, Qij);
+          rb_Q(dim, tj, Qji);
+          em_mtm(BS, Qij, &E[(size_t)k * BB], QM);      // Qij^T E
+          em_mm(BS, QM, Qji, T);
+          for (int x = 0; x < BB; x++) rm[q * BB + x] = -T[x];
+          em_mm(BS, QM, Qij, T);
+          for (int x = 0; x < BB; x++) ds[x] += T[x];
+        }
+        double tr = 0;
+        for (int r = 0; r < BS; r++) tr += ds[r * BS + r];
+        const double trinv = (double)BS / tr;
+        for (auto& v : rm) v *= trinv;
+        for (int x = 0; x < BB; x++) { ds[x] *= trinv; d[x] = ds[x]; }
+        pseudo_inverse_with_tol(d, BS);
+        const int cI = colidx(I);
+        pw(i, I, PW);
+        { double* v = &vals[(size_t)cI * BB]; for (int x = 0; x < BB; x++) v[x] += PW[x]; }
+        em_mm(BS, ds, PW, T);
+        sub_omega_d(cI, T);
+        for (size_t q = 0; q < unb.size(); q++) {
+          const int32_t j = G.adj[G.ptr[i] + unb[q]];
+          pw(j, agg[j], PW);
+          em_mm(BS, &rm[q * BB], PW, T);
+          sub_omega_d(colidx(agg[j]), T);
+        }
+      }
+      for (int q = 0; q < m; q++) {
+        const int64_t p = P.rowptr[i] + q;
+        P.col[p] = cc[q];
+        for (int r = 0; r < bs_f; r++) for (int c = 0; c < BS; c++) P.val[((size_t)p * bs_f + r) * BS + c] = vals[(size_t)q * BB + r * BS + c];
+      }
+    }
+  }
+  return P;
+}
+
 }  // namespace
 
 template <class Mat>
@@ -916,6 +1225,11 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     if (coords0) L.coords.assign(coords0, coords0 + A0.n_rows * dim);
     else if (o.energy == 1) throw Error("elasticity setup needs vertex coordinates");
   }
+  // edge_mats: the alg-mesh (edges with the energy's matrices) is carried from level to level beside the matrices
+  const bool emats = o.edge_mats && o.energy == 1;
+  if (emats && (!o.spw || o.robust_soc)) throw Error("edge_mats needs the SPW agglomerator (spw = 1, robust_soc = 0)");
+  Graph mesh;
+  std::vector<double> meshE;
   while (true) {
     const int lev = (int)H->levels.size() - 1;
     Level& F = H->levels[lev];
@@ -957,8 +1271,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         tl = t;
       };
       while (true) {
-        Graph G = strength_graph(*curA, cur_free, dim, o.energy);
-        lap("strength graph");
+        if (emats && lev == 0 && substeps == 0) mesh = fine_edge_mats(*curA, cur_free, cur_coords, dim, meshE);
+        Graph G = emats ? std::move(mesh) : strength_graph(*curA, cur_free, dim, o.energy);
+        lap(emats ? "alg-mesh (edge matrices)" : "strength graph");
         if (o.robust_soc) { G.vs = cur_vs; G.vs.resize(G.n, 0.0); }
         const double step_target = (o.enable_multistep && target < o.aaf) ? std::max(target, o.aaf) : target;
         std::vector<int32_t> sagg;
@@ -982,8 +1297,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         // block (elasticity) levels: the aux rule on the scalar edge weights for both smoothed types -- column selection and
         // replacement-matrix weights as in the reference, the blocks of P stay rigid-body transformations w Q(t); its matrix-valued
         // classic / aux formulas need the energy's edge matrices, which this setup does not carry
-        BCSR W = ptype == 3 ? prolongation_weights(G, sagg, snc, op)
-                            : prolongation_weights_ref((ptype == 2 && curA->br == 1) ? curA : nullptr, G, sagg, snc, op);
+        BCSR W;
+        if (!emats) W = ptype == 3 ? prolongation_weights(G, sagg, snc, op)
+                                   : prolongation_weights_ref((ptype == 2 && curA->br == 1) ? curA : nullptr, G, sagg, snc, op);
         lap("prolongation weights");
         const int sbf = curA->br;
         std::vector<double> sxc;
@@ -994,7 +1310,14 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
           for (int64_t i = 0; i < cn; i++) if (sagg[i] >= 0) { cnt[sagg[i]]++; for (int d = 0; d < dim; d++) sxc[(int64_t)sagg[i] * dim + d] += cur_coords[i * dim + d]; }
           for (int64_t I = 0; I < snc; I++) for (int d = 0; d < dim; d++) sxc[I * dim + d] /= std::max(1, cnt[I]);
         }
-        BCSR Pk = block_prolongation(W, sbf, bs_c, dim, o.energy, cur_coords, sxc);
+        // edge_mats: the matrix-valued rule; `own` (3) has no such form and takes the reference's default (2)
+        BCSR Pk = emats ? prolongation_edge_mats((ptype != 1 && curA->br == bs_c) ? curA : nullptr, G, meshE, dim, sbf, sagg, snc, cur_coords, sxc, op)
+                        : block_prolongation(W, sbf, bs_c, dim, o.energy, cur_coords, sxc);
+        if (emats) {
+          std::vector<double> nextE;
+          mesh = contract_edge_mats(G, meshE, dim, sagg, snc, cur_coords, sxc, nextE);
+          meshE = std::move(nextE);
+        }
         BCSR PkT = transpose(Pk);
         lap("block prolongation, P^T");
         BCSR nextA = restrict_matrix(PkT, *curA, Pk);

@@ -79,6 +79,29 @@ def test_elast_3d_lo(rot):
 
 
 @pytest.mark.parametrize("rot", [False, True])
+def test_elast_3d_lo_edge_mats(rot):
+    """the same two problems with ngs_amg_edge_mats: the matrix-valued smoothed prolongation of the reference (general 6x6 /
+    3x6 blocks, no rigid-body storage) runs through the general block transfer kernels; the reference's budget holds and the
+    application equals the oracle's on the same hierarchy"""
+    from ngsamg_amd import NgsAMG
+    from oracle.pyoracle import Oracle
+    shape, ext = ((9, 5, 5), (2.0, 1.0, 1.0)) if rot else ((41, 5, 5), (10.0, 1.0, 1.0))
+    p = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=ext)
+    c = NgsAMG.elast_3d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=10, ngs_amg_edge_mats=True, ngs_amg_sm_type="jacobi")
+    H = c.GetHierarchy()
+    dev = c.GetAMGMatrix()._dev
+    assert all(dev.matrix_info(l, "P")["fmt"] != "rigid-body" for l in range(H.n_levels - 1))
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    x = np.zeros_like(b)
+    c.Mult(b, x)
+    ref = Oracle(H.levels, sm_type="jacobi").apply(b)
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+    c2 = NgsAMG.elast_3d(_mat(p), p.free, coords=p.coords, ngs_amg_max_coarse_size=10, ngs_amg_edge_mats=True)
+    Solve(_mat(p), p.load, c2, ms=40, tol=1e-6)           # the reference's budget (default smoother)
+
+
+@pytest.mark.parametrize("rot", [False, True])
 def test_elast_2d_lo(rot):
     """reference tests/elasticity/mdim/simple/test_2d_lo.py (test_2d_lo, test_2d_lo_R): beam 10 x 1, maxh = 0.1, mu=1, lam=0,
     max_coarse_size 20, ms 50; 2x2 displacement blocks (3x3 with the rotation) on level 0, 3x3 below"""

@@ -445,3 +445,84 @@ def test_device_setup_without_a_gpu_keeps_the_host_product():
             _lib.device_setup(True)
     finally:
         _lib._device_setup = saved
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_edge_matrix_prolongation_of_the_reference(rot):
+    """ngs_amg_edge_mats: the setup carries the elasticity energy's edge matrices (finest level as BuildAlgMesh_ALG_blk,
+    elasticity_pc_impl.hpp:409-505; coarse levels as AttachedEED::map_data, elasticity_impl.hpp:23-78) and builds the
+    matrix-valued smoothed prolongation (SemiAuxSProlMap, vertex_factory_impl.hpp:1836-2290).  Properties the reference's
+    construction guarantees: general BS x BS blocks (not w Q(t)); every row of a free vertex reproduces the rigid-body modes on
+    every level (aux rows by construction, classic rows away from the clamped face because A annihilates them there); Galerkin
+    coarse operators; and the budgets of tests/elasticity/mdim/simple/test_3d_lo.py (40 iterations, tol 1e-6) at its mesh size."""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    shape, ext = ((9, 5, 5), (2.0, 1.0, 1.0)) if rot else ((41, 5, 5), (10.0, 1.0, 1.0))
+    p = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=ext)
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    kw = dict(dim=3, energy=1, max_coarse_size=10, regularize_cmats=0 if rot else 1)
+    H = Hierarchy(A, p.free, p.coords, edge_mats=1, **kw)
+    H0 = Hierarchy(A, p.free, p.coords, **kw)
+    assert H.n_levels >= 3 and all(L.bs == 6 for L in H.levels[1:])
+    rng = np.random.default_rng(2)
+    t, w = rng.standard_normal(3), rng.standard_normal(3)
+    general_blocks = False
+    for l in range(H.n_levels - 1):
+        Lf, Lc = H.levels[l], H.levels[l + 1]
+        P = Lf.P.to_scipy()
+        coarse = np.concatenate([t + np.cross(w, Lc.coords), np.tile(w, (Lc.n, 1))], axis=1).ravel()
+        fu = t + np.cross(w, Lf.coords)
+        fine = fu if Lf.bs == 3 else np.concatenate([fu, np.tile(w, (Lf.n, 1))], axis=1)
+        got = (P @ coarse).reshape(Lf.n, -1)
+        free = Lf.free.astype(bool)
+        err = np.abs(got[free] - fine[free]).max(axis=1)
+        scale = max(1.0, np.abs(fine).max())
+        # a classic row is pw_i - omega D^+ (A u)_i for the rigid-body mode u: exact where the level matrix annihilates u, i.e. away
+        # from the clamped face and its images on the coarse levels (the reference gives up the kernel there,
+        # vertex_factory_impl.hpp:2108-2117); level 0 of the displacement-only problem is aux only: exact everywhere
+        if l == 0 and not rot:
+            assert err.max() < 1e-10 * scale
+        else:
+            Af = Lf.A.to_scipy()
+            res = np.abs((Af @ (fine * free[:, None]).ravel()).reshape(Lf.n, -1)).max(axis=1)
+            sees_clamp = res > 1e-9 * abs(Af).max() * scale
+            assert 0 < (~sees_clamp[free]).sum()
+            assert err[~sees_clamp[free]].max() < 1e-8 * scale
+        Ac = Lc.A.to_scipy()
+        assert abs(Ac - Ac.T).max() < 1e-10 * abs(Ac).max()
+        assert abs(Ac - P.T @ Lf.A.to_scipy() @ P).max() < 1e-10 * abs(Ac).max()
+        # blocks beyond w Q(t): the displacement-displacement part of some block is not a multiple of the identity
+        blk = np.asarray(Lf.P.val).reshape(-1, Lf.P.br, Lf.P.bc)[:, :3, :3]
+        off = np.abs(blk - np.eye(3) * blk[:, :1, :1]).max()
+        general_blocks = general_blocks or off > 1e-6
+    assert general_blocks
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    it = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1]
+    it0 = Oracle(H0.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1]
+    assert it <= 40, it                       # the reference's budget
+    assert it <= it0 + 5, (it, it0)           # the scalar-weight rule w Q(t) of the default setup on the same problem
+
+
+def test_edge_matrix_option_errors_and_2d():
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    p = fem.poisson_fast((9, 9), dirichlet="left")
+    A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
+    with pytest.raises(NgsAMGError):
+        Hierarchy(A, p.free, None, dim=2, energy=0, edge_mats=1)             # an option of the elasticity energy
+    q = fem.elasticity_fast((41, 9), dirichlet="left", mu=1.0, lam=0.0, rotations=False, extent=(5.0, 1.0))
+    B = Matrix(q.n, q.n, q.bs, q.bs, q.rowptr, q.col, q.val)
+    with pytest.raises(NgsAMGError):
+        Hierarchy(B, q.free, q.coords, dim=2, energy=1, edge_mats=1, spw=0)
+    H = Hierarchy(B, q.free, q.coords, dim=2, energy=1, edge_mats=1, max_coarse_size=20, regularize_cmats=1)
+    assert H.levels[0].bs == 2 and all(L.bs == 3 for L in H.levels[1:])
+    # 2D rigid-body modes: u = t + w (-y, x), rotation w
+    rng = np.random.default_rng(5)
+    t, w = rng.standard_normal(2), float(rng.standard_normal())
+    Lf, Lc = H.levels[0], H.levels[1]
+    rb = lambda X: np.concatenate([t + w * np.stack([-X[:, 1], X[:, 0]], axis=1), np.full((len(X), 1), w)], axis=1)
+    got = (Lf.P.to_scipy() @ rb(Lc.coords).ravel()).reshape(Lf.n, 2)
+    free = Lf.free.astype(bool)
+    assert np.abs(got[free] - rb(Lf.coords)[free, :2]).max() < 1e-10
+    b = rng.standard_normal(q.n * q.bs) * np.repeat(q.free, q.bs)
+    assert Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1] <= 50   # budget of tests/elasticity/mdim/simple/test_2d_lo.py
