@@ -254,8 +254,79 @@ def run_distributed(args, torch, dist, world, rank, device, nv):
                          "algorithmic_bytes": int(spmv_bytes), "cycle_algorithmic_bytes_per_rank": int(per_rank),
                          "algorithmic_model_GBs_per_gpu": round(per_rank / (ms_per_step * 1e-3) / 1e9, 1)},
         }
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw)
+            except Exception as e:        # the baseline never takes the measured line down with it
+                log(f"cpu_baseline of the N > 1 line failed: {e!r}")
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         emit(json.dumps(out))
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw):
+    """cpu_baseline of an N > 1 line (rank 0 only, after the timed region, the other ranks wait in the final barrier): the CPU
+    oracle (oracle/oracle.c: the reference's V-cycle restated in C, OpenMP over rows) on the hierarchy ONE process builds for the
+    matrix the ranks share -- strong scaling: the global nv^3 matrix of the single-GPU line; weak scaling: one rank's nv^3 box,
+    value scaled by 1 / world (a CPU would have to run all `world` boxes).  Bounded sample (--cpu-seconds), threads = this
+    rank's CPU share."""
+    import __graft_entry__ as ge
+    from ngsamg_amd import fem
+    from ngsamg_amd._lib import Matrix
+    from ngsamg_amd.hierarchy import Hierarchy
+    if not os.environ.get("NGSAMG_NO_BUILD"):
+        ge.build_oracle()
+    from oracle.pyoracle import Oracle      # measured as the CPU baseline, never part of the product path
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(64, cores // max(1, world)))          # the node's cores are shared by `world` rank processes
+    if nv ** 3 * (1 if not elast else 6 if args.config == "cfg5" else 3) > 3e7:
+        log("cpu_baseline skipped: a single-process hierarchy of this size does not fit the bounded sample (see the N = 1 line)")
+        return None
+    t0 = time.time()
+    if elast:
+        rot = args.config == "cfg5"
+        prob = fem.elasticity_fast((nv, nv, nv), dirichlet="left", mu=1.0, lam=0.5, rotations=rot)
+        A = Matrix(prob.n, prob.n, prob.bs, prob.bs, prob.rowptr, prob.col, prob.val)
+        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=1, max_coarse_size=50, regularize_cmats=0 if rot else 1, **hier_kw)
+    else:
+        prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
+        A = Matrix(prob.n, prob.n, 1, 1, prob.rowptr, prob.col, prob.val)
+        H = Hierarchy(A, prob.free, prob.coords, dim=3, energy=0, max_coarse_size=50, max_levels=10, **hier_kw)
+    t1 = time.time()
+    n_s = prob.n * prob.bs
+    b = np.random.default_rng(0).standard_normal(n_s) * np.repeat(prob.free, prob.bs)
+    orc = Oracle(H.levels, sm_type="jacobi" if args.smoother == "jacobi" else "gs", omega=0.9, threads=cores)
+    if cores > 1:
+        orc.first_touch()
+    xo = np.zeros(n_s)
+    orc.apply(b, xo)
+    tc0 = time.perf_counter()
+    orc.apply(b, xo)
+    one = time.perf_counter() - tc0
+    reps = int(max(2, min(100, min(args.cpu_seconds, 15.0) / max(one, 1e-6))))
+    tc0 = time.perf_counter()
+    for _ in range(reps):
+        orc.apply(b, xo)
+    cpu_t = (time.perf_counter() - tc0) / reps
+    nnz = [int(L.A.nnz) for L in H.levels]
+    return {"value": round((1.0 if strong else 1.0 / world) / cpu_t, 3), "unit": "applies/s", "cores": int(cores), "kind": "port",
+            "sample": (f"{reps} V-cycle applications of the single-process hierarchy of "
+                       + (f"the same global {nv}^3 matrix" if strong else f"one rank's {nv}^3 box (value = 1 / ({world} x time): a CPU runs all {world} boxes)")
+                       + f" ({prob.n * prob.bs} DOF, {H.n_levels} levels, OC {sum(nnz) / max(1, nnz[0]):.3f}; oracle/oracle.c, OpenMP over rows, "
+                         f"{cores} threads = this rank's share of the node; setup {t1 - t0:.1f} s, not timed)"),
+            "hierarchy_note": "the rank-partitioned hierarchy (`hierarchy` above) is built by the distributed setup: same rules, rank-local aggregates"}
 
 
 def _wait_ranks(procs, limit):

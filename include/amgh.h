@@ -69,6 +69,10 @@ typedef struct amgh_options {
                              /*   AttachedEED::map_data, elasticity_impl.hpp:23-78) and builds the MATRIX-VALUED smoothed prolongation of the      */
                              /*   reference (SemiAuxSProlMap with TM = Mat<BS,BS>, vertex_factory_impl.hpp:1836-2290): general BS x BS blocks     */
                              /*   instead of w Q(t); the strength of connection reads the edges' approximate weights trace(E) / BS.              */
+  int32_t crs_robust;        /* ngs_amg_crs_robust (agglomerator.hpp:18; the reference's elasticity preconditioner sets it to false,           */
+                             /*   elasticity_pc_impl.hpp:55), default 0, needs edge_mats: the SPW pairing rounds pick the partner by the          */
+                             /*   energy-based strength of connection (CalcRobSOC with neighbour boost, agglomerator_utils.hpp:598-927;          */
+                             /*   FindNeib3Step with robustPick, spw_agg_impl.hpp:637-775)                                                        */
 } amgh_options;
 
 typedef struct amgh_level {

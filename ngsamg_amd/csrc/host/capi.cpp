@@ -92,6 +92,7 @@ void amgh_default_options(amgh_options* o, int dim, int energy) {
   o->prol_type = d.prol_type;
   o->sp_max_per_row_classic = d.sp_max_per_row_classic;
   o->edge_mats = 0;
+  o->crs_robust = 0;
 }
 
 int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
@@ -108,7 +109,8 @@ int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* 
     o.dim = opts->dim; o.energy = opts->energy; o.log_level = opts->log_level; o.enable_multistep = opts->enable_multistep; o.robust_soc = opts->robust_soc;
     o.spw = opts->spw; o.spw_rounds = opts->spw_rounds; o.spw_orphan_round = opts->spw_orphan_round;
     o.prol_type = opts->prol_type; o.sp_max_per_row_classic = opts->sp_max_per_row_classic;
-    o.edge_mats = opts->edge_mats;
+    o.edge_mats = opts->edge_mats; o.crs_robust = opts->crs_robust;
+    if (o.crs_robust && !o.edge_mats) throw amgh::Error("amgh_setup: crs_robust works on the energy's edge matrices (edge_mats = 1)");
     if (o.edge_mats && o.energy != 1) throw amgh::Error("amgh_setup: edge_mats belongs to the elasticity energy (energy = 1)");
     if (o.edge_mats && !coords_or_null) throw amgh::Error("amgh_setup: edge_mats needs vertex coordinates");
     if (o.edge_mats && (!o.spw || o.enable_multistep)) throw amgh::Error("amgh_setup: edge_mats needs spw = 1 and enable_multistep = 0");

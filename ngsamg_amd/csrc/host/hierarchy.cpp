@@ -306,6 +306,38 @@ int64_t aggregate(const Graph& G0, const std::vector<uint8_t>& free, double targ
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Elasticity with the energy's edge matrices (Options::edge_mats): the matrix-valued form of the reference's smoothed
+// prolongation.  State of a vertex = (displacement, rotation), BS = dim + dim (dim - 1) / 2 numbers; an edge (i, j) carries a
+// symmetric BS x BS matrix E in the frame of its midpoint m, its energy is |Q(m - x_i) u_i - Q(m - x_j) u_j|_E^2 with the
+// rigid-body transformation Q(t) = [I, S(t); 0, I] (state at x + t of the rigid motion given at x;
+// src/elasticity/elasticity_energy.hpp:28-118 with rot_scaling = 1, which is what BuildAlgMesh_ALG_blk sets and
+// AttachedEVD::map_data forwards, elasticity_pc_impl.hpp:479-480, elasticity_impl.hpp:153-155).
+constexpr int EM_MAX = 6;
+
+static inline int em_bs(int dim) { return dim + (dim * (dim - 1)) / 2; }
+
+static inline void rb_Q(int dim, const double* t, double* Q) {
+  const int BS = em_bs(dim);
+  for (int q = 0; q < BS * BS; q++) Q[q] = 0.0;
+  for (int r = 0; r < BS; r++) Q[r * BS + r] = 1.0;
+  if (dim == 2) { Q[0 * 3 + 2] = -t[1]; Q[1 * 3 + 2] = t[0]; }
+  else {
+    Q[0 * 6 + 4] = t[2];  Q[0 * 6 + 5] = -t[1];
+    Q[1 * 6 + 3] = -t[2]; Q[1 * 6 + 5] = t[0];
+    Q[2 * 6 + 3] = t[1];  Q[2 * 6 + 4] = -t[0];
+  }
+}
+static inline void em_mm(int n, const double* A, const double* B, double* C) {        // C = A B
+  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[r * n + k] * B[k * n + c]; C[r * n + c] = s; }
+}
+static inline void em_mtm(int n, const double* A, const double* B, double* C) {       // C = A^T B
+  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[k * n + r] * B[k * n + c]; C[r * n + c] = s; }
+}
+
+Graph contract_edge_mats(const Graph& g, const std::vector<double>& E, int dim, const std::vector<int32_t>& agg, int64_t nc,
+                         const std::vector<double>& xf, const std::vector<double>& xc, std::vector<double>& Ec);
+
+// ---------------------------------------------------------------------------------------------------------------------
 // SPW agglomeration with the scalar strength of connection, as the reference runs it for H1 (and for elasticity with
 // crs_robust = false): src/base/coarsening/spw_agg_impl.hpp
 //   FormAgglomerates_impl (:1436-1830): numRounds (3) pairing rounds on successively contracted graphs + one orphan round
@@ -349,7 +381,146 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
   return best;
 }
 
-int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const Options& o, std::vector<int32_t>& agg, int& rounds_done) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Energy-based ("robust") strength of connection of the reference's SPW agglomerator for matrix-valued data (crs_robust;
+// needs the edge matrices):
+//   PrepRobSOC / CalcRobSOC (agglomerator_utils.hpp:845-927): E = the edge's matrix + the neighbour boost (AddNeibBoost, :598-653:
+//       for every common neighbour n of i and j the parallel sum E_in (E_in + E_jn)^+ E_jn, formed in n's frame and moved to the
+//       edge's midpoint); d_i, d_j = the replacement-matrix diagonals ("aux diagonals": sum of Q^T E Q over a vertex's edges) moved
+//       to the midpoint; C = d_i (d_i + d_j)^+ d_j
+//   CalcRobustPairSOC (:763-841): the smallest eigenvalue of E v = lambda C v on the complement of ker C (eigenvalues of C below
+//       1e-10 of its largest count as kernel)
+//   FindNeib3Step with robustPick (spw_agg_impl.hpp:637-775): the neighbours that pass the scalar filter are re-weighted with this
+//       number, the strongest is taken if it reaches min(0.25 max scalar soc, edge_thresh = 0.025)
+// Not restated: the aggregate-wide check (checkBigSOC, off by default, spw_agg.hpp:31) and the robust form of the orphan round.
+constexpr double ROB_EDGE_THRESH = 0.025;       // agglomerator.hpp:16
+constexpr double ROB_ZERO_EV = 1e2 * 1e-12;     // 1e2 RelZeroTol (agglomerator_utils.hpp:923)
+
+static inline void em_qtmq(int n, const double* Q, const double* M, double* out) {   // out = Q^T M Q
+  double T[EM_MAX * EM_MAX];
+  em_mm(n, M, Q, T);
+  em_mtm(n, Q, T, out);
+}
+
+// A (A + B)^+ B
+static inline void em_parallel_sum(int n, const double* A, const double* B, double* out) {
+  double S[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+  for (int x = 0; x < n * n; x++) S[x] = A[x] + B[x];
+  pseudo_inverse_with_tol(S, n);
+  em_mm(n, S, B, T);
+  em_mm(n, A, T, out);
+}
+
+static double robust_pair_soc(int n, const double* C, const double* E) {
+  double w[EM_MAX * EM_MAX], ev[EM_MAX], V[EM_MAX * EM_MAX];
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) w[i * n + j] = 0.5 * (C[i * n + j] + C[j * n + i]);
+  sym_eig(w, n, ev, V);                         // columns of V = eigenvectors
+  double lmax = 0;
+  for (int k = 0; k < n; k++) lmax = std::max(lmax, ev[k]);
+  const double th = ROB_ZERO_EV * lmax;
+  int idx[EM_MAX], m = 0;
+  for (int k = 0; k < n; k++) if (ev[k] > th) idx[m++] = k;
+  if (m == 0) return 0.0;
+  // S = L^-1/2 V_r^T E V_r L^-1/2
+  double S[EM_MAX * EM_MAX], sv[EM_MAX], SV[EM_MAX * EM_MAX];
+  for (int a = 0; a < m; a++) for (int b = 0; b < m; b++) {
+    double s = 0;
+    for (int p = 0; p < n; p++) { double t = 0; for (int q = 0; q < n; q++) t += 0.5 * (E[p * n + q] + E[q * n + p]) * V[q * n + idx[b]]; s += V[p * n + idx[a]] * t; }
+    S[a * m + b] = s / std::sqrt(ev[idx[a]] * ev[idx[b]]);
+  }
+  sym_eig(S, m, sv, SV);
+  double lmin = sv[0];
+  for (int k = 1; k < m; k++) lmin = std::min(lmin, sv[k]);
+  return std::max(0.0, lmin);
+}
+
+struct RobustData {
+  int dim = 3;
+  const std::vector<double>* E = nullptr;   // per entry of the round's graph
+  const std::vector<double>* x = nullptr;   // positions of the round's vertices
+  std::vector<double> aux;                  // aux diagonal per vertex, in the vertex's frame
+};
+
+static void robust_aux_diags(const Graph& g, RobustData& R) {
+  const int dim = R.dim, BS = em_bs(dim), BB = BS * BS;
+  R.aux.assign((size_t)g.n * BB, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t v = 0; v < g.n; v++) {
+    double Q[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+    for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+      const int32_t j = g.adj[k];
+      double t[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) t[d] = 0.5 * ((*R.x)[(int64_t)j * dim + d] - (*R.x)[v * dim + d]);
+      rb_Q(dim, t, Q);
+      em_qtmq(BS, Q, &(*R.E)[(size_t)k * BB], T);
+      for (int x = 0; x < BB; x++) R.aux[(size_t)v * BB + x] += T[x];
+    }
+  }
+}
+
+static double robust_soc(const Graph& g, const RobustData& R, int64_t i, int64_t k) {
+  const int dim = R.dim, BS = em_bs(dim), BB = BS * BS;
+  const int32_t j = g.adj[k];
+  const std::vector<double>& X = *R.x;
+  double E[EM_MAX * EM_MAX], Q[EM_MAX * EM_MAX], Ein[EM_MAX * EM_MAX], Ejn[EM_MAX * EM_MAX], H[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+  std::copy(&(*R.E)[(size_t)k * BB], &(*R.E)[(size_t)k * BB] + BB, E);
+  double mid[3] = {0, 0, 0};
+  for (int d = 0; d < dim; d++) mid[d] = 0.5 * (X[i * dim + d] + X[(int64_t)j * dim + d]);
+  // neighbour boost over the common neighbours
+  for (int64_t ki = g.ptr[i]; ki < g.ptr[i + 1]; ki++) {
+    const int32_t nb = g.adj[ki];
+    if (nb == j) continue;
+    int64_t kj = -1;
+    for (int64_t q = g.ptr[j]; q < g.ptr[j + 1]; q++) if (g.adj[q] == nb) { kj = q; break; }
+    if (kj < 0) continue;
+    double t[3] = {0, 0, 0};
+    for (int d = 0; d < dim; d++) t[d] = 0.5 * (X[i * dim + d] - X[(int64_t)nb * dim + d]);      // n -> midpoint of (n, i)
+    rb_Q(dim, t, Q);
+    em_qtmq(BS, Q, &(*R.E)[(size_t)ki * BB], Ein);
+    for (int d = 0; d < dim; d++) t[d] = 0.5 * (X[(int64_t)j * dim + d] - X[(int64_t)nb * dim + d]);
+    rb_Q(dim, t, Q);
+    em_qtmq(BS, Q, &(*R.E)[(size_t)kj * BB], Ejn);
+    em_parallel_sum(BS, Ein, Ejn, H);
+    for (int d = 0; d < dim; d++) t[d] = X[(int64_t)nb * dim + d] - mid[d];                       // edge midpoint -> n
+    rb_Q(dim, t, Q);
+    em_qtmq(BS, Q, H, T);
+    for (int x = 0; x < BB; x++) E[x] += T[x];
+  }
+  double di[EM_MAX * EM_MAX], dj[EM_MAX * EM_MAX], C[EM_MAX * EM_MAX];
+  double t[3] = {0, 0, 0};
+  for (int d = 0; d < dim; d++) t[d] = X[i * dim + d] - mid[d];
+  rb_Q(dim, t, Q);
+  em_qtmq(BS, Q, &R.aux[(size_t)i * BB], di);
+  for (int d = 0; d < dim; d++) t[d] = X[(int64_t)j * dim + d] - mid[d];
+  rb_Q(dim, t, Q);
+  em_qtmq(BS, Q, &R.aux[(size_t)j * BB], dj);
+  em_parallel_sum(BS, di, dj, C);
+  return robust_pair_soc(BS, C, E);
+}
+
+static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, const std::vector<double>& mt, const std::vector<uint8_t>& handled, int64_t v) {
+  double mx = 0.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+    const double den = std::sqrt(mt[v] * mt[g.adj[k]]);
+    if (den > 0.0) mx = std::max(mx, g.w[k] / den);
+  }
+  if (!(mx > 0.0)) return -1;
+  const double th = SPW_REL_THRESH * mx;
+  int32_t best = -1;
+  double bw = -1.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+    const int32_t j = g.adj[k];
+    if (handled[j]) continue;
+    const double den = std::sqrt(mt[v] * mt[j]);
+    if (!(den > 0.0) || g.w[k] / den < th) continue;
+    const double w = robust_soc(g, R, v, k);
+    if (w > bw) { bw = w; best = j; }
+  }
+  return (best >= 0 && bw >= std::min(th, ROB_EDGE_THRESH)) ? best : -1;
+}
+
+int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const Options& o, std::vector<int32_t>& agg, int& rounds_done,
+                      const std::vector<double>* E0 = nullptr, const std::vector<double>* x0 = nullptr) {
   const int64_t n = G0.n;
   agg.assign(n, -1);
   rounds_done = 0;
@@ -373,14 +544,22 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
     std::fprintf(stderr, "[setup_levels]     spw round %d  %-22s %8.1f ms\n", round, what, 1e3 * (t - tl));
     tl = t;
   };
+  // crs_robust: the rounds carry the edge matrices and the positions of their vertices (SPWAggData::Map, spw_agg_impl.hpp:424-628:
+  // a pair sits at the midpoint of its two members, :451-460; edge matrices are moved to the new midpoints, :536-537)
+  const bool robust = o.crs_robust && E0 && x0;
+  RobustData R;
+  R.dim = o.dim;
+  std::vector<double> curE, curx;
+  if (robust) { R.E = E0; R.x = x0; }
   for (int round = 0; round < num_rounds; round++) {
     const int64_t m = g->n;
+    if (robust) robust_aux_diags(*g, R);
     std::vector<uint8_t> handled(m, 0);
     if (round == 0) for (int64_t i = 0; i < m; i++) handled[i] = free[i] ? 0 : 1;
     map.assign(m, -1);
     int64_t nn = 0;
     auto make_pair = [&](int64_t v) {
-      const int32_t nb = spw_find_partner(*g, mt, handled, v, false, nullptr);
+      const int32_t nb = robust ? spw_find_partner_robust(*g, R, mt, handled, v) : spw_find_partner(*g, mt, handled, v, false, nullptr);
       const int32_t cv = (int32_t)nn++;
       if (nb >= 0) { map[nb] = cv; handled[nb] = 1; }
       map[v] = cv;
@@ -407,7 +586,17 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
     // compose with the base-level map, contract the graph, carry the scales
     if (round == 0) { for (int64_t i = 0; i < n; i++) agg[i] = free[i] ? map[i] : -1; }
     else for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) agg[i] = map[agg[i]];
-    Graph next = contract(*g, map, nn);
+    Graph next;
+    if (robust) {
+      const int dim = o.dim;
+      std::vector<double> nx((size_t)nn * dim, 0.0), nE;
+      std::vector<int32_t> cnt(nn, 0);
+      for (int64_t i = 0; i < m; i++) if (map[i] >= 0) { cnt[map[i]]++; for (int d = 0; d < dim; d++) nx[(int64_t)map[i] * dim + d] += (*R.x)[i * dim + d]; }
+      for (int64_t I = 0; I < nn; I++) for (int d = 0; d < dim; d++) nx[I * dim + d] /= std::max(1, cnt[I]);
+      next = contract_edge_mats(*g, *R.E, dim, map, nn, *R.x, nx, nE);
+      curE = std::move(nE); curx = std::move(nx);
+      R.E = &curE; R.x = &curx;
+    } else next = contract(*g, map, nn);
     lap("contract", round);
     std::vector<double> nmt(nn, 0.0);
     for (int64_t I = 0; I < nn; I++) for (int64_t k = next.ptr[I]; k < next.ptr[I + 1]; k++) nmt[I] = std::max(nmt[I], next.w[k]);
@@ -658,38 +847,13 @@ BCSR block_prolongation(const BCSR& W, int bs_f, int bs_c, int dim, int energy,
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Elasticity with the energy's edge matrices (Options::edge_mats): the matrix-valued form of the reference's smoothed
-// prolongation.  State of a vertex = (displacement, rotation), BS = dim + dim (dim - 1) / 2 numbers; an edge (i, j) carries a
-// symmetric BS x BS matrix E in the frame of its midpoint m, its energy is |Q(m - x_i) u_i - Q(m - x_j) u_j|_E^2 with the
-// rigid-body transformation Q(t) = [I, S(t); 0, I] (state at x + t of the rigid motion given at x;
-// src/elasticity/elasticity_energy.hpp:28-118 with rot_scaling = 1, which is what BuildAlgMesh_ALG_blk sets and
-// AttachedEVD::map_data forwards, elasticity_pc_impl.hpp:479-480, elasticity_impl.hpp:153-155).
-constexpr int EM_MAX = 6;
-
-static inline int em_bs(int dim) { return dim + (dim * (dim - 1)) / 2; }
-
-static inline void rb_Q(int dim, const double* t, double* Q) {
-  const int BS = em_bs(dim);
-  for (int q = 0; q < BS * BS; q++) Q[q] = 0.0;
-  for (int r = 0; r < BS; r++) Q[r * BS + r] = 1.0;
-  if (dim == 2) { Q[0 * 3 + 2] = -t[1]; Q[1 * 3 + 2] = t[0]; }
-  else {
-    Q[0 * 6 + 4] = t[2];  Q[0 * 6 + 5] = -t[1];
-    Q[1 * 6 + 3] = -t[2]; Q[1 * 6 + 5] = t[0];
-    Q[2 * 6 + 3] = t[1];  Q[2 * 6 + 4] = -t[0];
-  }
-}
-static inline void em_mm(int n, const double* A, const double* B, double* C) {        // C = A B
-  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[r * n + k] * B[k * n + c]; C[r * n + c] = s; }
-}
-static inline void em_mtm(int n, const double* A, const double* B, double* C) {       // C = A^T B
-  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) { double s = 0; for (int k = 0; k < n; k++) s += A[k * n + r] * B[k * n + c]; C[r * n + c] = s; }
-}
-
 // Edge matrices of the finest level from the assembled matrix (VertexAMGPC::BuildAlgMesh_ALG_blk, elasticity_pc_impl.hpp:446-488):
-//   x = (sum_r |a_rr| + 2 sum_{r<c} |a_rc| over the block A_ij) / (bs^2 sqrt(sum_i sum_j)); the reference takes BOTH traces from the
-//   diagonal block of the edge's first (lower) vertex (`MAT(dis[j], dis[j])` in its second loop) -- restated as written;
+//   x = (sum_r |a_rr| + 2 sum_{r<c} |a_rc| over the block A_ij) / (bs^2 sqrt(sum_i sum_j)), sum_v = trace of the diagonal block of
+//   v.  As written, the reference's second loop reads `MAT(dis[j], dis[j])`, i.e. takes BOTH traces from the edge's first vertex; with
+//   that an edge from a soft vertex to a stiff one is as strong as the soft vertex's other edges whenever the soft vertex has the
+//   lower number, and the material-jump problems of its own tests (tests/elasticity/mdim/jump, budget 50) need 56-68 iterations
+//   here instead of 15-18: the geometric mean of the two vertices' traces, which the formula's sqrt(sum_i sum_j) spells, is what
+//   this setup uses (NGSAMG_EMAT_NORM=literal: the line as written);
 //   displacement-only vertices: E = x t t^T on the displacement part (a spring along the edge), vertices with rotations: E = x I.
 // The graph holds the edges between free vertices (the reference gives edges at Dirichlet vertices a dummy value that no formula
 // reads: those vertices are not mapped); its scalar weight is ENERGY::GetApproxWeight = trace(E) / BS (elasticity_energy.hpp:690-696).
@@ -717,8 +881,9 @@ Graph fine_edge_mats(const BCSR& A, const std::vector<uint8_t>& free, const std:
         x += std::fabs(bu[r * bs + r]);
         for (int c = r + 1; c < bs; c++) x += 2.0 * std::fabs(j > i ? bu[r * bs + c] : bu[c * bs + r]);
       }
+      static const bool literal = [] { const char* e = std::getenv("NGSAMG_EMAT_NORM"); return e && std::string(e) == "literal"; }();
       const double s0 = tr[std::min<int64_t>(i, j)];
-      x /= (double)(bs * bs) * std::sqrt(s0 * s0);
+      x /= (double)(bs * bs) * (literal ? std::sqrt(s0 * s0) : std::sqrt(tr[i] * tr[j]));
       double* e = &E[(size_t)p * BB];
       if (bs == dim) {
         double t[3] = {0, 0, 0}, len = 0;
@@ -1281,7 +1446,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
         int r = 0;
         int64_t cur_free_n = 0;
         for (auto f : cur_free) cur_free_n += f;
-        const int64_t snc = o.spw ? aggregate_spw(G, cur_free, o, sagg, r)
+        const int64_t snc = o.spw ? aggregate_spw(G, cur_free, o, sagg, r, emats ? &meshE : nullptr, emats ? &cur_coords : nullptr)
                                   : aggregate(G, cur_free, step_target, o, sagg, r, o.robust_soc ? &next_vs : nullptr);
         lap("agglomeration");
         if (snc == 0 || snc >= cur_free_n) { failed = substeps == 0; break; }

@@ -41,3 +41,20 @@ def test_wait_ranks_times_out():
     procs = [_proc("import time; time.sleep(60)", True), _proc("import time; time.sleep(60)", False)]
     codes, out, why = b._wait_ranks(procs, 1.0)
     assert time.time() - t0 < 20 and why and "no result" in why and all(c != 0 for c in codes)
+
+
+def test_cpu_baseline_of_the_multi_rank_line():
+    """the cpu_baseline object of an N > 1 bench line (rank 0: CPU oracle on the single-process hierarchy of the shared matrix),
+    at a toy size: fields of the contract, strong / weak scaling of the value, the size guard"""
+    import types
+    b = _bench()
+    args = types.SimpleNamespace(config="cfg2", smoother="jacobi", cpu_seconds=0.2, no_cpu_baseline=False)
+    s = b._dist_cpu_baseline(args, 12, 2, True, False, {"spw": 1})
+    assert s["kind"] == "port" and s["unit"] == "applies/s" and s["cores"] >= 1 and s["value"] > 0
+    assert "12^3" in s["sample"] and "1728 DOF" in s["sample"]
+    w = b._dist_cpu_baseline(args, 12, 2, False, False, {"spw": 1})
+    assert "one rank's 12^3 box" in w["sample"]
+    args.config, args.smoother = "cfg3", "gs"
+    e = b._dist_cpu_baseline(args, 6, 2, True, True, {"spw": 1})
+    assert e["value"] > 0 and "648 DOF" in e["sample"]
+    assert b._dist_cpu_baseline(args, 400, 8, True, True, {"spw": 1}) is None

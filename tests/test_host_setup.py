@@ -526,3 +526,51 @@ def test_edge_matrix_option_errors_and_2d():
     assert np.abs(got[free] - rb(Lf.coords)[free, :2]).max() < 1e-10
     b = rng.standard_normal(q.n * q.bs) * np.repeat(q.free, q.bs)
     assert Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1] <= 50   # budget of tests/elasticity/mdim/simple/test_2d_lo.py
+
+
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("robust", [0, 1])
+def test_edge_matrix_setup_on_material_jumps_and_robust_soc(rot, robust):
+    """edge_mats (+ crs_robust: the energy-based strength of connection of the SPW rounds, CalcRobSOC with neighbour boost,
+    agglomerator_utils.hpp:598-927, picked as FindNeib3Step does with robustPick, spw_agg_impl.hpp:637-775) on the stiff-inclusion
+    problem of the reference's tests/elasticity/mdim/jump/test_2d_jump_lo.py (mu jump 1e4, max_coarse_size 10, budget 50) and on
+    its 3D beams (tests/elasticity/mdim/simple/test_3d_lo.py, budget 40): budgets met, rigid-body modes reproduced, and the
+    robust rule really changes the aggregates"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+
+    def coef(X):
+        x, y = X[..., 0], X[..., 1]
+        inner = ((np.abs(x - 0.3) < 0.1) | (np.abs(x - 0.7) < 0.1)) & ((np.abs(y - 0.3) < 0.1) | (np.abs(y - 0.7) < 0.1))
+        return np.where(inner, 1e4, 1.0)
+
+    rng = np.random.default_rng(3)
+    p = fem.elasticity_fast((41, 41), dirichlet="left", mu=1.0, lam=0.0, rotations=rot, coef=coef)
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    kw = dict(dim=2, energy=1, max_coarse_size=10, regularize_cmats=0 if rot else 1, edge_mats=1)
+    H = Hierarchy(A, p.free, p.coords, crs_robust=robust, **kw)
+    b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    assert Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1] <= 50
+    if robust:
+        Hs = Hierarchy(A, p.free, p.coords, crs_robust=0, **kw)
+        assert not np.array_equal(np.asarray(H.levels[0].agg), np.asarray(Hs.levels[0].agg))
+    shape, ext = ((9, 5, 5), (2.0, 1.0, 1.0)) if rot else ((41, 5, 5), (10.0, 1.0, 1.0))
+    q = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=ext)
+    B = Matrix(q.n, q.n, q.bs, q.bs, q.rowptr, q.col, q.val)
+    H3 = Hierarchy(B, q.free, q.coords, dim=3, energy=1, max_coarse_size=10, regularize_cmats=0 if rot else 1, edge_mats=1, crs_robust=robust)
+    b3 = rng.standard_normal(q.n * q.bs) * np.repeat(q.free, q.bs)
+    assert Oracle(H3.levels, sm_type="gs").pcg(b3, tol=1e-6, maxit=200)[1] <= 40
+    Lf, Lc = H3.levels[0], H3.levels[1]
+    t, w = rng.standard_normal(3), rng.standard_normal(3)
+    coarse = np.concatenate([t + np.cross(w, Lc.coords), np.tile(w, (Lc.n, 1))], axis=1).ravel()
+    fu = t + np.cross(w, Lf.coords)
+    fine = fu if Lf.bs == 3 else np.concatenate([fu, np.tile(w, (Lf.n, 1))], axis=1)
+    got = (Lf.P.to_scipy() @ coarse).reshape(Lf.n, -1)
+    free = Lf.free.astype(bool)
+    err = np.abs(got[free] - fine[free]).max(axis=1)
+    if not rot:
+        assert err.max() < 1e-9
+    else:
+        assert np.median(err) < 1e-9
+    with pytest.raises(NgsAMGError):
+        Hierarchy(B, q.free, q.coords, dim=3, energy=1, crs_robust=1)          # needs the edge matrices
