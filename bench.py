@@ -412,6 +412,8 @@ def main():
     ap.add_argument("--smoother", default="jacobi", choices=["jacobi", "gs", "gs_mc"],
                     help="gs = Gauss-Seidel in the block-hybrid form (one launch per sweep); gs_mc = multicolour Gauss-Seidel (one launch per colour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--edge-mats", type=int, default=0, help="cfg3 / cfg5: 1 = the energy's edge matrices + matrix-valued smoothed prolongation "
+                    "(ngs_amg_edge_mats; general blocks in P instead of w Q(t)), 2 = also the energy-based strength of connection (ngs_amg_crs_robust)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--ops", action="store_true", help="print HIP-event timings of the individual kernels per level")
@@ -508,6 +510,8 @@ def main():
     # "continuity" (below) = the hierarchy of rounds 1-3 (--hierarchy aaf: agglomerate until the level has shrunk to
     # first_aaf / aaf; OC 1.09), kept only so that the rounds stay comparable.
     hier_kw = {"spw": 1} if args.hierarchy == "spw" else {"spw": 0, "enable_multistep": int(args.multistep)}
+    if args.edge_mats and args.config in ("cfg3", "cfg5"):
+        hier_kw.update({"edge_mats": 1, "crs_robust": int(args.edge_mats > 1)})
     t0 = time.time()
     if args.config == "cfg2":
         prob = fem.poisson_fast((nv, nv, nv), dirichlet="right|top", jitter=0.2, seed=1)
@@ -894,7 +898,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             # (one GPU: the N = 1 point of the strong-scaling series bench.py --gpus N runs for cfg 2 / cfg 4, of the weak one for cfg 3 / cfg 5)
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl + (" [enable_multistep]" if args.multistep else ""),
+            "config": {"workload": wl + (" [enable_multistep]" if args.multistep else "")
+                                   + ((" [edge_mats: matrix-valued smoothed prolongation" + (", crs_robust" if args.edge_mats > 1 else "") + "]") if hier_kw.get("edge_mats") else ""),
                        "level_sizes": [int(l.n) for l in H.levels],
                        "levels": H.n_levels, "operator_complexity": round(H.operator_complexity(), 3),
                        "nnz_level0": lv0.A.nnz, "graph_replay": not args.no_graph,
