@@ -170,11 +170,12 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
       C.vs[I] = std::max(C.vs[I], m);
     }
   }
+  // two passes over the members' edges (count, then fill at the final offsets): growing per-thread result vectors instead costs
+  // 5-10x the traversal itself in page faults of the reallocated buffers (1.7 s of a 2.5 s agglomeration at 2 M vertices)
   const int nt = std::min(omp_get_max_threads(), 32);   // each thread owns dense markers of size n_cols: bound the memory
-  std::vector<std::vector<int32_t>> tadj(nt);
-  std::vector<std::vector<double>> tw(nt);
   std::vector<int64_t> len(nn, 0), tstart(nt + 1);
   for (int t = 0; t <= nt; t++) tstart[t] = (nn * t) / nt;
+  C.ptr.assign(nn + 1, 0);
 #pragma omp parallel num_threads(nt)
   {
     int t = omp_get_thread_num();
@@ -183,6 +184,26 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
     std::vector<int32_t> cols;
     std::vector<double> acc;
     std::vector<int32_t> order;
+    for (int64_t I = tstart[t]; I < tstart[t + 1]; I++) {
+      int64_t c = 0;
+      for (int64_t m = mptr[I]; m < mptr[I + 1]; m++) {
+        int32_t i = mem[m];
+        for (int64_t k = G.ptr[i]; k < G.ptr[i + 1]; k++) {
+          int32_t J = map[G.adj[k]];
+          if (J < 0 || J == I) continue;
+          if (owner[J] != I) { owner[J] = I; c++; }
+        }
+      }
+      len[I] = c;
+    }
+#pragma omp barrier
+#pragma omp single
+    {
+      for (int64_t I = 0; I < nn; I++) C.ptr[I + 1] = C.ptr[I] + len[I];
+      C.adj.resize(C.ptr[nn]);
+      C.w.resize(C.ptr[nn]);
+    }
+    std::fill(owner.begin(), owner.end(), (int64_t)-1);
     for (int64_t I = tstart[t]; I < tstart[t + 1]; I++) {
       cols.clear(); acc.clear();
       for (int64_t m = mptr[I]; m < mptr[I + 1]; m++) {
@@ -197,18 +218,9 @@ Graph contract(const Graph& G, const std::vector<int32_t>& map, int64_t nn) {
       order.resize(cols.size());
       std::iota(order.begin(), order.end(), 0);
       std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cols[a] < cols[b]; });
-      for (auto q : order) { tadj[t].push_back(cols[q]); tw[t].push_back(acc[q]); }
-      len[I] = (int64_t)cols.size();
+      int64_t p = C.ptr[I];
+      for (auto q : order) { C.adj[p] = cols[q]; C.w[p] = acc[q]; p++; }
     }
-  }
-  C.ptr.assign(nn + 1, 0);
-  for (int64_t I = 0; I < nn; I++) C.ptr[I + 1] = C.ptr[I] + len[I];
-  C.adj.resize(C.ptr[nn]);
-  C.w.resize(C.ptr[nn]);
-  for (int t = 0; t < nt; t++) {
-    int64_t off = C.ptr[tstart[t]];
-    std::copy(tadj[t].begin(), tadj[t].end(), C.adj.begin() + off);
-    std::copy(tw[t].begin(), tw[t].end(), C.w.begin() + off);
   }
   return C;
 }
