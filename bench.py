@@ -321,7 +321,15 @@ def _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw):
         orc.apply(b, xo)
     cpu_t = (time.perf_counter() - tc0) / reps
     nnz = [int(L.A.nnz) for L in H.levels]
-    return {"value": round((1.0 if strong else 1.0 / world) / cpu_t, 3), "unit": "applies/s", "cores": int(cores), "kind": "port",
+    # the single-process hierarchy beside the rank-partitioned one (`hierarchy` of the line): sizes, OC, PCG iterations to 1e-8 --
+    # what changes in the OPERATOR between the N = 1 point of a scaling curve and the N > 1 points
+    sp = {"level_sizes": [int(L.n) for L in H.levels], "operator_complexity": round(sum(nnz) / max(1, nnz[0]), 3)}
+    if cpu_t * 60 < 60.0:                    # ~2.5 oracle applications per PCG iteration, <= 1 minute
+        try:
+            sp["pcg_iterations"] = int(orc.pcg(b, tol=1e-8, maxit=200)[1])
+        except Exception as e:
+            log(f"oracle PCG on the single-process hierarchy failed: {e!r}")
+    return {"value": round((1.0 if strong else 1.0 / world) / cpu_t, 3), "single_process_hierarchy": sp, "unit": "applies/s", "cores": int(cores), "kind": "port",
             "sample": (f"{reps} V-cycle applications of the single-process hierarchy of "
                        + (f"the same global {nv}^3 matrix" if strong else f"one rank's {nv}^3 box (value = 1 / ({world} x time): a CPU runs all {world} boxes)")
                        + f" ({prob.n * prob.bs} DOF, {H.n_levels} levels, OC {sum(nnz) / max(1, nnz[0]):.3f}; oracle/oracle.c, OpenMP over rows, "

@@ -52,6 +52,8 @@ def test_cpu_baseline_of_the_multi_rank_line():
     s = b._dist_cpu_baseline(args, 12, 2, True, False, {"spw": 1})
     assert s["kind"] == "port" and s["unit"] == "applies/s" and s["cores"] >= 1 and s["value"] > 0
     assert "12^3" in s["sample"] and "1728 DOF" in s["sample"]
+    sp = s["single_process_hierarchy"]
+    assert sp["level_sizes"][0] == 1728 and sp["operator_complexity"] > 1.0 and 0 < sp["pcg_iterations"] < 60
     w = b._dist_cpu_baseline(args, 12, 2, False, False, {"spw": 1})
     assert "one rank's 12^3 box" in w["sample"]
     args.config, args.smoother = "cfg3", "gs"
