@@ -404,7 +404,7 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
 //       1e-10 of its largest count as kernel)
 //   FindNeib3Step with robustPick (spw_agg_impl.hpp:637-775): the neighbours that pass the scalar filter are re-weighted with this
 //       number, the strongest is taken if it reaches min(0.25 max scalar soc, edge_thresh = 0.025)
-// Not restated: the aggregate-wide check (checkBigSOC, off by default, spw_agg.hpp:31) and the robust form of the orphan round.
+// Not restated: the aggregate-wide check (checkBigSOC, off by default, spw_agg.hpp:31).
 constexpr double ROB_EDGE_THRESH = 0.025;       // agglomerator.hpp:16
 constexpr double ROB_ZERO_EV = 1e2 * 1e-12;     // 1e2 RelZeroTol (agglomerator_utils.hpp:923)
 
@@ -470,13 +470,14 @@ static void robust_aux_diags(const Graph& g, RobustData& R) {
   }
 }
 
-static double robust_soc(const Graph& g, const RobustData& R, int64_t i, int64_t k) {
+// the edge's matrix with the neighbour boost, in the frame of the edge's midpoint
+static void robust_boosted_edge(const Graph& g, const RobustData& R, int64_t i, int64_t k, double* E, double* mid) {
   const int dim = R.dim, BS = em_bs(dim), BB = BS * BS;
   const int32_t j = g.adj[k];
   const std::vector<double>& X = *R.x;
-  double E[EM_MAX * EM_MAX], Q[EM_MAX * EM_MAX], Ein[EM_MAX * EM_MAX], Ejn[EM_MAX * EM_MAX], H[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+  double Q[EM_MAX * EM_MAX], Ein[EM_MAX * EM_MAX], Ejn[EM_MAX * EM_MAX], H[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
   std::copy(&(*R.E)[(size_t)k * BB], &(*R.E)[(size_t)k * BB] + BB, E);
-  double mid[3] = {0, 0, 0};
+  for (int d = 0; d < 3; d++) mid[d] = 0.0;
   for (int d = 0; d < dim; d++) mid[d] = 0.5 * (X[i * dim + d] + X[(int64_t)j * dim + d]);
   // neighbour boost over the common neighbours
   for (int64_t ki = g.ptr[i]; ki < g.ptr[i + 1]; ki++) {
@@ -498,6 +499,14 @@ static double robust_soc(const Graph& g, const RobustData& R, int64_t i, int64_t
     em_qtmq(BS, Q, H, T);
     for (int x = 0; x < BB; x++) E[x] += T[x];
   }
+}
+
+static double robust_soc(const Graph& g, const RobustData& R, int64_t i, int64_t k) {
+  const int dim = R.dim, BS = em_bs(dim), BB = BS * BS;
+  const int32_t j = g.adj[k];
+  const std::vector<double>& X = *R.x;
+  double E[EM_MAX * EM_MAX], Q[EM_MAX * EM_MAX], mid[3];
+  robust_boosted_edge(g, R, i, k, E, mid);
   double di[EM_MAX * EM_MAX], dj[EM_MAX * EM_MAX], C[EM_MAX * EM_MAX];
   double t[3] = {0, 0, 0};
   for (int d = 0; d < dim; d++) t[d] = X[i * dim + d] - mid[d];
@@ -526,6 +535,29 @@ static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, cons
     const double den = std::sqrt(mt[v] * mt[j]);
     if (!(den > 0.0) || g.w[k] / den < th) continue;
     const double w = robust_soc(g, R, v, k);
+    if (w > bw) { bw = w; best = j; }
+  }
+  return (best >= 0 && bw >= std::min(th, ROB_EDGE_THRESH)) ? best : -1;
+}
+
+// orphan round (FindNeighborToJoin with robustPick, spw_agg_impl.hpp:870-940): scalar filter w_Oj / maxTrOD_O >= 0.25 max, survivors
+// re-weighted with CalcRobJoinSOC (agglomerator_utils.hpp:1086-1126): the boosted edge matrix against the ORPHAN's aux diagonal
+// alone (smallest generalised eigenvalue; the reference takes the diagonal in the orphan's own frame -- restated as written)
+static int32_t spw_find_join_robust(const Graph& g, const RobustData& R, const std::vector<double>& mt, const std::vector<uint8_t>& joinable, int64_t v) {
+  const int BS = em_bs(R.dim), BB = BS * BS;
+  if (!(mt[v] > 0.0)) return -1;
+  double mx = 0.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) mx = std::max(mx, g.w[k] / mt[v]);
+  if (!(mx > 0.0)) return -1;
+  const double th = SPW_REL_THRESH * mx;
+  int32_t best = -1;
+  double bw = -1.0;
+  for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
+    const int32_t j = g.adj[k];
+    if (!joinable[j] || g.w[k] / mt[v] < th) continue;
+    double E[EM_MAX * EM_MAX], mid[3];
+    robust_boosted_edge(g, R, v, k, E, mid);
+    const double w = robust_pair_soc(BS, &R.aux[(size_t)v * BB], E);
     if (w > bw) { bw = w; best = j; }
   }
   return (best >= 0 && bw >= std::min(th, ROB_EDGE_THRESH)) ? best : -1;
@@ -629,9 +661,10 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   std::vector<uint8_t> joinable(ncur, 0);
   for (int64_t I = 0; I < ncur; I++) { if (size[I] > 1) { joinable[I] = 1; fin[I] = (int32_t)nn++; } else any_orphan = true; }
   if (o.spw_orphan_round && any_orphan) {
+    if (robust) robust_aux_diags(cur, R);
     for (int64_t I = ncur - 1; I >= 0; I--) {
       if (joinable[I]) continue;
-      const int32_t J = spw_find_partner(cur, mt, joinable, I, true, &joinable);
+      const int32_t J = robust ? spw_find_join_robust(cur, R, mt, joinable, I) : spw_find_partner(cur, mt, joinable, I, true, &joinable);
       fin[I] = J >= 0 ? fin[J] : (int32_t)nn++;
     }
   } else {
