@@ -73,6 +73,9 @@ typedef struct amgh_options {
                              /*   elasticity_pc_impl.hpp:55), default 0, needs edge_mats: the SPW pairing rounds pick the partner by the          */
                              /*   energy-based strength of connection (CalcRobSOC with neighbour boost, agglomerator_utils.hpp:598-927;          */
                              /*   FindNeib3Step with robustPick, spw_agg_impl.hpp:637-775)                                                        */
+  int32_t spw_cbs;           /* ngs_amg_spw_cbs (checkBigSOC, spw_agg.hpp:31, 57; default 0), needs crs_robust: from the second pairing round on a   */
+                             /*   partner must also pass the aggregate-wide stability check of the two vertices' base-level members                */
+                             /*   (AggregateWideStabilityCheck, agglomerator_utils.hpp:392-539)                                                    */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -404,7 +404,6 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
 //       1e-10 of its largest count as kernel)
 //   FindNeib3Step with robustPick (spw_agg_impl.hpp:637-775): the neighbours that pass the scalar filter are re-weighted with this
 //       number, the strongest is taken if it reaches min(0.25 max scalar soc, edge_thresh = 0.025)
-// Not restated: the aggregate-wide check (checkBigSOC, off by default, spw_agg.hpp:31).
 constexpr double ROB_EDGE_THRESH = 0.025;       // agglomerator.hpp:16
 constexpr double ROB_ZERO_EV = 1e2 * 1e-12;     // 1e2 RelZeroTol (agglomerator_utils.hpp:923)
 
@@ -519,7 +518,87 @@ static double robust_soc(const Graph& g, const RobustData& R, int64_t i, int64_t
   return robust_pair_soc(BS, C, E);
 }
 
-static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, const std::vector<double>& mt, const std::vector<uint8_t>& handled, int64_t v) {
+// Aggregate-wide stability check (checkBigSOC: AggregateWideStabilityCheck, agglomerator_utils.hpp:392-539), used from the second
+// pairing round on when ngs_amg_spw_cbs is set (spw_agg.hpp:31, 57; off by default): for the union of the BASE-level members of two
+// round vertices, A = the replacement matrix of the base-level edges inside the union, M = the block diagonal of the base-level aux
+// diagonals, P = the rigid-body modes of the union; the pair is viable if A - rho (M - M P (P^T M P)^+ P^T M) is positive
+// semi-definite (the reference tests that with a pivoted Cholesky factorisation, here with the smallest eigenvalue; its assembly of
+// the second block row reuses Q_i^T E where the symmetric replacement matrix has Q_j^T E -- the symmetric matrix is assembled here).
+struct BigSocData {
+  const Graph* g0 = nullptr;
+  const std::vector<double>* E0 = nullptr;
+  const std::vector<double>* x0 = nullptr;
+  std::vector<double> aux0;                 // base-level aux diagonals
+  std::vector<int64_t> mptr;                // members (base vertices, ascending) of the current round's vertices
+  std::vector<int32_t> mem;
+  int dim = 3;
+};
+
+static bool big_soc_ok(const BigSocData& B, int32_t vi, int32_t vj, double rho) {
+  const int dim = B.dim, BS = em_bs(dim), BB = BS * BS;
+  std::vector<int32_t> mems(B.mem.begin() + B.mptr[vi], B.mem.begin() + B.mptr[vi + 1]);
+  mems.insert(mems.end(), B.mem.begin() + B.mptr[vj], B.mem.begin() + B.mptr[vj + 1]);
+  std::sort(mems.begin(), mems.end());
+  const int n = (int)mems.size();
+  if (n < 3) return true;
+  const int N = BS * n;
+  const Graph& g = *B.g0;
+  const std::vector<double>& X = *B.x0;
+  std::vector<double> A((size_t)N * N, 0.0), M((size_t)N * N, 0.0), P((size_t)N * BS, 0.0);
+  double Qi[EM_MAX * EM_MAX], Qj[EM_MAX * EM_MAX], QiE[EM_MAX * EM_MAX], QjE[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+  auto add = [&](int a, int b, double sgn, const double* blk) { for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) A[(size_t)(a * BS + r) * N + b * BS + c] += sgn * blk[r * BS + c]; };
+  for (int a = 0; a < n; a++) {
+    const int32_t vK = mems[a];
+    for (int64_t k = g.ptr[vK]; k < g.ptr[vK + 1]; k++) {
+      const int32_t vJ = g.adj[k];
+      if (vJ >= vK) continue;
+      auto it = std::lower_bound(mems.begin(), mems.end(), vJ);
+      if (it == mems.end() || *it != vJ) continue;
+      const int b = (int)(it - mems.begin());
+      double ti[3] = {0, 0, 0}, tj[3] = {0, 0, 0};
+      for (int d = 0; d < dim; d++) { const double mid = 0.5 * (X[(int64_t)vK * dim + d] + X[(int64_t)vJ * dim + d]); ti[d] = mid - X[(int64_t)vK * dim + d]; tj[d] = mid - X[(int64_t)vJ * dim + d]; }
+      rb_Q(dim, ti, Qi);
+      rb_Q(dim, tj, Qj);
+      em_mtm(BS, Qi, &(*B.E0)[(size_t)k * BB], QiE);
+      em_mtm(BS, Qj, &(*B.E0)[(size_t)k * BB], QjE);
+      em_mm(BS, QiE, Qi, T); add(a, a, 1.0, T);
+      em_mm(BS, QiE, Qj, T); add(a, b, -1.0, T);
+      em_mm(BS, QjE, Qi, T); add(b, a, -1.0, T);
+      em_mm(BS, QjE, Qj, T); add(b, b, 1.0, T);
+    }
+  }
+  for (int a = 0; a < n; a++) {
+    const double* d = &B.aux0[(size_t)mems[a] * BB];
+    for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) M[(size_t)(a * BS + r) * N + a * BS + c] = d[r * BS + c];
+    double t[3] = {0, 0, 0};
+    for (int dd = 0; dd < dim; dd++) t[dd] = X[(int64_t)mems[a] * dim + dd] - X[(int64_t)mems[0] * dim + dd];
+    rb_Q(dim, t, Qi);
+    for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) P[(size_t)(a * BS + r) * BS + c] = Qi[r * BS + c];
+  }
+  // PTM = P^T M (BS x N), PTMP = PTM P
+  std::vector<double> PTM((size_t)BS * N, 0.0), W((size_t)BS * N, 0.0);
+  for (int r = 0; r < BS; r++) for (int c = 0; c < N; c++) { double sm = 0; for (int q = 0; q < N; q++) sm += P[(size_t)q * BS + r] * M[(size_t)q * N + c]; PTM[(size_t)r * N + c] = sm; }
+  double PTMP[EM_MAX * EM_MAX];
+  for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) { double sm = 0; for (int q = 0; q < N; q++) sm += PTM[(size_t)r * N + q] * P[(size_t)q * BS + c]; PTMP[r * BS + c] = sm; }
+  pseudo_inverse_with_tol(PTMP, BS);
+  for (int r = 0; r < BS; r++) for (int c = 0; c < N; c++) { double sm = 0; for (int q = 0; q < BS; q++) sm += PTMP[r * BS + q] * PTM[(size_t)q * N + c]; W[(size_t)r * N + c] = sm; }
+  double maxd = 0;
+  for (int r = 0; r < N; r++) for (int c = 0; c < N; c++) {
+    double sm = 0;
+    for (int q = 0; q < BS; q++) sm += PTM[(size_t)q * N + r] * W[(size_t)q * N + c];
+    A[(size_t)r * N + c] -= rho * (M[(size_t)r * N + c] - sm);
+  }
+  for (int r = 0; r < N; r++) for (int c = r + 1; c < N; c++) { const double m = 0.5 * (A[(size_t)r * N + c] + A[(size_t)c * N + r]); A[(size_t)r * N + c] = A[(size_t)c * N + r] = m; }
+  for (int r = 0; r < N; r++) maxd = std::max(maxd, std::fabs(A[(size_t)r * N + r]));
+  std::vector<double> ev(N), V((size_t)N * N);
+  sym_eig(A.data(), N, ev.data(), V.data());
+  double lmin = ev[0];
+  for (int r = 1; r < N; r++) lmin = std::min(lmin, ev[r]);
+  return lmin >= -1e-10 * maxd;
+}
+
+static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, const std::vector<double>& mt, const std::vector<uint8_t>& handled, int64_t v,
+                                       const BigSocData* big = nullptr) {
   double mx = 0.0;
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
     const double den = std::sqrt(mt[v] * mt[g.adj[k]]);
@@ -529,15 +608,25 @@ static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, cons
   const double th = SPW_REL_THRESH * mx;
   int32_t best = -1;
   double bw = -1.0;
+  std::vector<std::pair<double, int32_t>> cand;
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
     const int32_t j = g.adj[k];
     if (handled[j]) continue;
     const double den = std::sqrt(mt[v] * mt[j]);
     if (!(den > 0.0) || g.w[k] / den < th) continue;
     const double w = robust_soc(g, R, v, k);
+    if (big) cand.push_back({w, j});
     if (w > bw) { bw = w; best = j; }
   }
-  return (best >= 0 && bw >= std::min(th, ROB_EDGE_THRESH)) ? best : -1;
+  const double wth = std::min(th, ROB_EDGE_THRESH);
+  if (!big) return (best >= 0 && bw >= wth) ? best : -1;
+  // strongest first, the first one that also passes the aggregate-wide check (rho = min(robust threshold, absBigThresh = edge_thresh))
+  std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  for (const auto& c : cand) {
+    if (c.first < wth) break;
+    if (big_soc_ok(*big, (int32_t)v, c.second, wth)) return c.second;
+  }
+  return -1;
 }
 
 // orphan round (FindNeighborToJoin with robustPick, spw_agg_impl.hpp:870-940): scalar filter w_Oj / maxTrOD_O >= 0.25 max, survivors
@@ -595,15 +684,27 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   R.dim = o.dim;
   std::vector<double> curE, curx;
   if (robust) { R.E = E0; R.x = x0; }
+  const bool cbs = robust && o.spw_cbs;
+  BigSocData big;
   for (int round = 0; round < num_rounds; round++) {
     const int64_t m = g->n;
     if (robust) robust_aux_diags(*g, R);
+    if (cbs && round == 0) { big.g0 = &G0; big.E0 = E0; big.x0 = x0; big.dim = o.dim; big.aux0 = R.aux; }
+    if (cbs && round > 0) {        // base-level members of this round's vertices
+      big.mptr.assign(m + 1, 0);
+      for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) big.mptr[agg[i] + 1]++;
+      for (int64_t I = 0; I < m; I++) big.mptr[I + 1] += big.mptr[I];
+      big.mem.resize(big.mptr[m]);
+      std::vector<int64_t> pos(big.mptr.begin(), big.mptr.end() - 1);
+      for (int64_t i = 0; i < n; i++) if (agg[i] >= 0) big.mem[pos[agg[i]]++] = (int32_t)i;
+    }
+    const BigSocData* bigp = (cbs && round > 0) ? &big : nullptr;
     std::vector<uint8_t> handled(m, 0);
     if (round == 0) for (int64_t i = 0; i < m; i++) handled[i] = free[i] ? 0 : 1;
     map.assign(m, -1);
     int64_t nn = 0;
     auto make_pair = [&](int64_t v) {
-      const int32_t nb = robust ? spw_find_partner_robust(*g, R, mt, handled, v) : spw_find_partner(*g, mt, handled, v, false, nullptr);
+      const int32_t nb = robust ? spw_find_partner_robust(*g, R, mt, handled, v, bigp) : spw_find_partner(*g, mt, handled, v, false, nullptr);
       const int32_t cv = (int32_t)nn++;
       if (nb >= 0) { map[nb] = cv; handled[nb] = 1; }
       map[v] = cv;

@@ -27,6 +27,7 @@ struct Options {
   int prol_type = -1;            // ngs_amg_prol_type: 0 piecewise, 1 aux_smoothed, 2 semi_aux_smoothed (reference default), 3 own rule; -1: 2 with spw, else 3
   int sp_max_per_row_classic = 5;   // vertex_factory_impl.hpp:71
   int crs_robust = 0;            // ngs_amg_crs_robust: energy-based strength of connection in the SPW rounds (needs edge_mats; agglomerator.hpp:18)
+  int spw_cbs = 0;               // ngs_amg_spw_cbs: aggregate-wide stability check from the second pairing round on (needs crs_robust; spw_agg.hpp:31)
   int edge_mats = 0;             // elasticity: carry the energy's edge matrices, matrix-valued smoothed prolongation (amgh.h)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level

@@ -574,3 +574,33 @@ def test_edge_matrix_setup_on_material_jumps_and_robust_soc(rot, robust):
         assert np.median(err) < 1e-9
     with pytest.raises(NgsAMGError):
         Hierarchy(B, q.free, q.coords, dim=3, energy=1, crs_robust=1)          # needs the edge matrices
+
+
+def test_aggregate_wide_stability_check_of_the_spw_rounds():
+    """ngs_amg_spw_cbs (checkBigSOC, spw_agg.hpp:31, off by default in the reference): from the second pairing round on a pair must
+    pass AggregateWideStabilityCheck (agglomerator_utils.hpp:392-539) on the union of its base-level members.  With full-rank edge
+    matrices (rotations: E = x I) the pairs the robust rule picks pass it; with the rank-one springs of a displacement-only level
+    the replacement matrix of a few vertices is far weaker than their aux diagonals and the check keeps aggregates small -- slower
+    coarsening, still a convergent hierarchy inside the reference's budget."""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    rng = np.random.default_rng(4)
+    for rot, shape, ext in ((True, (9, 5, 5), (2.0, 1.0, 1.0)), (False, (21, 5, 5), (5.0, 1.0, 1.0))):
+        p = fem.elasticity_fast(shape, dirichlet="left", mu=1.0, lam=0.0, rotations=rot, extent=ext)
+        A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+        kw = dict(dim=3, energy=1, max_coarse_size=10, regularize_cmats=0 if rot else 1, edge_mats=1, crs_robust=1)
+        H0 = Hierarchy(A, p.free, p.coords, **kw)
+        H1 = Hierarchy(A, p.free, p.coords, spw_cbs=1, **kw)
+        assert H1.levels[1].n >= H0.levels[1].n
+        if rot:
+            assert H1.levels[1].n <= 1.2 * H0.levels[1].n
+        else:
+            assert H1.levels[1].n > 1.5 * H0.levels[1].n
+        b = rng.standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+        assert Oracle(H1.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1] <= 40
+        for l in range(H1.n_levels - 1):
+            Lf, Lc = H1.levels[l], H1.levels[l + 1]
+            P, Ac = Lf.P.to_scipy(), Lc.A.to_scipy()
+            assert abs(Ac - P.T @ Lf.A.to_scipy() @ P).max() < 1e-10 * abs(Ac).max()
+    with pytest.raises(NgsAMGError):
+        Hierarchy(A, p.free, p.coords, dim=3, energy=1, edge_mats=1, spw_cbs=1)          # belongs to crs_robust
