@@ -76,6 +76,9 @@ typedef struct amgh_options {
   int32_t spw_cbs;           /* ngs_amg_spw_cbs (checkBigSOC, spw_agg.hpp:31, 57; default 0), needs crs_robust: from the second pairing round on a   */
                              /*   partner must also pass the aggregate-wide stability check of the two vertices' base-level members                */
                              /*   (AggregateWideStabilityCheck, agglomerator_utils.hpp:392-539)                                                    */
+  int32_t sp_improve_its;    /* ngs_amg_sp_improve_its (0; vertex_factory_impl.hpp:1745-1831, 2350-2420): smoothing steps on the smoothed             */
+                             /*   prolongation that keep its graph: P_i -= omega D^+ (A P)_i with the entries outside the row's pattern moved to the   */
+                             /*   row's own aggregate (through the rigid-body transformation for elasticity)                                          */
 } amgh_options;
 
 typedef struct amgh_level {

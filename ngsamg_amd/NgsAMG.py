@@ -319,7 +319,7 @@ class _AMGPreconditioner:
         dim = int(f.get("dim", self._dim))
         opts = {k: f[k] for k in ("max_levels", "max_coarse_size", "first_aaf", "aaf", "enable_sp", "sp_omega",
                                   "sp_max_per_row", "sp_min_frac", "soc_thresh", "max_rounds", "log_level", "enable_multistep",
-                                  "robust_soc", "spw", "spw_rounds", "spw_orphan_treatment", "prol_type", "sp_max_per_row_classic", "edge_mats", "crs_robust", "spw_cbs") if k in f}
+                                  "robust_soc", "spw", "spw_rounds", "spw_orphan_treatment", "prol_type", "sp_max_per_row_classic", "edge_mats", "crs_robust", "spw_cbs", "sp_improve_its") if k in f}
         if self._energy == 1:
             rots = A.br > dim
             opts["regularize_cmats"] = int(f.get("regularize_cmats", not rots))   # elasticity_pc_impl.hpp:134-139

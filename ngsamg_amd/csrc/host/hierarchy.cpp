@@ -1277,6 +1277,66 @@ BCSR prolongation_edge_mats(const BCSR* A, const Graph& G, const std::vector<dou
   return P;
 }
 
+
+// sp_improve_its (ngs_amg_sp_improve_its, off by default; SemiAuxSProlMap's last stage with ImproveSProlRow,
+// vertex_factory_impl.hpp:1745-1831, 2350-2420): further smoothing steps on the prolongation WITHOUT growing its graph.  Per step
+// AP = A P; a row with more than one entry becomes P_i - omega D^+ (AP)_i E with D = A_ii (pseudo-inverse with tolerance for
+// blocks) and the coarse extension E: an entry of (AP)_i in a column c of the row's own pattern stays where it is, an entry outside
+// the pattern is moved to the row's own aggregate I through the rigid-body transformation Q(X_c - X_I) (identity for H1).
+void improve_prolongation(const BCSR& A, BCSR& P, const std::vector<int32_t>& agg, const std::vector<double>& xc, int dim, int energy,
+                          double omega, int its) {
+  const int br = P.br, bc = P.bc, bb = br * bc;
+  if (A.br != br || A.bc != br) throw Error("improve_prolongation: block shapes do not match");
+  const bool rb = energy == 1 && bc == em_bs(dim);
+  for (int it = 0; it < its; it++) {
+    const BCSR AP = matmul(A, P);
+#pragma omp parallel
+    {
+      std::vector<double> up, d(br * br), T(bb), T2(bb);
+      double Q[EM_MAX * EM_MAX];
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < P.n_rows; i++) {
+        const int64_t p0 = P.rowptr[i], len = P.rowptr[i + 1] - p0;
+        if (len < 2) continue;
+        const int32_t I = agg[i];
+        const int32_t* pc = &P.col[p0];
+        const int32_t* itI = std::lower_bound(pc, pc + len, I);
+        if (itI == pc + len || *itI != I) continue;
+        const int64_t posI = itI - pc;
+        bool have_d = false;
+        for (int64_t k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) if (A.col[k] == i) { std::copy(&A.val[(size_t)k * br * br], &A.val[(size_t)k * br * br] + br * br, d.begin()); have_d = true; break; }
+        if (!have_d) continue;
+        if (br == 1) { if (d[0] == 0.0) continue; d[0] = 1.0 / d[0]; }
+        else pseudo_inverse_with_tol(d.data(), br);
+        up.assign((size_t)len * bb, 0.0);
+        for (int64_t k = AP.rowptr[i]; k < AP.rowptr[i + 1]; k++) {
+          const int32_t c = AP.col[k];
+          const double* v = &AP.val[(size_t)k * bb];
+          for (int r = 0; r < br; r++) for (int q = 0; q < bc; q++) { double sm = 0; for (int x = 0; x < br; x++) sm += d[r * br + x] * v[x * bc + q]; T[r * bc + q] = sm; }
+          const int32_t* itc = std::lower_bound(pc, pc + len, c);
+          if (itc != pc + len && *itc == c) {
+            double* u = &up[(size_t)(itc - pc) * bb];
+            for (int x = 0; x < bb; x++) u[x] -= omega * T[x];
+          } else {
+            double* u = &up[(size_t)posI * bb];
+            if (rb) {
+              double t[3] = {0, 0, 0};
+              for (int dd = 0; dd < dim; dd++) t[dd] = xc[(int64_t)c * dim + dd] - xc[(int64_t)I * dim + dd];
+              rb_Q(dim, t, Q);
+              for (int r = 0; r < br; r++) for (int q = 0; q < bc; q++) { double sm = 0; for (int x = 0; x < bc; x++) sm += T[r * bc + x] * Q[x * bc + q]; T2[r * bc + q] = sm; }
+              for (int x = 0; x < bb; x++) u[x] -= omega * T2[x];
+            } else {
+              for (int x = 0; x < bb; x++) u[x] -= omega * T[x];
+            }
+          }
+        }
+        double* pv = &P.val[(size_t)p0 * bb];
+        for (size_t x = 0; x < (size_t)len * bb; x++) pv[x] += up[x];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 template <class Mat>
@@ -1628,6 +1688,10 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
           std::vector<double> nextE;
           mesh = contract_edge_mats(G, meshE, dim, sagg, snc, cur_coords, sxc, nextE);
           meshE = std::move(nextE);
+        }
+        if (o.sp_improve_its > 0 && op.enable_sp) {
+          improve_prolongation(*curA, Pk, sagg, sxc, dim, o.energy, o.sp_omega, o.sp_improve_its);
+          lap("prolongation improve steps");
         }
         BCSR PkT = transpose(Pk);
         lap("block prolongation, P^T");
