@@ -1029,13 +1029,15 @@ Graph fine_edge_mats(const BCSR& A, const std::vector<uint8_t>& free, const std:
       }
       static const bool literal = [] { const char* e = std::getenv("NGSAMG_EMAT_NORM"); return e && std::string(e) == "literal"; }();
       const double s0 = tr[std::min<int64_t>(i, j)];
-      x /= (double)(bs * bs) * (literal ? std::sqrt(s0 * s0) : std::sqrt(tr[i] * tr[j]));
+      const double nrm = (double)(bs * bs) * (literal ? std::sqrt(s0 * s0) : std::sqrt(tr[i] * tr[j]));
+      x = nrm > 0.0 ? x / nrm : 0.0;
       double* e = &E[(size_t)p * BB];
       if (bs == dim) {
         double t[3] = {0, 0, 0}, len = 0;
         for (int d = 0; d < dim; d++) { t[d] = xf[(int64_t)j * dim + d] - xf[i * dim + d]; len += t[d] * t[d]; }
         len = std::sqrt(len);
-        for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++) e[r * BS + c] = x * (t[r] / len) * (t[c] / len);
+        if (len > 0.0) { for (int r = 0; r < dim; r++) for (int c = 0; c < dim; c++) e[r * BS + c] = x * (t[r] / len) * (t[c] / len); }
+        else for (int r = 0; r < dim; r++) e[r * BS + r] = x;        // coincident vertices: no direction to project on
       } else {
         for (int r = 0; r < BS; r++) e[r * BS + r] = x;
       }
@@ -1251,6 +1253,16 @@ BCSR prolongation_edge_mats(const BCSR* A, const Graph& G, const std::vector<dou
         }
         double tr = 0;
         for (int r = 0; r < BS; r++) tr += ds[r * BS + r];
+        if (!(tr > 0.0)) {        // structurally present but numerically empty edges: the piecewise row
+          const int cI0 = colidx(I);
+          pw(i, I, &vals[(size_t)cI0 * BB]);
+          for (int q = 0; q < m; q++) {
+            const int64_t p = P.rowptr[i] + q;
+            P.col[p] = cc[q];
+            for (int r = 0; r < bs_f; r++) for (int c = 0; c < BS; c++) P.val[((size_t)p * bs_f + r) * BS + c] = vals[(size_t)q * BB + r * BS + c];
+          }
+          continue;
+        }
         const double trinv = (double)BS / tr;
         for (auto& v : rm) v *= trinv;
         for (int x = 0; x < BB; x++) { ds[x] *= trinv; d[x] = ds[x]; }
