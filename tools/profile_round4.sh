@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles of round 4 on the GPU box (gpurun): kernel-trace statistics and HBM traffic counters of bench.py on the library-default
 # (= reference) hierarchy -- cfg 2 Jacobi and Gauss-Seidel, cfg 3 / cfg 5 Gauss-Seidel -- plus the bench lines themselves.
-#   tools/profile_round4.sh <out_dir under gpurun_out> <commit> [part]      part: a (cfg 2), b (cfg 3 / cfg 5), c (rank-partitioned), default all
+#   tools/profile_round4.sh <out_dir under gpurun_out> <commit> [part]      part: a (cfg 2), b (cfg 3 / cfg 5), c (rank-partitioned), d (edge-matrix hierarchies, N > 1 line at world 1), default abc
 # PMC passes are separate runs with --pmc only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -o pipefail
 OUT=gpurun_out/$1; COMMIT=$2; PART=${3:-abc}
@@ -60,6 +60,17 @@ if [[ $PART == *c* ]]; then
   NGSAMG_FORCE_DIST=1 python bench.py --nv 108 --steps 200 --no-cpu-baseline > $OUT/bench_dist_world1_nv108.json 2> /dev/null
   NGSAMG_FORCE_DIST=1 python bench.py --smoother gs --steps 50 --no-cpu-baseline > $OUT/bench_dist_world1_gs.json 2> /dev/null
   NGSAMG_FORCE_DIST=1 python bench.py --config cfg5 --smoother gs --steps 30 --warmup 5 > $OUT/bench_dist_world1_cfg5_gs.json 2> /dev/null; echo "bench dist" >> $OUT/progress.txt
+fi
+if [[ $PART == *d* ]]; then      # part d (not in the default set): what round 4 left unmeasured on the GPU
+  # the edge-matrix hierarchies at full size (general blocks in P: no rigid-body transfer storage), with sp_improve_its beside them
+  for cfg in cfg3 cfg5; do
+    python bench.py --config $cfg --smoother gs --edge-mats 1 --steps 30 --warmup 5 --cpu-seconds 6 --no-continuity > $OUT/bench_${cfg}_gs_edge_mats.json 2> $OUT/bench_${cfg}_gs_edge_mats.err
+    echo "bench $cfg edge_mats" >> $OUT/progress.txt
+  done
+  python bench.py --config cfg3 --smoother gs --edge-mats 2 --steps 30 --warmup 5 --cpu-seconds 6 --no-continuity > $OUT/bench_cfg3_gs_edge_mats_robust.json 2> $OUT/bench_cfg3_gs_edge_mats_robust.err
+  # the N > 1 bench line's code path (cpu_baseline of the shared matrix, single-process hierarchy) at world size 1
+  NGSAMG_FORCE_DIST=1 python bench.py --nv 108 --steps 200 --cpu-seconds 5 > $OUT/bench_dist_world1_nv108_with_cpu_baseline.json 2> $OUT/bench_dist_world1_nv108_with_cpu_baseline.err
+  NGSAMG_SETUP_LOG=1 python bench.py --steps 20 --no-cpu-baseline --no-continuity > /dev/null 2> $OUT/setup_log_cfg2_two_pass_contract.txt
 fi
 echo $COMMIT > $OUT/commit_part_$PART.txt
 ls $OUT
