@@ -79,6 +79,9 @@ typedef struct amgh_options {
   int32_t sp_improve_its;    /* ngs_amg_sp_improve_its (0; vertex_factory_impl.hpp:1745-1831, 2350-2420): smoothing steps on the smoothed             */
                              /*   prolongation that keep its graph: P_i -= omega D^+ (A P)_i with the entries outside the row's pattern moved to the   */
                              /*   row's own aggregate (through the rigid-body transformation for elasticity)                                          */
+  int32_t no_coarse_inv;     /* own, default 0.  1: the dense inverse of the last level is not formed (coarse_n = 0, as for a last level that is     */
+                             /*   left to the device): for callers that take ONE coarsening step and never solve on its coarse level -- the          */
+                             /*   rank-partitioned setup (ngsamg_amd/dist.py), where an unread 4096-unknown inverse cost more than the whole step    */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -405,6 +405,7 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
 //   FindNeib3Step with robustPick (spw_agg_impl.hpp:637-775): the neighbours that pass the scalar filter are re-weighted with this
 //       number, the strongest is taken if it reaches min(0.25 max scalar soc, edge_thresh = 0.025)
 constexpr double ROB_EDGE_THRESH = 0.025;       // agglomerator.hpp:16
+constexpr double SPW_IN_AGG_EDGE_FACTOR = -2.0 * (1.0 - 0.5);   // -2 (1 - diagStabBoost), spw_agg.hpp:42, spw_agg_impl.hpp:516
 constexpr double ROB_ZERO_EV = 1e2 * 1e-12;     // 1e2 RelZeroTol (agglomerator_utils.hpp:923)
 
 static inline void em_qtmq(int n, const double* Q, const double* M, double* out) {   // out = Q^T M Q
@@ -688,7 +689,26 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   BigSocData big;
   for (int round = 0; round < num_rounds; round++) {
     const int64_t m = g->n;
-    if (robust) robust_aux_diags(*g, R);
+    if (robust && round == 0) {
+      // base level: aux diagonals from the edges; maxTrOD = the largest average trace of an edge's contribution IN THE VERTEX'S FRAME
+      // (VertexAgglomerator::InitializeAggData, agglomerator_impl.hpp:124-147).  Later rounds carry the members' diagonals (below).
+      robust_aux_diags(*g, R);
+      const int BS = em_bs(o.dim), BB = BS * BS;
+#pragma omp parallel for schedule(static)
+      for (int64_t v = 0; v < m; v++) {
+        double Q[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX], mv = 0.0;
+        for (int64_t k = g->ptr[v]; k < g->ptr[v + 1]; k++) {
+          double t[3] = {0, 0, 0};
+          for (int d = 0; d < o.dim; d++) t[d] = 0.5 * ((*R.x)[(int64_t)g->adj[k] * o.dim + d] - (*R.x)[v * o.dim + d]);
+          rb_Q(o.dim, t, Q);
+          em_qtmq(BS, Q, &(*R.E)[(size_t)k * BB], T);
+          double tr = 0;
+          for (int r = 0; r < BS; r++) tr += T[r * BS + r];
+          mv = std::max(mv, tr / BS);
+        }
+        mt[v] = mv;
+      }
+    }
     if (cbs && round == 0) { big.g0 = &G0; big.E0 = E0; big.x0 = x0; big.dim = o.dim; big.aux0 = R.aux; }
     if (cbs && round > 0) {        // base-level members of this round's vertices
       big.mptr.assign(m + 1, 0);
@@ -739,6 +759,39 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
       for (int64_t i = 0; i < m; i++) if (map[i] >= 0) { cnt[map[i]]++; for (int d = 0; d < dim; d++) nx[(int64_t)map[i] * dim + d] += (*R.x)[i * dim + d]; }
       for (int64_t I = 0; I < nn; I++) for (int d = 0; d < dim; d++) nx[I * dim + d] /= std::max(1, cnt[I]);
       next = contract_edge_mats(*g, *R.E, dim, map, nn, *R.x, nx, nE);
+      // inside the rounds the scalar weight of a contracted edge is the SUM of its fine edges' weights (cEdgeTrace, spw_agg_impl.hpp:542),
+      // not the trace of the transformed matrix (that is the rule from level to level)
+      {
+        Graph sw = contract(*g, map, nn);
+        if (sw.adj != next.adj) throw Error("aggregate_spw: contracted graphs differ");
+        next.w = std::move(sw.w);
+      }
+      // aux diagonal of a merged vertex = its members' diagonals moved to its position (SPWAggData::Map, spw_agg_impl.hpp:462-486)
+      // minus (1 - diagStabBoost) of what the edges that vanished inside it had put there (:516, 545-566; diagStabBoost = 0.5,
+      // spw_agg.hpp:42: every such edge sits in both members' diagonals, one of the two copies is taken out)
+      {
+        const int BS = em_bs(dim), BB = BS * BS;
+        std::vector<double> naux((size_t)nn * BB, 0.0);
+        double Q[EM_MAX * EM_MAX], T[EM_MAX * EM_MAX];
+        for (int64_t i = 0; i < m; i++) {
+          const int32_t I = map[i];
+          if (I < 0) continue;
+          double t[3] = {0, 0, 0};
+          for (int d = 0; d < dim; d++) t[d] = (*R.x)[i * dim + d] - nx[(int64_t)I * dim + d];
+          rb_Q(dim, t, Q);
+          em_qtmq(BS, Q, &R.aux[(size_t)i * BB], T);
+          for (int x = 0; x < BB; x++) naux[(size_t)I * BB + x] += T[x];
+          for (int64_t k = g->ptr[i]; k < g->ptr[i + 1]; k++) {
+            const int32_t j = g->adj[k];
+            if (j <= i || map[j] != I) continue;            // every in-aggregate edge once
+            for (int d = 0; d < dim; d++) t[d] = 0.5 * ((*R.x)[i * dim + d] + (*R.x)[(int64_t)j * dim + d]) - nx[(int64_t)I * dim + d];
+            rb_Q(dim, t, Q);
+            em_qtmq(BS, Q, &(*R.E)[(size_t)k * BB], T);
+            for (int x = 0; x < BB; x++) naux[(size_t)I * BB + x] += SPW_IN_AGG_EDGE_FACTOR * T[x];
+          }
+        }
+        R.aux = std::move(naux);
+      }
       curE = std::move(nE); curx = std::move(nx);
       R.E = &curE; R.x = &curx;
     } else next = contract(*g, map, nn);
@@ -762,7 +815,6 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   std::vector<uint8_t> joinable(ncur, 0);
   for (int64_t I = 0; I < ncur; I++) { if (size[I] > 1) { joinable[I] = 1; fin[I] = (int32_t)nn++; } else any_orphan = true; }
   if (o.spw_orphan_round && any_orphan) {
-    if (robust) robust_aux_diags(cur, R);
     for (int64_t I = ncur - 1; I >= 0; I--) {
       if (joinable[I]) continue;
       const int32_t J = robust ? spw_find_join_robust(cur, R, mt, joinable, I) : spw_find_partner(cur, mt, joinable, I, true, &joinable);
@@ -1754,7 +1806,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     // matrix cores, csrc/device/dense_spd.hpp); NGSAMG_HOST_COARSE_MAX moves the limit (tests force the device path with it)
     int64_t host_max = 4096;
     if (const char* e = std::getenv("NGSAMG_HOST_COARSE_MAX")) host_max = std::atoll(e);
-    if (N <= host_max) {
+    if (o.no_coarse_inv) {
+      H->coarse_n = 0;   // the caller only wants the levels (one step of the rank-partitioned setup): no O(N^3) inverse nobody reads
+    } else if (N <= host_max) {
       std::vector<int64_t> fidx;
       for (int64_t i = 0; i < L.A.n_rows; i++) if (L.free[i]) for (int c = 0; c < bs; c++) fidx.push_back(i * bs + c);
       const int64_t nfr = (int64_t)fidx.size();

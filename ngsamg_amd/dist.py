@@ -546,6 +546,7 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         kw["first_aaf"] = o.get("first_aaf", dflt) if first else o.get("aaf", 2.0 ** -dim)
         kw["max_levels"] = 2
         kw["max_coarse_size"] = 1
+        kw["no_coarse_inv"] = 1       # one step: nobody solves on this two-level hierarchy's coarse level
         # prolongation rule: the reference smooths vertices shared between ranks with the replacement matrix only
         # (get_cols_classic: "if (eqc != 0) return false", vertex_factory_impl.hpp:1920); the rank-local setup sees the owned x owned
         # block of A, whose rows at the interface are incomplete, so every row takes that branch here (aux_smoothed)
