@@ -79,9 +79,11 @@ typedef struct amgh_options {
   int32_t sp_improve_its;    /* ngs_amg_sp_improve_its (0; vertex_factory_impl.hpp:1745-1831, 2350-2420): smoothing steps on the smoothed             */
                              /*   prolongation that keep its graph: P_i -= omega D^+ (A P)_i with the entries outside the row's pattern moved to the   */
                              /*   row's own aggregate (through the rigid-body transformation for elasticity)                                          */
-  int32_t no_coarse_inv;     /* own, default 0.  1: the dense inverse of the last level is not formed (coarse_n = 0, as for a last level that is     */
-                             /*   left to the device): for callers that take ONE coarsening step and never solve on its coarse level -- the          */
-                             /*   rank-partitioned setup (ngsamg_amd/dist.py), where an unread 4096-unknown inverse cost more than the whole step    */
+  int32_t prol_only;         /* own, default 0.  1: ONE coarsening step that returns the prolongation only: level 0 carries P and the aggregates,     */
+                             /*   level 1 its size, block size and coordinates; no P^T, no Galerkin product, no smoother data, no coarse inverse (the    */
+                             /*   arrays of amgh_level keep their sizes, zero-filled; level 1's A has no entries).  For callers that form the coarse     */
+                             /*   operator themselves -- the rank-partitioned setup (ngsamg_amd/dist.py), whose product needs the halo rows of P and     */
+                             /*   where the unread dense inverse of a <= 4096-unknown coarse level alone cost more than the step                          */
 } amgh_options;
 
 typedef struct amgh_level {

@@ -95,7 +95,7 @@ void amgh_default_options(amgh_options* o, int dim, int energy) {
   o->crs_robust = 0;
   o->spw_cbs = 0;
   o->sp_improve_its = 0;
-  o->no_coarse_inv = 0;
+  o->prol_only = 0;
 }
 
 int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
@@ -113,7 +113,8 @@ int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* 
     o.spw = opts->spw; o.spw_rounds = opts->spw_rounds; o.spw_orphan_round = opts->spw_orphan_round;
     o.prol_type = opts->prol_type; o.sp_max_per_row_classic = opts->sp_max_per_row_classic;
     o.edge_mats = opts->edge_mats; o.crs_robust = opts->crs_robust;
-    o.spw_cbs = opts->spw_cbs; o.sp_improve_its = opts->sp_improve_its; o.no_coarse_inv = opts->no_coarse_inv;
+    o.spw_cbs = opts->spw_cbs; o.sp_improve_its = opts->sp_improve_its; o.prol_only = opts->prol_only;
+    if (o.prol_only && o.enable_multistep) throw amgh::Error("amgh_setup: prol_only takes one step (enable_multistep = 0)");
     if (o.sp_improve_its < 0 || o.sp_improve_its > 100) throw amgh::Error("amgh_setup: sp_improve_its out of range");
     if (o.sp_improve_its && o.enable_multistep) throw amgh::Error("amgh_setup: sp_improve_its needs enable_multistep = 0");
     if (o.spw_cbs && !o.crs_robust) throw amgh::Error("amgh_setup: spw_cbs (aggregate-wide check) belongs to the energy-based strength of connection (crs_robust = 1)");

@@ -1757,6 +1757,18 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
           improve_prolongation(*curA, Pk, sagg, sxc, dim, o.energy, o.sp_omega, o.sp_improve_its);
           lap("prolongation improve steps");
         }
+        if (o.prol_only) {       // one step, P only (amgh.h): no transpose, no Galerkin product; the coarse level is a placeholder
+          Ptot = std::move(Pk);
+          agg = sagg;
+          tmpA = BCSR();
+          tmpA.n_rows = tmpA.n_cols = snc; tmpA.br = tmpA.bc = bs_c;
+          tmpA.rowptr.assign(snc + 1, 0);
+          curA = &tmpA;
+          cur_coords = std::move(sxc);
+          nc = snc;
+          substeps = 1;
+          break;
+        }
         BCSR PkT = transpose(Pk);
         lap("block prolongation, P^T");
         BCSR nextA = restrict_matrix(PkT, *curA, Pk);
@@ -1777,7 +1789,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       }
       if (failed || substeps == 0) { log << "  coarsening stuck (nc=" << nc << ")\n"; break; }
       F.P = std::move(Ptot);
-      F.PT = substeps == 1 ? std::move(PTlast) : transpose(F.P);       // (one step: the transpose the Galerkin product used)
+      if (!o.prol_only) F.PT = substeps == 1 ? std::move(PTlast) : transpose(F.P);       // (one step: the transpose the Galerkin product used)
       F.agg = agg;
       C.A = std::move(tmpA);
       xc = std::move(cur_coords);
@@ -1789,6 +1801,17 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     C.coords = std::move(xc);
     log << "  rounds=" << rounds << " nc=" << nc << " P nnz=" << F.P.nnz() << "\n";
     H->levels.push_back(std::move(C));
+    if (o.prol_only) break;
+  }
+  if (o.prol_only) {       // placeholders of the right sizes: the caller reads P, agg and the coarse coordinates only
+    for (auto& L : H->levels) {
+      L.dinv.assign((size_t)L.A.n_rows * L.A.br * L.A.br, 0.0);
+      L.color.assign(L.A.n_rows, 0);
+      L.n_colors = 0;
+    }
+    H->coarse_n = 0;
+    H->log = log.str();
+    return H;
   }
   // smoother data per level
   for (auto& L : H->levels) {
@@ -1806,9 +1829,7 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     // matrix cores, csrc/device/dense_spd.hpp); NGSAMG_HOST_COARSE_MAX moves the limit (tests force the device path with it)
     int64_t host_max = 4096;
     if (const char* e = std::getenv("NGSAMG_HOST_COARSE_MAX")) host_max = std::atoll(e);
-    if (o.no_coarse_inv) {
-      H->coarse_n = 0;   // the caller only wants the levels (one step of the rank-partitioned setup): no O(N^3) inverse nobody reads
-    } else if (N <= host_max) {
+    if (N <= host_max) {
       std::vector<int64_t> fidx;
       for (int64_t i = 0; i < L.A.n_rows; i++) if (L.free[i]) for (int c = 0; c < bs; c++) fidx.push_back(i * bs + c);
       const int64_t nfr = (int64_t)fidx.size();

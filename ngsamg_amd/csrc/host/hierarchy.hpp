@@ -29,7 +29,7 @@ struct Options {
   int crs_robust = 0;            // ngs_amg_crs_robust: energy-based strength of connection in the SPW rounds (needs edge_mats; agglomerator.hpp:18)
   int spw_cbs = 0;               // ngs_amg_spw_cbs: aggregate-wide stability check from the second pairing round on (needs crs_robust; spw_agg.hpp:31)
   int sp_improve_its = 0;        // ngs_amg_sp_improve_its: smoothing steps on the prolongation inside its graph (vertex_factory_impl.hpp:2350-2420)
-  int no_coarse_inv = 0;         // skip the dense inverse of the last level (amgh.h)
+  int prol_only = 0;             // ONE coarsening step, P / aggregates / coarse coordinates only (amgh.h)
   int edge_mats = 0;             // elasticity: carry the energy's edge matrices, matrix-valued smoothed prolongation (amgh.h)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level

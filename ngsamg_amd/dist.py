@@ -364,10 +364,10 @@ def _mat(A, br=1, bc=None):
     A = sp.csr_matrix(A)
     A.sort_indices()
     if br == 1 and bc == 1:
-        return Matrix(A.shape[0], A.shape[1], 1, 1, A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data)
+        return Matrix(A.shape[0], A.shape[1], 1, 1, A.indptr.astype(np.int64), A.indices.astype(np.int32, copy=False), A.data)
     B = sp.bsr_matrix(A, blocksize=(br, bc))
     B.sort_indices()
-    return Matrix(A.shape[0] // br, A.shape[1] // bc, br, bc, B.indptr.astype(np.int64), B.indices.astype(np.int32), B.data)
+    return Matrix(A.shape[0] // br, A.shape[1] // bc, br, bc, B.indptr.astype(np.int64), B.indices.astype(np.int32, copy=False), B.data)
 
 
 def _bs(s):
@@ -546,7 +546,8 @@ def coarsen_distributed_level(comm, states, dim, first, opts):
         kw["first_aaf"] = o.get("first_aaf", dflt) if first else o.get("aaf", 2.0 ** -dim)
         kw["max_levels"] = 2
         kw["max_coarse_size"] = 1
-        kw["no_coarse_inv"] = 1       # one step: nobody solves on this two-level hierarchy's coarse level
+        if not int(kw.get("enable_multistep", 0)):
+            kw["prol_only"] = 1   # one step, P only: the coarse operator is formed below with the halo rows of P
         # prolongation rule: the reference smooths vertices shared between ranks with the replacement matrix only
         # (get_cols_classic: "if (eqc != 0) return false", vertex_factory_impl.hpp:1920); the rank-local setup sees the owned x owned
         # block of A, whose rows at the interface are incomplete, so every row takes that branch here (aux_smoothed)

@@ -658,3 +658,29 @@ def test_prolongation_improve_steps_keep_the_graph_and_the_kernel():
         assert it2 <= it0, (rot, em, it2, it0)
     with pytest.raises(NgsAMGError):
         Hierarchy(A, p.free, p.coords, dim=3, energy=0, sp_improve_its=1, spw=0, enable_multistep=1)
+
+
+@pytest.mark.parametrize("energy", [0, 1])
+def test_prol_only_step_equals_the_first_step_of_the_full_setup(energy):
+    """amgh_options.prol_only (what the rank-partitioned setup calls per level): one coarsening step that returns P, the aggregates
+    and the coarse coordinates and skips P^T, the Galerkin product, smoother data and the dense coarse inverse -- bit-identical to
+    level 0 of the full setup"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    if energy == 0:
+        p = fem.poisson_fast((14, 13, 12), dirichlet="right|top", jitter=0.2, seed=1)
+        kw = dict(dim=3, energy=0)
+    else:
+        p = fem.elasticity_fast((9, 8, 7), dirichlet="left", mu=1.0, lam=0.5, rotations=False)
+        kw = dict(dim=3, energy=1, regularize_cmats=1)
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    H = Hierarchy(A, p.free, p.coords, max_coarse_size=10, **kw)
+    Hp = Hierarchy(A, p.free, p.coords, max_coarse_size=10, prol_only=1, **kw)
+    assert Hp.n_levels == 2 and Hp.levels[0].PT is None and Hp.coarse_n == 0
+    for name in ("rowptr", "col", "val"):
+        assert np.array_equal(np.asarray(getattr(H.levels[0].P, name)), np.asarray(getattr(Hp.levels[0].P, name)))
+    assert np.array_equal(np.asarray(H.levels[0].agg), np.asarray(Hp.levels[0].agg))
+    assert np.array_equal(H.levels[1].coords, Hp.levels[1].coords)
+    L1 = Hp.levels[1]
+    assert L1.n == H.levels[1].n and L1.bs == H.levels[1].bs and L1.A.nnz == 0 and L1.dinv.shape[0] == L1.n * L1.bs ** 2
+    with pytest.raises(NgsAMGError):
+        Hierarchy(A, p.free, p.coords, prol_only=1, spw=0, enable_multistep=1, **kw)
