@@ -1814,11 +1814,19 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
     return H;
   }
   // smoother data per level
-  for (auto& L : H->levels) {
-    L.dinv.resize((size_t)L.A.n_rows * L.A.br * L.A.br);
-    calc_dinv(L.A, L.free.data(), o.regularize_cmats != 0, L.dinv.data());
-    L.color.resize(L.A.n_rows);
-    L.n_colors = greedy_coloring(L.A, L.free.data(), L.color.data());
+  {
+    const bool tlog = std::getenv("NGSAMG_SETUP_LOG") != nullptr;
+    double td = 0, tc = 0;
+    for (auto& L : H->levels) {
+      const double t0 = omp_get_wtime();
+      L.dinv.resize((size_t)L.A.n_rows * L.A.br * L.A.br);
+      calc_dinv(L.A, L.free.data(), o.regularize_cmats != 0, L.dinv.data());
+      const double t1 = omp_get_wtime();
+      L.color.resize(L.A.n_rows);
+      L.n_colors = greedy_coloring(L.A, L.free.data(), L.color.data());
+      td += t1 - t0; tc += omp_get_wtime() - t1;
+    }
+    if (tlog) std::fprintf(stderr, "[setup_levels] smoother data: inverted diagonals %8.1f ms, greedy colouring %8.1f ms\n", 1e3 * td, 1e3 * tc);
   }
   // coarsest-level inverse on the free dofs (zero rows/cols elsewhere), dense
   {
