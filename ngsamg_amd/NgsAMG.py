@@ -33,6 +33,24 @@ def _flags(kwargs):
     return out
 
 
+def _energy_flag(f, energy, name="ngs_amg"):
+    """ngs_amg_energy = triv | alg | elmat (amg_pc.cpp:333; reference default alg).  H1: alg is what the setup does (edge weights
+    from the matrix entries, BuildAlgMesh_ALG_scal).  Elasticity: an explicit alg selects the reference's edge matrices from the
+    assembled matrix and its matrix-valued prolongation (ngs_amg_edge_mats, DESIGN 5.8a) unless ngs_amg_edge_mats is given;
+    elmat needs the element matrices, which do not cross this interface."""
+    e = f.get("energy")
+    if e is None:
+        return {}
+    e = str(e).lower()
+    if e not in ("triv", "alg", "elmat"):
+        raise NgsAMGError(f"{name}: ngs_amg_energy = '{e}' (triv | alg | elmat)")
+    if e == "elmat":
+        raise NgsAMGError(f"{name}: ngs_amg_energy = 'elmat' needs element matrices (AddElementMatrix), which this interface does not carry")
+    if e == "alg" and energy == 1 and "edge_mats" not in f:
+        return {"edge_mats": 1}
+    return {}
+
+
 def _as_matrix(mat, bs):
     if isinstance(mat, Matrix):
         return mat
@@ -320,6 +338,7 @@ class _AMGPreconditioner:
         opts = {k: f[k] for k in ("max_levels", "max_coarse_size", "first_aaf", "aaf", "enable_sp", "sp_omega",
                                   "sp_max_per_row", "sp_min_frac", "soc_thresh", "max_rounds", "log_level", "enable_multistep",
                                   "robust_soc", "spw", "spw_rounds", "spw_orphan_treatment", "prol_type", "sp_max_per_row_classic", "edge_mats", "crs_robust", "spw_cbs", "sp_improve_its") if k in f}
+        opts.update(_energy_flag(f, self._energy, self._name))
         if self._energy == 1:
             rots = A.br > dim
             opts["regularize_cmats"] = int(f.get("regularize_cmats", not rots))   # elasticity_pc_impl.hpp:134-139

@@ -152,3 +152,20 @@ def test_rank_without_rows_takes_part_in_the_collective_cycle(sm):
     ref = Oracle(glv, sm_type=oracle_sm_types(amg)).apply(np.concatenate([b.numpy() for b in bs]))
     got = np.concatenate([x.numpy() for x in xs])
     assert np.linalg.norm(got - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_energy_flag_of_the_reference():
+    """ngs_amg_energy (amg_pc.cpp:333): alg on an elasticity preconditioner = the reference's edge-matrix setup, elmat is refused"""
+    from ngsamg_amd.NgsAMG import _energy_flag, _flags
+    from ngsamg_amd._lib import NgsAMGError
+    assert _energy_flag(_flags({}), 1) == {}
+    assert _energy_flag(_flags({"ngs_amg_energy": "alg"}), 0) == {}
+    assert _energy_flag(_flags({"ngs_amg_energy": "alg"}), 1) == {"edge_mats": 1}
+    assert _energy_flag(_flags({"ngs_amg_energy": "alg", "ngs_amg_edge_mats": False}), 1) == {}
+    assert _energy_flag(_flags({"ngs_amg_energy": "triv"}), 1) == {}
+    for bad in ("elmat", "nonsense"):
+        try:
+            _energy_flag(_flags({"ngs_amg_energy": bad}), 1)
+            assert False
+        except NgsAMGError:
+            pass
