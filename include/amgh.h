@@ -114,6 +114,10 @@ void amgh_destroy(amgh_hierarchy* h);
  * reference src/base/smoothers/python_smoothers.cpp:144-387) */
 int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, double* dinv_out);
 int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors);
+/* The pair strength of connection of the energy-based agglomeration (options.crs_robust; reference CalcRobustPairSOC,
+ * src/base/coarsening/agglomerator_utils.hpp:763-841): the smallest eigenvalue of E v = lambda C v on the complement of ker C
+ * (eigenvalues of C below 1e-10 of its largest count as kernel), clipped at 0.  C, E: symmetric n x n, row-major, n <= 6. */
+int amgh_robust_pair_soc(int32_t n, const double* C, const double* E, double* soc_out);
 /* Block-hybrid Gauss-Seidel (amgx_level_desc.gs_block_rows): blocks of block_rows consecutive rows are swept like the
  * ranks of the reference's HybridGSSmoother (gssmoother.cpp:709-861) -- Gauss-Seidel inside a block, couplings that leave
  * the block frozen at their sweep-start values.  amgh_coloring_blocked: greedy colouring that only sees couplings inside a

@@ -83,6 +83,7 @@ def host():
     lib.amgh_destroy.restype = None
     lib.amgh_calc_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int, c_f64p]
     lib.amgh_coloring.argtypes = [C.POINTER(amgh_matrix), c_u8p, c_i32p, c_i32p]
+    lib.amgh_robust_pair_soc.argtypes = [C.c_int32, c_f64p, c_f64p, c_f64p]
     lib.amgh_coloring_blocked.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_i32p, c_i32p]
     lib.amgh_hybrid_dinv.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p]
     lib.amgh_hybrid_dinv_ext.argtypes = [C.POINTER(amgh_matrix), c_u8p, C.c_int64, c_f64p, c_f64p]
@@ -252,7 +253,7 @@ AMGH_SYMBOLS = [
     "amgh_coarse_inverse", "amgh_log", "amgh_destroy", "amgh_calc_dinv", "amgh_coloring", "amgh_transpose_count",
     "amgh_transpose_fill", "amgh_matmul", "amgh_kuhn_pattern", "amgh_kuhn_assemble", "amgh_bgs_dinv", "amgh_bgs_coloring",
     "amgh_coloring_blocked", "amgh_hybrid_dinv", "amgh_hybrid_dinv_ext", "amgh_hybrid_dinv_block", "amgh_compact_blocks", "amgh_coloring_blockids", "amgh_hybrid_dinv_block_ids",
-    "amgh_set_galerkin_hook",
+    "amgh_set_galerkin_hook", "amgh_robust_pair_soc",
 ]
 
 

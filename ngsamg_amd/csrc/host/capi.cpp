@@ -175,6 +175,13 @@ int amgh_calc_dinv(const amgh_matrix* A, const uint8_t* free_or_null, int pinv, 
   });
 }
 
+int amgh_robust_pair_soc(int32_t n, const double* C, const double* E, double* soc_out) {
+  return guard([&] {
+    if (!C || !E || !soc_out) throw amgh::Error("amgh_robust_pair_soc: null argument");
+    *soc_out = amgh::robust_pair_soc_of(n, C, E);
+  });
+}
+
 int amgh_coloring(const amgh_matrix* A, const uint8_t* free_or_null, int32_t* color_out, int32_t* n_colors) {
   return guard([&] {
     check_matrix(A);

@@ -1403,6 +1403,11 @@ void improve_prolongation(const BCSR& A, BCSR& P, const std::vector<int32_t>& ag
 
 }  // namespace
 
+double robust_pair_soc_of(int n, const double* C, const double* E) {
+  if (n < 1 || n > EM_MAX) throw Error("robust_pair_soc: block size must be 1 ... 6");
+  return robust_pair_soc(n, C, E);
+}
+
 template <class Mat>
 static void calc_dinv_t(const Mat& A, const uint8_t* free, bool pinv, double* dinv) {
   const int bs = A.br, bb = bs * bs;

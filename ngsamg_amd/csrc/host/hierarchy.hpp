@@ -72,6 +72,8 @@ void hybrid_mod_dinv(const BCSR& A, const uint8_t* free, int64_t block_rows, dou
 void hybrid_mod_dinv(const CsrView& A, const uint8_t* free, int64_t block_rows, double* dinv, const double* ghost_diag = nullptr);
 void hybrid_mod_dinv_block(const BCSR& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row = nullptr);
 void hybrid_mod_dinv_block(const CsrView& A, const uint8_t* free, int64_t block_rows, bool pinv, double* dinv, const int32_t* block_of_row = nullptr);
+// CalcRobustPairSOC (agglomerator_utils.hpp:763-841): smallest eigenvalue of E v = lambda C v off the kernel of C (n <= 6)
+double robust_pair_soc_of(int n, const double* C, const double* E);
 int64_t compact_blocks(const BCSR& A, const uint8_t* free, int target, int max_rows, int32_t* block_of_row);
 int greedy_coloring_blockids(const BCSR& A, const uint8_t* free, const int32_t* block_of_row, int32_t* color);
 

@@ -684,3 +684,39 @@ def test_prol_only_step_equals_the_first_step_of_the_full_setup(energy):
     assert L1.n == H.levels[1].n and L1.bs == H.levels[1].bs and L1.A.nnz == 0 and L1.dinv.shape[0] == L1.n * L1.bs ** 2
     with pytest.raises(NgsAMGError):
         Hierarchy(A, p.free, p.coords, prol_only=1, spw=0, enable_multistep=1, **kw)
+
+
+def test_robust_pair_soc_is_the_smallest_generalised_eigenvalue():
+    """amgh_robust_pair_soc (CalcRobustPairSOC, agglomerator_utils.hpp:763-841) against scipy: full-rank C, rank-deficient C (the
+    kernel of C is projected out, where E may be anything), scaling behaviour, the 1 x 1 case"""
+    import ctypes as C
+    import scipy.linalg as sla
+    from ngsamg_amd import _lib
+    lib = _lib.host()
+
+    def soc(Cm, Em):
+        n = Cm.shape[0]
+        out = C.c_double()
+        Cm, Em = np.ascontiguousarray(Cm, dtype=np.float64), np.ascontiguousarray(Em, dtype=np.float64)
+        _lib.hcheck(lib.amgh_robust_pair_soc(n, _lib.ptr(Cm, C.c_double), _lib.ptr(Em, C.c_double), C.byref(out)))
+        return out.value
+
+    rng = np.random.default_rng(9)
+    for n in (2, 3, 6):
+        X, Y = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+        Cm, Em = X @ X.T + 0.1 * np.eye(n), Y @ Y.T
+        ref = max(0.0, sla.eigh(Em, Cm, eigvals_only=True)[0])
+        assert abs(soc(Cm, Em) - ref) <= 1e-9 * max(1.0, ref)
+        assert abs(soc(3.0 * Cm, Em) - ref / 3.0) <= 1e-9 and abs(soc(Cm, 5.0 * Em) - 5.0 * ref) <= 1e-8 * max(1.0, ref)
+        # rank-deficient C: only range(C) counts
+        k = n - 1
+        U = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        lam = np.concatenate([rng.uniform(0.5, 2.0, k), [0.0]])
+        Cd = (U * lam) @ U.T
+        W = U[:, :k] / np.sqrt(lam[:k])
+        ref = max(0.0, np.linalg.eigvalsh(W.T @ Em @ W)[0])
+        assert abs(soc(Cd, Em) - ref) <= 1e-8 * max(1.0, ref)
+        assert soc(np.zeros((n, n)), Em) == 0.0
+    assert abs(soc(np.array([[4.0]]), np.array([[2.0]])) - 0.5) < 1e-14
+    with pytest.raises(NgsAMGError):
+        soc(np.eye(7), np.eye(7))
