@@ -84,6 +84,9 @@ typedef struct amgh_options {
                              /*   arrays of amgh_level keep their sizes, zero-filled; level 1's A has no entries).  For callers that form the coarse     */
                              /*   operator themselves -- the rank-partitioned setup (ngsamg_amd/dist.py), whose product needs the halo rows of P and     */
                              /*   where the unread dense inverse of a <= 4096-unknown coarse level alone cost more than the step                          */
+  int32_t spw_pick_robust;   /* ngs_amg_spw_pick_robust (1, spw_agg.hpp:26, 55), with crs_robust: 1 = the robust strength orders the candidates,       */
+                             /*   0 = the scalar strength orders them and the robust one only vetoes (FindNeib3Step, spw_agg_impl.hpp:722-765)       */
+  int32_t spw_neib_boost;    /* ngs_amg_spw_neib_boost (1, spw_agg.hpp:27, 56): the neighbour boost of the robust edge matrix (AddNeibBoost)            */
 } amgh_options;
 
 typedef struct amgh_level {

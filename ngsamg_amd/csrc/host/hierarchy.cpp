@@ -451,6 +451,8 @@ struct RobustData {
   const std::vector<double>* E = nullptr;   // per entry of the round's graph
   const std::vector<double>* x = nullptr;   // positions of the round's vertices
   std::vector<double> aux;                  // aux diagonal per vertex, in the vertex's frame
+  bool neib_boost = true;                   // cfg.neibBoost   (ngs_amg_spw_neib_boost, spw_agg.hpp:27, 56)
+  bool pick_robust = true;                  // cfg.robustPick  (ngs_amg_spw_pick_robust, spw_agg.hpp:26, 55)
 };
 
 static void robust_aux_diags(const Graph& g, RobustData& R) {
@@ -480,7 +482,7 @@ static void robust_boosted_edge(const Graph& g, const RobustData& R, int64_t i, 
   for (int d = 0; d < 3; d++) mid[d] = 0.0;
   for (int d = 0; d < dim; d++) mid[d] = 0.5 * (X[i * dim + d] + X[(int64_t)j * dim + d]);
   // neighbour boost over the common neighbours
-  for (int64_t ki = g.ptr[i]; ki < g.ptr[i + 1]; ki++) {
+  if (R.neib_boost) for (int64_t ki = g.ptr[i]; ki < g.ptr[i + 1]; ki++) {
     const int32_t nb = g.adj[ki];
     if (nb == j) continue;
     int64_t kj = -1;
@@ -615,11 +617,24 @@ static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, cons
     if (handled[j]) continue;
     const double den = std::sqrt(mt[v] * mt[j]);
     if (!(den > 0.0) || g.w[k] / den < th) continue;
+    if (!R.pick_robust) { cand.push_back({g.w[k] / den, (int32_t)(k - g.ptr[v])}); continue; }
     const double w = robust_soc(g, R, v, k);
     if (big) cand.push_back({w, j});
     if (w > bw) { bw = w; best = j; }
   }
   const double wth = std::min(th, ROB_EDGE_THRESH);
+  if (!R.pick_robust) {
+    // robustPick = false (FindNeib3Step, spw_agg_impl.hpp:722-765): the scalar order decides, the robust number only vetoes: the
+    // strongest scalar candidate whose robust strength reaches min(scalar threshold, edge_thresh) (and passes the aggregate-wide check)
+    std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    for (const auto& c : cand) {
+      const int64_t k = g.ptr[v] + c.second;
+      if (robust_soc(g, R, v, k) < wth) continue;
+      if (big && !big_soc_ok(*big, (int32_t)v, g.adj[k], wth)) continue;
+      return g.adj[k];
+    }
+    return -1;
+  }
   if (!big) return (best >= 0 && bw >= wth) ? best : -1;
   // strongest first, the first one that also passes the aggregate-wide check (rho = min(robust threshold, absBigThresh = edge_thresh))
   std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
@@ -684,7 +699,7 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   RobustData R;
   R.dim = o.dim;
   std::vector<double> curE, curx;
-  if (robust) { R.E = E0; R.x = x0; }
+  if (robust) { R.E = E0; R.x = x0; R.neib_boost = o.spw_neib_boost != 0; R.pick_robust = o.spw_pick_robust != 0; }
   const bool cbs = robust && o.spw_cbs;
   BigSocData big;
   for (int round = 0; round < num_rounds; round++) {

@@ -30,6 +30,8 @@ struct Options {
   int spw_cbs = 0;               // ngs_amg_spw_cbs: aggregate-wide stability check from the second pairing round on (needs crs_robust; spw_agg.hpp:31)
   int sp_improve_its = 0;        // ngs_amg_sp_improve_its: smoothing steps on the prolongation inside its graph (vertex_factory_impl.hpp:2350-2420)
   int prol_only = 0;             // ONE coarsening step, P / aggregates / coarse coordinates only (amgh.h)
+  int spw_pick_robust = 1;       // ngs_amg_spw_pick_robust (spw_agg.hpp:26): crs_robust picks by the robust number (1) or only vetoes with it (0)
+  int spw_neib_boost = 1;        // ngs_amg_spw_neib_boost (spw_agg.hpp:27): neighbour boost of the robust edge matrix
   int edge_mats = 0;             // elasticity: carry the energy's edge matrices, matrix-valued smoothed prolongation (amgh.h)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level

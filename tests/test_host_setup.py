@@ -720,3 +720,25 @@ def test_robust_pair_soc_is_the_smallest_generalised_eigenvalue():
     assert abs(soc(np.array([[4.0]]), np.array([[2.0]])) - 0.5) < 1e-14
     with pytest.raises(NgsAMGError):
         soc(np.eye(7), np.eye(7))
+
+
+def test_robust_agglomeration_switches_of_the_reference():
+    """ngs_amg_spw_pick_robust = False (the scalar order decides, the robust number only vetoes) and ngs_amg_spw_neib_boost = False
+    (spw_agg.hpp:26-27, 55-56): both give valid, different hierarchies inside the reference's budget on its 3D beam"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    p = fem.elasticity_fast((21, 5, 5), dirichlet="left", mu=1.0, lam=0.0, rotations=True, extent=(5.0, 1.0, 1.0))
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    kw = dict(dim=3, energy=1, max_coarse_size=10, regularize_cmats=0, edge_mats=1, crs_robust=1)
+    b = np.random.default_rng(8).standard_normal(p.n * p.bs) * np.repeat(p.free, p.bs)
+    aggs = {}
+    for name, extra in (("default", {}), ("veto", {"spw_pick_robust": 0}), ("noboost", {"spw_neib_boost": 0})):
+        H = Hierarchy(A, p.free, p.coords, **kw, **extra)
+        aggs[name] = np.asarray(H.levels[0].agg).copy()
+        assert H.n_levels >= 3
+        assert Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-6, maxit=200)[1] <= 40
+        Lf, Lc = H.levels[0], H.levels[1]
+        P = Lf.P.to_scipy()
+        assert abs(Lc.A.to_scipy() - P.T @ Lf.A.to_scipy() @ P).max() < 1e-10 * abs(Lc.A.to_scipy()).max()
+    assert not np.array_equal(aggs["default"], aggs["veto"])
+    assert not np.array_equal(aggs["default"], aggs["noboost"])
