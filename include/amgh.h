@@ -87,6 +87,10 @@ typedef struct amgh_options {
   int32_t spw_pick_robust;   /* ngs_amg_spw_pick_robust (1, spw_agg.hpp:26, 55), with crs_robust: 1 = the robust strength orders the candidates,       */
                              /*   0 = the scalar strength orders them and the robust one only vetoes (FindNeib3Step, spw_agg_impl.hpp:722-765)       */
   int32_t spw_neib_boost;    /* ngs_amg_spw_neib_boost (1, spw_agg.hpp:27, 56): the neighbour boost of the robust edge matrix (AddNeibBoost)            */
+  int32_t spw_pick_avg;      /* ngs_amg_spw_pick_avg (geom; spw_agg.hpp:22, 62-65): average of the two vertices' maxTrOD in the scalar strength         */
+                             /*   soc = w / avg: 0 min, 1 geom, 2 harm, 3 alg, 4 max                                                                  */
+  double spw_diag_stab_boost; /* ngs_amg_spw_diag_stab_boost (0.5; spw_agg.hpp:36-42), with crs_robust: share of the edges that vanish inside a pair  */
+                             /*   that stays in the pair's aux diagonal (0: all removed, most matches; 1: all kept, most stable)                        */
 } amgh_options;
 
 typedef struct amgh_level {

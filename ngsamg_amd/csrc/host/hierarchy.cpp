@@ -370,12 +370,24 @@ Graph contract_edge_mats(const Graph& g, const std::vector<double>& E, int dim, 
 // the MPI equivalence-class rules, the energy (robust) SOC of matrix-valued vertex data.
 constexpr double SPW_REL_THRESH = 0.25;     // cfg.scalRelThresh (spw_agg_impl.hpp:1410)
 
+// ngs_amg_spw_pick_avg (spw_agg.hpp:22, 62-65; Average, agglomerator_utils.hpp:213-226): how the two vertices' maxTrOD enter the scalar
+// strength soc = w / avg: 0 min, 1 geom (default), 2 harm, 3 alg, 4 max
+static inline double spw_avg(int type, double a, double b) {
+  switch (type) {
+    case 0: return std::min(a, b);
+    case 2: return (a + b) > 0.0 ? 2.0 * (a * b) / (a + b) : 0.0;
+    case 3: return 0.5 * (a + b);
+    case 4: return std::max(a, b);
+    default: return std::sqrt(a * b);
+  }
+}
+
 static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, const std::vector<uint8_t>& handled, int64_t v, bool join,
-                                const std::vector<uint8_t>* joinable) {
+                                const std::vector<uint8_t>* joinable, int avg = 1) {
   double mx = 0.0;
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
     const int32_t j = g.adj[k];
-    const double den = join ? mt[v] : std::sqrt(mt[v] * mt[j]);
+    const double den = join ? mt[v] : spw_avg(avg, mt[v], mt[j]);
     if (den > 0.0) mx = std::max(mx, g.w[k] / den);
   }
   if (!(mx > 0.0)) return -1;
@@ -385,7 +397,7 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
     const int32_t j = g.adj[k];
     if (join ? !(*joinable)[j] : handled[j]) continue;
-    const double den = join ? mt[v] : std::sqrt(mt[v] * mt[j]);
+    const double den = join ? mt[v] : spw_avg(avg, mt[v], mt[j]);
     if (!(den > 0.0)) continue;
     const double soc = g.w[k] / den;
     if (soc >= th && soc > bw) { bw = soc; best = j; }
@@ -405,7 +417,6 @@ static int32_t spw_find_partner(const Graph& g, const std::vector<double>& mt, c
 //   FindNeib3Step with robustPick (spw_agg_impl.hpp:637-775): the neighbours that pass the scalar filter are re-weighted with this
 //       number, the strongest is taken if it reaches min(0.25 max scalar soc, edge_thresh = 0.025)
 constexpr double ROB_EDGE_THRESH = 0.025;       // agglomerator.hpp:16
-constexpr double SPW_IN_AGG_EDGE_FACTOR = -2.0 * (1.0 - 0.5);   // -2 (1 - diagStabBoost), spw_agg.hpp:42, spw_agg_impl.hpp:516
 constexpr double ROB_ZERO_EV = 1e2 * 1e-12;     // 1e2 RelZeroTol (agglomerator_utils.hpp:923)
 
 static inline void em_qtmq(int n, const double* Q, const double* M, double* out) {   // out = Q^T M Q
@@ -453,6 +464,8 @@ struct RobustData {
   std::vector<double> aux;                  // aux diagonal per vertex, in the vertex's frame
   bool neib_boost = true;                   // cfg.neibBoost   (ngs_amg_spw_neib_boost, spw_agg.hpp:27, 56)
   bool pick_robust = true;                  // cfg.robustPick  (ngs_amg_spw_pick_robust, spw_agg.hpp:26, 55)
+  int pick_avg = 1;                         // cfg.avgTypeScal (ngs_amg_spw_pick_avg)
+  double in_agg_edge_factor = -1.0;         // -2 (1 - diagStabBoost) (ngs_amg_spw_diag_stab_boost = 0.5)
 };
 
 static void robust_aux_diags(const Graph& g, RobustData& R) {
@@ -604,7 +617,7 @@ static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, cons
                                        const BigSocData* big = nullptr) {
   double mx = 0.0;
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
-    const double den = std::sqrt(mt[v] * mt[g.adj[k]]);
+    const double den = spw_avg(R.pick_avg, mt[v], mt[g.adj[k]]);
     if (den > 0.0) mx = std::max(mx, g.w[k] / den);
   }
   if (!(mx > 0.0)) return -1;
@@ -615,7 +628,7 @@ static int32_t spw_find_partner_robust(const Graph& g, const RobustData& R, cons
   for (int64_t k = g.ptr[v]; k < g.ptr[v + 1]; k++) {
     const int32_t j = g.adj[k];
     if (handled[j]) continue;
-    const double den = std::sqrt(mt[v] * mt[j]);
+    const double den = spw_avg(R.pick_avg, mt[v], mt[j]);
     if (!(den > 0.0) || g.w[k] / den < th) continue;
     if (!R.pick_robust) { cand.push_back({g.w[k] / den, (int32_t)(k - g.ptr[v])}); continue; }
     const double w = robust_soc(g, R, v, k);
@@ -700,6 +713,8 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
   R.dim = o.dim;
   std::vector<double> curE, curx;
   if (robust) { R.E = E0; R.x = x0; R.neib_boost = o.spw_neib_boost != 0; R.pick_robust = o.spw_pick_robust != 0; }
+  R.pick_avg = o.spw_pick_avg;
+  R.in_agg_edge_factor = -2.0 * (1.0 - std::min(1.0, std::max(0.0, o.spw_diag_stab_boost)));      // (spw_agg_impl.hpp:516, 1386-1387)
   const bool cbs = robust && o.spw_cbs;
   BigSocData big;
   for (int round = 0; round < num_rounds; round++) {
@@ -739,7 +754,7 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
     map.assign(m, -1);
     int64_t nn = 0;
     auto make_pair = [&](int64_t v) {
-      const int32_t nb = robust ? spw_find_partner_robust(*g, R, mt, handled, v, bigp) : spw_find_partner(*g, mt, handled, v, false, nullptr);
+      const int32_t nb = robust ? spw_find_partner_robust(*g, R, mt, handled, v, bigp) : spw_find_partner(*g, mt, handled, v, false, nullptr, o.spw_pick_avg);
       const int32_t cv = (int32_t)nn++;
       if (nb >= 0) { map[nb] = cv; handled[nb] = 1; }
       map[v] = cv;
@@ -802,7 +817,7 @@ int64_t aggregate_spw(const Graph& G0, const std::vector<uint8_t>& free, const O
             for (int d = 0; d < dim; d++) t[d] = 0.5 * ((*R.x)[i * dim + d] + (*R.x)[(int64_t)j * dim + d]) - nx[(int64_t)I * dim + d];
             rb_Q(dim, t, Q);
             em_qtmq(BS, Q, &(*R.E)[(size_t)k * BB], T);
-            for (int x = 0; x < BB; x++) naux[(size_t)I * BB + x] += SPW_IN_AGG_EDGE_FACTOR * T[x];
+            for (int x = 0; x < BB; x++) naux[(size_t)I * BB + x] += R.in_agg_edge_factor * T[x];
           }
         }
         R.aux = std::move(naux);

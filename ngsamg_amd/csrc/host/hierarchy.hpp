@@ -32,6 +32,8 @@ struct Options {
   int prol_only = 0;             // ONE coarsening step, P / aggregates / coarse coordinates only (amgh.h)
   int spw_pick_robust = 1;       // ngs_amg_spw_pick_robust (spw_agg.hpp:26): crs_robust picks by the robust number (1) or only vetoes with it (0)
   int spw_neib_boost = 1;        // ngs_amg_spw_neib_boost (spw_agg.hpp:27): neighbour boost of the robust edge matrix
+  int spw_pick_avg = 1;          // ngs_amg_spw_pick_avg: 0 min, 1 geom, 2 harm, 3 alg, 4 max (spw_agg.hpp:22, 62-65)
+  double spw_diag_stab_boost = 0.5;   // ngs_amg_spw_diag_stab_boost (spw_agg.hpp:42): crs_robust, share of the in-aggregate edges kept in the carried aux diagonals
   int edge_mats = 0;             // elasticity: carry the energy's edge matrices, matrix-valued smoothed prolongation (amgh.h)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level

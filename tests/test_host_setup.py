@@ -742,3 +742,30 @@ def test_robust_agglomeration_switches_of_the_reference():
         assert abs(Lc.A.to_scipy() - P.T @ Lf.A.to_scipy() @ P).max() < 1e-10 * abs(Lc.A.to_scipy()).max()
     assert not np.array_equal(aggs["default"], aggs["veto"])
     assert not np.array_equal(aggs["default"], aggs["noboost"])
+
+
+def test_spw_pick_avg_and_diag_stab_boost():
+    """ngs_amg_spw_pick_avg (min | geom | harm | alg | max; default geom) changes the scalar filter of the pairing, so the aggregates of
+    a problem with a coefficient jump (where the two vertices' scales differ) move; on a quasi-uniform problem with equal scales
+    every average gives the same aggregates.  ngs_amg_spw_diag_stab_boost acts on the carried aux diagonals of crs_robust."""
+    from ngsamg_amd.hierarchy import Hierarchy
+
+    def coef(X):
+        return np.where(X[..., 0] > 0.5, 1e3, 1.0)
+
+    p = fem.poisson_fast((21, 21), dirichlet="left", coef=coef) if "coef" in fem.poisson_fast.__code__.co_varnames else None
+    if p is not None:
+        A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
+        aggs = {a: np.asarray(Hierarchy(A, p.free, p.coords, dim=2, energy=0, max_coarse_size=10, spw_pick_avg=a).levels[0].agg).copy()
+                for a in ("min", "geom", "max")}
+        assert not (np.array_equal(aggs["min"], aggs["geom"]) and np.array_equal(aggs["max"], aggs["geom"]))
+    q = fem.elasticity_fast((13, 5, 5), dirichlet="left", mu=1.0, lam=0.0, rotations=True, extent=(3.0, 1.0, 1.0))
+    B = Matrix(q.n, q.n, q.bs, q.bs, q.rowptr, q.col, q.val)
+    kw = dict(dim=3, energy=1, max_coarse_size=10, regularize_cmats=0, edge_mats=1, crs_robust=1)
+    a0 = np.asarray(Hierarchy(B, q.free, q.coords, spw_diag_stab_boost=0.0, **kw).levels[0].agg).copy()
+    a1 = np.asarray(Hierarchy(B, q.free, q.coords, spw_diag_stab_boost=1.0, **kw).levels[0].agg).copy()
+    assert a0.max() > 0 and a1.max() > 0 and not np.array_equal(a0, a1)
+    with pytest.raises(NgsAMGError):
+        Hierarchy(B, q.free, q.coords, spw_pick_avg="median", **kw)
+    with pytest.raises(NgsAMGError):
+        Hierarchy(B, q.free, q.coords, spw_pick_avg=7, **kw)
