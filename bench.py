@@ -271,8 +271,8 @@ def _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw):
     """cpu_baseline of an N > 1 line (rank 0 only, after the timed region, the other ranks wait in the final barrier): the CPU
     oracle (oracle/oracle.c: the reference's V-cycle restated in C, OpenMP over rows) on the hierarchy ONE process builds for the
     matrix the ranks share -- strong scaling: the global nv^3 matrix of the single-GPU line; weak scaling: one rank's nv^3 box,
-    value scaled by 1 / world (a CPU would have to run all `world` boxes).  Bounded sample (--cpu-seconds), threads = this
-    rank's CPU share."""
+    value scaled by 1 / world (a CPU would have to run all `world` boxes).  Bounded sample (--cpu-seconds), threads = the
+    cores rank 0 may use (the other ranks are blocked in the barrier meanwhile)."""
     import __graft_entry__ as ge
     from ngsamg_amd import fem
     from ngsamg_amd._lib import Matrix
@@ -290,7 +290,7 @@ def _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw):
             cores = max(1, min(cores, int(int(q) // int(per))))
     except (OSError, ValueError):
         pass
-    cores = max(1, min(64, cores // max(1, world)))          # the node's cores are shared by `world` rank processes
+    cores = max(1, min(64, cores))        # the other ranks wait in a gloo barrier (blocked on a socket, not spinning): the cores are free
     if nv ** 3 * (1 if not elast else 6 if args.config == "cfg5" else 3) > 3e7:
         log("cpu_baseline skipped: a single-process hierarchy of this size does not fit the bounded sample (see the N = 1 line)")
         return None
@@ -333,7 +333,7 @@ def _dist_cpu_baseline(args, nv, world, strong, elast, hier_kw):
             "sample": (f"{reps} V-cycle applications of the single-process hierarchy of "
                        + (f"the same global {nv}^3 matrix" if strong else f"one rank's {nv}^3 box (value = 1 / ({world} x time): a CPU runs all {world} boxes)")
                        + f" ({prob.n * prob.bs} DOF, {H.n_levels} levels, OC {sum(nnz) / max(1, nnz[0]):.3f}; oracle/oracle.c, OpenMP over rows, "
-                         f"{cores} threads = this rank's share of the node; setup {t1 - t0:.1f} s, not timed)"),
+                         f"{cores} threads on rank 0 while the other ranks wait in the final barrier; setup {t1 - t0:.1f} s, not timed)"),
             "hierarchy_note": "the rank-partitioned hierarchy (`hierarchy` above) is built by the distributed setup: same rules, rank-local aggregates"}
 
 
