@@ -11,7 +11,7 @@ Each fixture stores every level's CSR arrays, P, PT, dinv, free mask, colours, a
 the vectors after each stage of one V-cycle:  x after pre-smoothing, r, b_1 (level 0), the final x,
 plus W / BS cycle outputs and the PCG error history.
 
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py [fixture names; default all]
 """
 import os
 import sys
@@ -35,6 +35,10 @@ CASES = {
     "poisson3d_9": dict(kind="poisson", shape=(9, 9, 9), diri="right|top", mcs=10),
     "elast3d_4_bs3": dict(kind="elast", shape=(4, 4, 4), diri="left", mcs=4, rot=False),
     "elast3d_4_bs6": dict(kind="elast", shape=(4, 4, 4), diri="left", mcs=4, rot=True),
+    # hierarchies of the edge-matrix setup: general 3x6 / 6x6 blocks in P instead of w Q(t)
+    "elast3d_5_bs3_edge_mats": dict(kind="elast", shape=(5, 4, 4), diri="left", mcs=4, rot=False, extra={"edge_mats": 1}),
+    "elast3d_4_bs6_edge_mats": dict(kind="elast", shape=(4, 4, 4), diri="left", mcs=4, rot=True,
+                                    extra={"edge_mats": 1, "crs_robust": 1, "sp_improve_its": 1}),
 }
 
 
@@ -47,13 +51,17 @@ def build(case):
         p = fem.elasticity_fast(case["shape"], dirichlet=case["diri"], mu=1.0, lam=0.5, rotations=case["rot"])
         energy = 1
         kw = {"regularize_cmats": 0 if case["rot"] else 1}
+        kw.update(case.get("extra", {}))
     A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
     H = Hierarchy(A, p.free, p.coords, dim=len(case["shape"]), energy=energy, max_coarse_size=case["mcs"], **kw)
     return p, H
 
 
 def main():
+    only = sys.argv[1:]          # python tests/golden/make_golden.py [names ...]: regenerate just these
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         p, H = build(case)
         d = {"n_levels": np.int64(H.n_levels), "bs0": np.int64(p.bs)}
         for l, L in enumerate(H.levels):

@@ -7,7 +7,8 @@ import numpy as np
 from ngsamg_amd._lib import Matrix
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["poisson2d_9", "poisson2d_17", "poisson3d_5", "poisson3d_9", "elast3d_4_bs3", "elast3d_4_bs6"]
+NAMES = ["poisson2d_9", "poisson2d_17", "poisson3d_5", "poisson3d_9", "elast3d_4_bs3", "elast3d_4_bs6",
+         "elast3d_5_bs3_edge_mats", "elast3d_4_bs6_edge_mats"]
 
 
 def load(name):

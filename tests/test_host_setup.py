@@ -769,3 +769,26 @@ def test_spw_pick_avg_and_diag_stab_boost():
         Hierarchy(B, q.free, q.coords, spw_pick_avg="median", **kw)
     with pytest.raises(NgsAMGError):
         Hierarchy(B, q.free, q.coords, spw_pick_avg=7, **kw)
+
+
+@pytest.mark.parametrize("name", ["elast3d_5_bs3_edge_mats", "elast3d_4_bs6_edge_mats"])
+def test_edge_matrix_setup_reproduces_its_golden_fixture(name):
+    """the committed fixtures of the edge-matrix setup (tests/golden/make_golden.py: edge_mats; edge_mats + crs_robust +
+    sp_improve_its) pin its prolongations and coarse operators against regressions"""
+    import importlib.util
+    import os
+    from tests import golden_io
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_io.GOLDEN_DIR, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    p, H = mg.build(mg.CASES[name])
+    z, levels = golden_io.load(name)
+    assert H.n_levels == len(levels)
+    for L, G in zip(H.levels, levels):
+        for tag in ("A", "P"):
+            M, F = getattr(L, tag), getattr(G, tag)
+            assert (M is None) == (F is None)
+            if M is None:
+                continue
+            assert np.array_equal(np.asarray(M.rowptr), np.asarray(F.rowptr)) and np.array_equal(np.asarray(M.col), np.asarray(F.col))
+            assert np.allclose(np.asarray(M.val), np.asarray(F.val), rtol=1e-10, atol=1e-12 * np.abs(np.asarray(F.val)).max())
