@@ -1887,6 +1887,41 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
             if (pr >= 0 && pc >= 0) D[pr * nfr + pc] = L.A.val[(k * bs + r) * bs + c];
           }
         }
+      // regularize_cmats on an elasticity hierarchy: the reference regularises the DIAGONAL BLOCKS of the coarsest matrix before it
+      // inverts it (CoarseLevelInv -> RegularizeMatrix, amg_pc.cpp:861-862; elasticity_pc_impl.hpp:710-764): 3D RegTM<0,6,6>
+      // (utils_denseLA.hpp:1198-1233): the smallest non-zero eigenvalue of the block is added along its kernel (identity if the
+      // block is zero); 2D: a rotation diagonal below 1e-8 becomes 1.  A block without kernel is left alone, so coarsest matrices
+      // that are positive definite -- every hierarchy the oracle accepts -- invert exactly as before.
+      if (o.regularize_cmats && o.energy == 1 && bs == dim + nrot) {
+        int64_t nreg = 0;
+        for (int64_t i = 0; i < L.A.n_rows; i++) {
+          if (!L.free[i]) continue;
+          const int64_t p0 = pos[i * bs];
+          auto at = [&](int r, int c) -> double& { return D[(size_t)(p0 + r) * nfr + (p0 + c)]; };     // free rows are contiguous per block
+          if (dim == 2) {
+            if (std::fabs(at(2, 2)) < 1e-8) { at(2, 2) = 1.0; nreg++; }
+            continue;
+          }
+          double M[36], ev[6], V[36];
+          for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) M[r * 6 + c] = 0.5 * (at(r, c) + at(c, r));
+          sym_eig(M, 6, ev, V);
+          double emax = ev[0];
+          for (int q = 1; q < 6; q++) emax = std::max(emax, ev[q]);
+          const double eps = std::max(1e-15, 1e-12 * emax);
+          double min_nz = 0.0;
+          int nzero = 0;
+          for (int q = 0; q < 6; q++) { if (ev[q] > eps) min_nz = (min_nz == 0.0) ? ev[q] : std::min(min_nz, ev[q]); else nzero++; }
+          if (nzero == 0) continue;
+          nreg++;
+          if (nzero < 6) {
+            for (int q = 0; q < 6; q++) if (!(ev[q] > eps))
+              for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) at(r, c) += min_nz * V[r * 6 + q] * V[c * 6 + q];
+          } else {
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) at(r, c) = r == c ? 1.0 : 0.0;
+          }
+        }
+        if (nreg) log << "  coarsest level: " << nreg << " diagonal block(s) regularised\n";
+      }
       bool chol = nfr > 0 ? spd_inverse(D.data(), (int)nfr) : true;
       if (!chol) log << "  coarse matrix not SPD: pseudo-inverse used\n";
       H->coarse_n = N;

@@ -792,3 +792,44 @@ def test_edge_matrix_setup_reproduces_its_golden_fixture(name):
                 continue
             assert np.array_equal(np.asarray(M.rowptr), np.asarray(F.rowptr)) and np.array_equal(np.asarray(M.col), np.asarray(F.col))
             assert np.allclose(np.asarray(M.val), np.asarray(F.val), rtol=1e-10, atol=1e-12 * np.abs(np.asarray(F.val)).max())
+
+
+def test_coarsest_level_regularisation_of_the_reference():
+    """regularize_cmats on an elasticity hierarchy: before the coarsest matrix is inverted its diagonal blocks are regularised as the
+    reference's CoarseLevelInv does (RegularizeMatrix / RegTM<0,6,6>, elasticity_pc_impl.hpp:710-764, utils_denseLA.hpp:1198-1233):
+    the smallest non-zero eigenvalue of a block is added along the block's kernel.  Two-vertex aggregates of a displacement-only
+    beam (no rotation about the pair's axis) give singular 6x6 blocks; the returned inverse is the inverse of the regularised
+    matrix, and a hierarchy whose coarsest blocks are regular is inverted exactly as without the rule."""
+    from ngsamg_amd.hierarchy import Hierarchy
+    p = fem.elasticity_fast((7, 2, 2), dirichlet="left", mu=1.0, lam=0.0, rotations=False)
+    A = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
+    H = Hierarchy(A, p.free, p.coords, dim=3, energy=1, max_levels=2, max_coarse_size=1, enable_sp=0, regularize_cmats=1, spw_rounds=1)
+    assert "diagonal block(s) regularised" in H.log
+    L = H.levels[-1]
+    Ac = L.A.to_scipy().toarray()
+    n, bs = L.n, L.bs
+    assert bs == 6 and H.coarse_n == n * bs
+    Areg = Ac.copy()
+    nsing = 0
+    for i in range(n):
+        blk = Ac[i * bs:(i + 1) * bs, i * bs:(i + 1) * bs]
+        ev, V = np.linalg.eigh(0.5 * (blk + blk.T))
+        eps = max(1e-15, 1e-12 * ev[-1])
+        zero = ev <= eps
+        if zero.any():
+            nsing += 1
+            mn = ev[~zero].min()
+            Areg[i * bs:(i + 1) * bs, i * bs:(i + 1) * bs] += mn * (V[:, zero] @ V[:, zero].T)
+    assert nsing > 0
+    inv = np.asarray(H.coarse_inv).reshape(n * bs, n * bs)
+    assert np.abs(inv @ Areg - np.eye(n * bs)).max() < 1e-8
+    assert np.linalg.eigvalsh(0.5 * (Areg + Areg.T))[0] > 0          # the regularised matrix is positive definite: Cholesky, no fallback
+    assert "pseudo-inverse used" not in H.log
+    # regular coarsest blocks: nothing changes
+    q = fem.elasticity_fast((9, 5, 5), dirichlet="left", mu=1.0, lam=0.0, rotations=False, extent=(2.0, 1.0, 1.0))
+    B = Matrix(q.n, q.n, q.bs, q.bs, q.rowptr, q.col, q.val)
+    G = Hierarchy(B, q.free, q.coords, dim=3, energy=1, max_coarse_size=10, regularize_cmats=1)
+    assert "regularised" not in G.log
+    Lc = G.levels[-1]
+    Acc = Lc.A.to_scipy().toarray()
+    assert np.abs(np.asarray(G.coarse_inv).reshape(Acc.shape) @ Acc - np.eye(Acc.shape[0])).max() < 1e-8
