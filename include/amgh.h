@@ -91,6 +91,11 @@ typedef struct amgh_options {
                              /*   soc = w / avg: 0 min, 1 geom, 2 harm, 3 alg, 4 max                                                                  */
   double spw_diag_stab_boost; /* ngs_amg_spw_diag_stab_boost (0.5; spw_agg.hpp:36-42), with crs_robust: share of the edges that vanish inside a pair  */
                              /*   that stays in the pair's aux diagonal (0: all removed, most matches; 1: all kept, most stable)                        */
+  int32_t carry_mesh;        /* own, default 0.  1: the alg-mesh (strength graph) of a coarse level is the CONTRACTED mesh of the level above -- an     */
+                             /*   edge between two aggregates that a fine edge connects, weight = the sum of those fine weights -- which is how the     */
+                             /*   reference's meshes descend (coarse maps of BlockTM, H1EData / AttachedEED map_data), instead of the graph of the     */
+                             /*   Galerkin matrix, whose rows the smoothed prolongation has widened (50-80 entries from level 1 on at cfg 2).          */
+                             /*   Changes aggregates and aux rows from level 1 on; edge_mats implies it for elasticity.                                */
 } amgh_options;
 
 typedef struct amgh_level {

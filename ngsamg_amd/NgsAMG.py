@@ -337,7 +337,7 @@ class _AMGPreconditioner:
         dim = int(f.get("dim", self._dim))
         opts = {k: f[k] for k in ("max_levels", "max_coarse_size", "first_aaf", "aaf", "enable_sp", "sp_omega",
                                   "sp_max_per_row", "sp_min_frac", "soc_thresh", "max_rounds", "log_level", "enable_multistep",
-                                  "robust_soc", "spw", "spw_rounds", "spw_orphan_treatment", "prol_type", "sp_max_per_row_classic", "edge_mats", "crs_robust", "spw_cbs", "sp_improve_its", "spw_pick_robust", "spw_neib_boost", "spw_pick_avg", "spw_diag_stab_boost") if k in f}
+                                  "robust_soc", "spw", "spw_rounds", "spw_orphan_treatment", "prol_type", "sp_max_per_row_classic", "edge_mats", "crs_robust", "spw_cbs", "sp_improve_its", "spw_pick_robust", "spw_neib_boost", "spw_pick_avg", "spw_diag_stab_boost", "carry_mesh") if k in f}
         opts.update(_energy_flag(f, self._energy, self._name))
         if self._energy == 1:
             rots = A.br > dim

@@ -41,7 +41,7 @@ class amgh_options(C.Structure):
                 ("max_rounds", C.c_int32), ("regularize_cmats", C.c_int32), ("dim", C.c_int32),
                 ("energy", C.c_int32), ("log_level", C.c_int32), ("enable_multistep", C.c_int32), ("robust_soc", C.c_int32),
                 ("spw", C.c_int32), ("spw_rounds", C.c_int32), ("spw_orphan_round", C.c_int32),
-                ("prol_type", C.c_int32), ("sp_max_per_row_classic", C.c_int32), ("edge_mats", C.c_int32), ("crs_robust", C.c_int32), ("spw_cbs", C.c_int32), ("sp_improve_its", C.c_int32), ("prol_only", C.c_int32), ("spw_pick_robust", C.c_int32), ("spw_neib_boost", C.c_int32), ("spw_pick_avg", C.c_int32), ("spw_diag_stab_boost", C.c_double)]
+                ("prol_type", C.c_int32), ("sp_max_per_row_classic", C.c_int32), ("edge_mats", C.c_int32), ("crs_robust", C.c_int32), ("spw_cbs", C.c_int32), ("sp_improve_its", C.c_int32), ("prol_only", C.c_int32), ("spw_pick_robust", C.c_int32), ("spw_neib_boost", C.c_int32), ("spw_pick_avg", C.c_int32), ("spw_diag_stab_boost", C.c_double), ("carry_mesh", C.c_int32)]
 
 
 class amgh_level(C.Structure):

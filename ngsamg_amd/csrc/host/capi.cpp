@@ -98,6 +98,7 @@ void amgh_default_options(amgh_options* o, int dim, int energy) {
   o->spw_pick_robust = 1;
   o->spw_neib_boost = 1;
   o->spw_pick_avg = 1;
+  o->carry_mesh = 0;
   o->spw_diag_stab_boost = 0.5;
   o->prol_only = 0;
 }
@@ -118,7 +119,8 @@ int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* 
     o.prol_type = opts->prol_type; o.sp_max_per_row_classic = opts->sp_max_per_row_classic;
     o.edge_mats = opts->edge_mats; o.crs_robust = opts->crs_robust;
     o.spw_pick_robust = opts->spw_pick_robust; o.spw_neib_boost = opts->spw_neib_boost;
-    o.spw_pick_avg = opts->spw_pick_avg; o.spw_diag_stab_boost = opts->spw_diag_stab_boost;
+    o.spw_pick_avg = opts->spw_pick_avg; o.spw_diag_stab_boost = opts->spw_diag_stab_boost; o.carry_mesh = opts->carry_mesh;
+    if (o.carry_mesh && (!o.spw || o.enable_multistep)) throw amgh::Error("amgh_setup: carry_mesh needs spw = 1 and enable_multistep = 0");
     if (o.spw_pick_avg < 0 || o.spw_pick_avg > 4) throw amgh::Error("amgh_setup: spw_pick_avg must be 0 (min), 1 (geom), 2 (harm), 3 (alg) or 4 (max)");
     o.spw_cbs = opts->spw_cbs; o.sp_improve_its = opts->sp_improve_its; o.prol_only = opts->prol_only;
     if (o.prol_only && o.enable_multistep) throw amgh::Error("amgh_setup: prol_only takes one step (enable_multistep = 0)");

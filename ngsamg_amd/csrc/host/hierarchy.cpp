@@ -1698,6 +1698,8 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
   // edge_mats: the alg-mesh (edges with the energy's matrices) is carried from level to level beside the matrices
   const bool emats = o.edge_mats && o.energy == 1;
   if (emats && (!o.spw || o.robust_soc)) throw Error("edge_mats needs the SPW agglomerator (spw = 1, robust_soc = 0)");
+  const bool carry = o.carry_mesh && !emats;
+  if (carry && (!o.spw || o.robust_soc)) throw Error("carry_mesh needs the SPW agglomerator (spw = 1, robust_soc = 0)");
   Graph mesh;
   std::vector<double> meshE;
   while (true) {
@@ -1742,8 +1744,12 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
       };
       while (true) {
         if (emats && lev == 0 && substeps == 0) mesh = fine_edge_mats(*curA, cur_free, cur_coords, dim, meshE);
-        Graph G = emats ? std::move(mesh) : strength_graph(*curA, cur_free, dim, o.energy);
-        lap(emats ? "alg-mesh (edge matrices)" : "strength graph");
+        // carry_mesh: the alg-mesh of a coarse level is the contracted mesh of the level above (edges between aggregates, weights
+        // summed: BlockTM coarse maps, H1EData::map_data), not the graph of the Galerkin matrix, whose stencil the smoothed
+        // prolongation has widened
+        const bool carried = carry && !(lev == 0 && substeps == 0);
+        Graph G = (emats || carried) ? std::move(mesh) : strength_graph(*curA, cur_free, dim, o.energy);
+        lap(emats ? "alg-mesh (edge matrices)" : carried ? "alg-mesh (carried)" : "strength graph");
         if (o.robust_soc) { G.vs = cur_vs; G.vs.resize(G.n, 0.0); }
         const double step_target = (o.enable_multistep && target < o.aaf) ? std::max(target, o.aaf) : target;
         std::vector<int32_t> sagg;
@@ -1787,6 +1793,9 @@ Hierarchy* setup_levels(const BCSR& A0, const uint8_t* free0, const double* coor
           std::vector<double> nextE;
           mesh = contract_edge_mats(G, meshE, dim, sagg, snc, cur_coords, sxc, nextE);
           meshE = std::move(nextE);
+        } else if (carry) {
+          G.vs.clear();
+          mesh = contract(G, sagg, snc);
         }
         if (o.sp_improve_its > 0 && op.enable_sp) {
           improve_prolongation(*curA, Pk, sagg, sxc, dim, o.energy, o.sp_omega, o.sp_improve_its);

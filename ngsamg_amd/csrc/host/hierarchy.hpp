@@ -34,6 +34,7 @@ struct Options {
   int spw_neib_boost = 1;        // ngs_amg_spw_neib_boost (spw_agg.hpp:27): neighbour boost of the robust edge matrix
   int spw_pick_avg = 1;          // ngs_amg_spw_pick_avg: 0 min, 1 geom, 2 harm, 3 alg, 4 max (spw_agg.hpp:22, 62-65)
   double spw_diag_stab_boost = 0.5;   // ngs_amg_spw_diag_stab_boost (spw_agg.hpp:42): crs_robust, share of the in-aggregate edges kept in the carried aux diagonals
+  int carry_mesh = 0;            // coarse alg-meshes by contraction of the finer one instead of the Galerkin matrix's graph (amgh.h)
   int edge_mats = 0;             // elasticity: carry the energy's edge matrices, matrix-valued smoothed prolongation (amgh.h)
   double soc_thresh = 0.25;      // relative strength threshold for a viable partner
   int max_rounds = 8;            // hard cap of pairwise rounds per level

@@ -91,7 +91,7 @@ _OPTION_KEYS = {
     "max_levels": int, "max_coarse_size": int, "first_aaf": float, "aaf": float, "enable_sp": int,
     "sp_omega": float, "sp_max_per_row": int, "sp_min_frac": float, "soc_thresh": float, "max_rounds": int,
     "regularize_cmats": int, "log_level": int, "enable_multistep": int, "robust_soc": int,
-    "spw": int, "spw_rounds": int, "spw_orphan_round": int, "prol_type": int, "sp_max_per_row_classic": int, "edge_mats": int, "crs_robust": int, "spw_cbs": int, "sp_improve_its": int, "prol_only": int, "spw_pick_robust": int, "spw_neib_boost": int, "spw_pick_avg": int, "spw_diag_stab_boost": float,
+    "spw": int, "spw_rounds": int, "spw_orphan_round": int, "prol_type": int, "sp_max_per_row_classic": int, "edge_mats": int, "crs_robust": int, "spw_cbs": int, "sp_improve_its": int, "prol_only": int, "spw_pick_robust": int, "spw_neib_boost": int, "spw_pick_avg": int, "spw_diag_stab_boost": float, "carry_mesh": int,
 }
 _PICK_AVGS = {"min": 0, "geom": 1, "harm": 2, "alg": 3, "max": 4}        # spw_agg.hpp:62-65
 _PROL_TYPES = {"piecewise": 0, "aux_smoothed": 1, "semi_aux_smoothed": 2, "own": 3}        # vertex_factory_impl.hpp:123-125

@@ -833,3 +833,27 @@ def test_coarsest_level_regularisation_of_the_reference():
     Lc = G.levels[-1]
     Acc = Lc.A.to_scipy().toarray()
     assert np.abs(np.asarray(G.coarse_inv).reshape(Acc.shape) @ Acc - np.eye(Acc.shape[0])).max() < 1e-8
+
+
+def test_carried_alg_mesh_gives_an_equivalent_hierarchy():
+    """carry_mesh: coarse alg-meshes by contraction of the finer mesh (the reference's way) instead of the Galerkin matrix's graph:
+    level 0 is untouched, the coarse levels coarsen at the same rate, the hierarchy is Galerkin and as good a preconditioner"""
+    from ngsamg_amd.hierarchy import Hierarchy
+    from oracle.pyoracle import Oracle
+    p = fem.poisson_fast((20, 20, 20), dirichlet="right|top", jitter=0.2, seed=1)
+    A = Matrix(p.n, p.n, 1, 1, p.rowptr, p.col, p.val)
+    H0 = Hierarchy(A, p.free, p.coords, dim=3, energy=0, max_coarse_size=20)
+    H1 = Hierarchy(A, p.free, p.coords, dim=3, energy=0, max_coarse_size=20, carry_mesh=1)
+    assert np.array_equal(np.asarray(H0.levels[0].P.val), np.asarray(H1.levels[0].P.val)) and H0.levels[1].n == H1.levels[1].n
+    assert H1.n_levels >= 3 and not np.array_equal(np.asarray(H0.levels[1].agg), np.asarray(H1.levels[1].agg))
+    assert abs(H1.levels[2].n - H0.levels[2].n) <= 0.1 * H0.levels[2].n
+    for l in range(H1.n_levels - 1):
+        P = H1.levels[l].P.to_scipy()
+        Ac = H1.levels[l + 1].A.to_scipy()
+        assert abs(Ac - P.T @ H1.levels[l].A.to_scipy() @ P).max() < 1e-10 * abs(Ac).max()
+    b = np.random.default_rng(1).standard_normal(p.n) * p.free
+    it0 = Oracle(H0.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=100)[1]
+    it1 = Oracle(H1.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=100)[1]
+    assert abs(it1 - it0) <= 2
+    with pytest.raises(NgsAMGError):
+        Hierarchy(A, p.free, p.coords, dim=3, energy=0, carry_mesh=1, spw=0)
