@@ -111,6 +111,9 @@ typedef struct amgh_level {
 typedef struct amgh_hierarchy amgh_hierarchy;
 
 const char* amgh_last_error(void);
+/* Fills EVERY field with the library default for the problem class.  Callers start from it and then override single fields: the
+ * struct grows at its end from round to round (zero is not the default of every field: spw, spw_rounds, spw_pick_robust,
+ * spw_neib_boost, spw_pick_avg = 1 (geom), spw_diag_stab_boost = 0.5, prol_type = -1, ...). */
 void amgh_default_options(amgh_options* o, int dim, int energy);
 
 int amgh_setup(const amgh_matrix* A, const uint8_t* free_or_null, const double* coords_or_null,
