@@ -309,10 +309,10 @@ def test_block_levels_hgs_smoother_flags_and_iterations(rot):
             if ur:
                 f = fr.astype(bool)
                 assert np.linalg.norm((res - ro)[f]) <= 1e-9 * max(np.linalg.norm(ro[f]), 1.0)
-    # symmetric preconditioner, and PCG needs at most 20 % more iterations than with the reference's sequential order
+    # symmetric preconditioner, and PCG stays inside SURVEY 8d's +15 % of the reference's sequential order (13 / 11 and 15 / 13 here)
     u, v = rng.standard_normal(n) * fr, rng.standard_normal(n) * fr
     assert abs(np.dot(v, dev.apply(u)) - np.dot(u, dev.apply(v))) <= 1e-10 * abs(np.dot(v, dev.apply(u)))
     b = rng.standard_normal(n) * fr
     it_h = orc.pcg(b, tol=1e-8, maxit=200)[1]
     it_seq = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=200)[1]
-    assert it_h <= int(np.ceil(1.2 * it_seq)) + 1
+    assert it_h <= int(np.ceil(1.15 * it_seq)), (it_h, it_seq)

@@ -857,3 +857,22 @@ def test_carried_alg_mesh_gives_an_equivalent_hierarchy():
     assert abs(it1 - it0) <= 2
     with pytest.raises(NgsAMGError):
         Hierarchy(A, p.free, p.coords, dim=3, energy=0, carry_mesh=1, spw=0)
+
+
+@pytest.mark.parametrize("rot", [False, True])
+def test_default_gpu_gauss_seidel_order_of_block_levels_is_inside_the_tolerance(rot):
+    """the order data DeviceAMGMatrix hands to the device for sm_type = hgs (ngsamg_amd.device.hierarchy_desc: host code) on the
+    elasticity toy of tests/test_gpu_hgs.py, replayed by the oracle: PCG iterations within ceil(1.15 x) of the sequential order"""
+    from ngsamg_amd.device import hierarchy_desc
+    from oracle.pyoracle import Oracle
+    from tests.problems import elasticity_case
+    from tests.hgs_oracle import hgs_levels
+    p, H = elasticity_case((16, 14, 12), rotations=rot, max_coarse_size=10)
+    _, _, hgs = hierarchy_desc(H, "hgs")
+    lv, types = hgs_levels(H.levels, hgs)
+    fr = np.repeat(p.free, p.bs).astype(np.float64)
+    for seed in range(3):
+        b = np.random.default_rng(seed).standard_normal(p.n * p.bs) * fr
+        it_h = Oracle(lv, sm_type=types).pcg(b, tol=1e-8, maxit=200)[1]
+        it_seq = Oracle(H.levels, sm_type="gs").pcg(b, tol=1e-8, maxit=200)[1]
+        assert it_h <= int(np.ceil(1.15 * it_seq)), (it_h, it_seq)
