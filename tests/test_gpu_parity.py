@@ -148,7 +148,7 @@ def test_pcg_iteration_parity_cfg1():
     assert cg.errors[-1] < 1e-12 * cg.errors[0] * 10
     assert cg.iterations < 100
     # multicolour GS (GPU ordering) vs the reference's sequential ordering: within +15 %
-    assert cg.iterations <= int(np.ceil(1.15 * it_seq)) + 1
+    assert cg.iterations <= int(np.ceil(1.15 * it_seq)), (cg.iterations, it_seq)        # (oracle: 24 multicolour, 24 sequential)
 
 
 def test_create_errors():
@@ -475,7 +475,7 @@ def test_block_gs_pcg_iterations_and_registry():
     dev = _dev(H, sm_type="bgs")
     cg = CGSolver(dev, dev, tol=1e-6, maxsteps=100)
     cg.Solve(torch.from_numpy(p.load).cuda())
-    assert cg.iterations <= int(np.ceil(1.15 * it_ref)) + 1 and cg.errors[-1] < 1e-5 * cg.errors[0]
+    assert cg.iterations <= int(np.ceil(1.15 * it_ref)) and cg.errors[-1] < 1e-5 * cg.errors[0]       # (oracle: 10 in both orders)
     a = Matrix(p.n, p.n, p.bs, p.bs, p.rowptr, p.col, p.val)
     pre = ngs_amg.elast_3d(a, p.free, coords=p.coords, ngs_amg_sm_type="bgs", ngs_amg_max_coarse_size=5, ngs_amg_first_aaf=0.12)
     amg = pre.GetAMGMatrix()
